@@ -1,0 +1,71 @@
+// zs3hip -- shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.
+// Wave size is 64 everywhere; MFMA shapes used: v_mfma_f32_32x32x16_bf16 and v_mfma_f32_32x32x2_f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define ZS3_WAVE 64
+
+// ---- split-bf16 ("bf16x3") arithmetic ---------------------------------------------------------
+// An fp32 value x is carried through the matrix cores as hi + lo with hi = bf16(x) and
+// lo = bf16(x - hi); a product is hi*hi + hi*lo + lo*hi (three bf16 MFMAs, fp32 accumulate), the
+// dropped lo*lo term is <= 2^-16 |a b|.  Activations are split while they are staged into LDS
+// (hi by truncation: one bit-op, the remainder x - hi is exact in fp32 and lo rounds it to
+// nearest-even); weights are split once per step by zs3_prep_weight (both halves round-to-nearest).
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // {bf16(a) low half, bf16(b) high half}, RNE
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned pack_hi_trunc(float a, float b) {
+  return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+}
+__device__ __forceinline__ float trunc_bf16_f32(float a) { return __uint_as_float(__float_as_uint(a) & 0xFFFF0000u); }
+
+template <int PREC>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  if (PREC == 1) {
+    hi = cvt_pk_bf16(a, b);
+    lo = 0u;
+  } else {
+    hi = pack_hi_trunc(a, b);
+    lo = cvt_pk_bf16(a - trunc_bf16_f32(a), b - trunc_bf16_f32(b));
+  }
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks that land on one XCD (id % 8) get a contiguous
+// chunk of logical tile ids, so tiles that share an operand panel hit the same (private) L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int nx = 8;
+  int xcd = bid % nx, slot = bid / nx;
+  int q = nblk / nx, r = nblk % nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+#define ZS3_LAUNCH_CHECK() ((int)hipGetLastError())

@@ -1,0 +1,85 @@
+// Operand preparation kernels: bf16 hi/lo split of weights (forward and transposed-for-dgrad
+// layouts), NCHW -> padded NHWC4 image conversion for the 7x7 stem.
+#include "common.h"
+#include "zs3hip.h"
+
+namespace {
+
+// w: [cout][taps][cin] fp32 (the channels_last storage of an OIHW parameter).
+// fwd planes : [cout][taps][cin_pad]            (k = (tap, ci), zero padded channels)
+// dgrad planes: [cin][taps][cout_pad]           (k = (tap, co))
+__global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ f_hi,
+                                   unsigned short* __restrict__ f_lo, unsigned short* __restrict__ t_hi,
+                                   unsigned short* __restrict__ t_lo, int cout, int taps, int cin, int cin_pad,
+                                   int cout_pad) {
+  const long nf = (long)cout * taps * cin_pad;
+  const long nt = t_hi ? (long)cin * taps * cout_pad : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nt; i += (long)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    unsigned short *dh, *dl;
+    if (i < nf) {
+      int ci = (int)(i % cin_pad);
+      long r = i / cin_pad;
+      int tap = (int)(r % taps), co = (int)(r / taps);
+      if (ci < cin) v = w[((long)co * taps + tap) * cin + ci];
+      dh = f_hi + i;
+      dl = f_lo + i;
+    } else {
+      long k = i - nf;
+      int co = (int)(k % cout_pad);
+      long r = k / cout_pad;
+      int tap = (int)(r % taps), ci = (int)(r / taps);
+      if (co < cout) v = w[((long)co * taps + tap) * cin + ci];
+      dh = t_hi + k;
+      dl = t_lo + k;
+    }
+    unsigned short h = f32_to_bf16_rne(v);
+    *dh = h;
+    *dl = f32_to_bf16_rne(v - bf16_bits_to_f32(h));
+  }
+}
+
+// img: [N][3][H][W] fp32 (NCHW) -> out: [N][H][Wp][4] with the image at columns [left, left+W) and
+// zeros elsewhere (4th channel zero).  Feeds the 7x7/s2 stem as a 7x1 conv over 32-float windows.
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int N, int H, int W,
+                                      int Wp, int left) {
+  const long total = (long)N * H * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int wp = (int)(i % Wp);
+    long r = i / Wp;
+    int h = (int)(r % H), n = (int)(r / H);
+    int w = wp - left;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (w >= 0 && w < W) {
+      const float* src = img + ((long)n * 3 * H + h) * W + w;
+      v[0] = src[0];
+      v[1] = src[(long)H * W];
+      v[2] = src[2L * H * W];
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int zs3_prep_weight(const float* w, void* f_hi, void* f_lo, void* t_hi, void* t_lo, int cout, int taps,
+                               int cin, int cin_pad, int cout_pad, void* stream) {
+  long total = (long)cout * taps * cin_pad + (t_hi ? (long)cin * taps * cout_pad : 0);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)f_hi,
+                     (unsigned short*)f_lo, (unsigned short*)t_hi, (unsigned short*)t_lo, cout, taps, cin, cin_pad,
+                     cout_pad);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_nchw3_to_nhwc4(const float* img, float* out, int N, int H, int W, int Wp, int left, void* stream) {
+  long total = (long)N * H * Wp;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, out, N, H, W, Wp,
+                     left);
+  return ZS3_LAUNCH_CHECK();
+}
