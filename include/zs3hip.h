@@ -43,6 +43,92 @@ int zs3_conv_igemm(const float* x, const void* w_hi, const void* w_lo, float* y,
                    int tile_cfg, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
 
+/* ---- weight gradient ------------------------------------------------------------------------- */
+/* dw[co][kh][kw][ci] = sum_m dy[m][co] * x[gather(m,kh,kw)][ci]  (channels_last weight layout).
+ * dy: [M][lddy] with co_read (multiple of 4) readable channels of which co_write rows are produced;
+ * x likewise (ci_read / ci_write).  Split-K over pixels: call zs3_conv_wgrad_plan for the workspace
+ * size (floats), pass NULL when it returns 0.  Replaces convolution_backward(weight) of the same
+ * call sites as zs3_conv_igemm. */
+int zs3_conv_wgrad_plan(int M, int co, int ci, int taps, int* splitk_out, long* workspace_floats);
+int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int Ho, int Wo,
+                   int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read, int co_write, int ci_read,
+                   int ci_write, int lddy, int ldx, int prec, void* stream);
+
+/* ---- BatchNorm / ReLU / residual (bn.hip) ---------------------------------------------------- */
+/* Replaces native_batch_norm fwd/bwd, relu_, threshold_backward, residual add_ at resnet.py:33-53,
+ * aspp.py:25-29,111-116, decoder.py:30-32,15-24.  Partial-sum buffers are [chunks][2][C] floats. */
+int zs3_colstats_plan(int M, int C, int* chunks, int* rows_per_block);
+int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, void* stream);
+int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
+                     const float* invstd, int M, int C, float* partial, void* stream);
+int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const float* gamma, const float* beta,
+                        float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
+                        float* invstd_out, float* scale_out, float* shift_out, void* stream);
+int zs3_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int C, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
+                       void* stream);
+int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, float* dgamma, float* dbeta, float* c1,
+                        float* c2, int use_batch_stats, void* stream);
+/* out[m][c] = act(alpha*(x[m/div][c]*scale[c] + shift[c]) + res[m][c]) (+= if accumulate); act 0/1/2 */
+int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shift, float alpha, const float* res,
+                   int ldr, float* out, int ldo, long M, int C, int div, int act, float leak, int accumulate,
+                   void* stream);
+/* dz = act'(a_out)*dA; dres (=|+=) dz; dy = gamma*invstd*(dz - c1 - xhat*c2)  (c1==NULL: dy = gamma*invstd*dz) */
+int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
+                   const float* invstd, const float* gamma, const float* c1, const float* c2, float* dy, int ldo,
+                   float* dres, int ldr, int dres_accumulate, long M, int C, int act, float leak, void* stream);
+/* out[g][c] = scale * sum_{r<R} x[g*R + r][c]: AdaptiveAvgPool2d((1,1)) of aspp.py:85 and its broadcast backward */
+int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo, void* stream);
+
+/* ---- pooling / resize (pool_resize.hip) ------------------------------------------------------- */
+/* nn.MaxPool2d(3,2,1) of resnet.py:82 (idx: one byte per output element, the winning tap) */
+int zs3_maxpool_fwd(const float* x, int ldx, float* out, int ldo, void* idx, int N, int H, int W, int Ho, int Wo, int C,
+                    int K, int stride, int pad, void* stream);
+int zs3_maxpool_bwd(const float* dy, int ldd, const void* idx, float* dx, int ldo, int N, int H, int W, int Ho, int Wo,
+                    int C, int K, int stride, int pad, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=True) of aspp.py:109, decoder.py:34-36, deeplab.py:44,55 */
+int zs3_bilinear_fwd(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int Ho, int Wo, int C,
+                     void* stream);
+int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int H, int W, int Ho, int Wo, int C,
+                     int accumulate, void* stream);
+
+/* ---- losses (loss.hip) ------------------------------------------------------------------------ */
+/* SegmentationLosses.CrossEntropyLoss (zs3/utils/loss.py:31-46): logits [P][ld] (P = B*H*W pixels, C classes),
+ * target float32 or int64 [P]; loss_ws[0] = loss, loss_ws[1] = sum of weights; partial_ws: zs3_ce_ws_doubles()
+ * doubles.  batch = B for batch_average, 0 for none.  gout: device scalar (upstream gradient). */
+int zs3_ce_ws_doubles(void);
+int zs3_ce_fwd(const float* logits, int ld, const void* target, int target_is_i64, const float* weight, long P, int C,
+               int ignore_index, int batch, double* partial_ws, float* loss_ws, void* stream);
+int zs3_ce_bwd(const float* logits, int ld, const void* target, int target_is_i64, const float* weight, long P, int C,
+               int ignore_index, int batch, const float* loss_ws, const float* gout, float* dlogits, int ldo,
+               void* stream);
+/* GMMNLoss.moment_loss (zs3/utils/loss.py:92-115) for M == N samples of dimension D (even).  sigma: HOST array.
+ * G: [2N][2N] floats kept for backward; tile_ws: 2*ceil(2N/32)^2 doubles; loss: device scalar. */
+int zs3_mmd_fwd(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* sigma, int nsig,
+                float* G, double* tile_ws, float* loss, void* stream);
+int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G, const float* loss,
+                const float* gout, float* dgen, int ldo, void* stream);
+
+/* ---- GMMN step helpers and optimisers (misc.hip) ---------------------------------------------- */
+/* nn.Dropout (aspp.py:100, decoder.py:19,23, gmmn.py:20): y = keep ? x/(1-p) : 0 with a counter-based mask
+ * that is a pure function of (seed, element index); the backward is the same call on dy. */
+int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
+                void* stream);
+int zs3_uniform(float* out, long n, unsigned long long seed, void* stream);
+/* F.interpolate(mode="nearest") of one [C][H][W] image into pixel rows [ho*wo][ldo] (train_pascal_GMMN.py:175-195) */
+int zs3_nearest_rows(const float* src, int C, int H, int W, int ho, int wo, float* rows, int ldo, void* stream);
+/* out[r] = [a[idx[r]][0:Ca] | b[r][0:Cb] | 0...]: torch.cat((embd, noise), 1) of gmmn.py:44 fused with the class mask */
+int zs3_gather_cat(const float* a, int lda, const long* idx, int Ca, const float* b, int ldb, int Cb, float* out,
+                   int ldo, long n, void* stream);
+int zs3_gather_rows(const float* src, int lds, const long* idx, float* out, int ldo, long n, int C, void* stream);
+int zs3_scatter_rows(const float* src, int lds, const long* idx, float* out, int ldo, long n, int C, void* stream);
+int zs3_index_add_rows(const float* src, int lds, const long* idx, float* out, int ldo, int n, int C, void* stream);
+/* torch.optim.SGD (train_pascal.py:55-60) and torch.optim.Adam (train_pascal_GMMN.py:65-67) update rules */
+int zs3_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, int nesterov,
+                 int first, void* stream);
+int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                  float wd, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

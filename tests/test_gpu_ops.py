@@ -1,0 +1,191 @@
+"""GPU parity of the individual HIP ops against the CPU oracle arithmetic (plain torch fp64/fp32 on CPU).
+Everything here calls through the C ABI (libzs3hip.so)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+CONV_CASES = [  # N,H,W,Cin,Cout,k,stride,dil
+    (2, 33, 33, 256, 256, 3, 1, 1), (2, 33, 33, 512, 512, 3, 1, 4), (2, 65, 65, 128, 128, 3, 2, 1),
+    (3, 17, 19, 64, 256, 1, 1, 1), (2, 65, 65, 256, 512, 1, 2, 1), (2, 17, 17, 2048, 256, 3, 1, 18),
+    (1, 67, 65, 304, 256, 3, 1, 1), (2, 9, 9, 256, 48, 1, 1, 1), (2, 40, 40, 256, 21, 1, 1, 1),
+    (1, 1, 700, 600, 256, 1, 1, 1), (5, 1, 1, 2048, 256, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    from zs3_amd import ops
+    n, h, w, ci, co, k, s, d = case
+    g = torch.Generator().manual_seed(n * h + ci + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    pad = d * (k // 2)
+    xr = x.double().requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=s, padding=pad, dilation=d)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    xg = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    wp = ops.prep_weight(wt.to(dev))
+    y, st = ops.conv2d_fwd(xg, wp, s, pad, d, want_stats=True)
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5
+    ssum = st[:, 0].double().sum(0).cpu()
+    assert ((ssum - ref.detach().sum((0, 2, 3))).abs().max() / ref.detach().abs().sum((0, 2, 3)).max()).item() < 1e-5
+    from zs3_amd.functional import _pad_channels
+    dyg = _pad_channels(dy.to(dev).permute(0, 2, 3, 1).contiguous(), 8)
+    dx = ops.conv2d_dgrad(dyg, wp, (h, w), s, pad, d)
+    assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 5e-5
+    dw = ops.conv2d_wgrad(dyg, xg, co, ci, k, k, s, pad, pad, d)
+    assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 5e-5
+
+
+@pytest.mark.parametrize("shape,res,relu,train", [((2, 17, 19, 64), True, True, True), ((3, 9, 9, 48), False, True, True),
+                                                  ((2, 5, 5, 2048), True, True, True), ((4, 1, 1, 256), False, True, True),
+                                                  ((2, 17, 19, 64), True, True, False), ((2, 8, 8, 1280), False, False, True)])
+def test_conv_bn_act_function(dev, shape, res, relu, train):
+    """fused conv1x1 + BN(train/eval) + residual + ReLU node vs torch autograd in fp64"""
+    import torch.nn as nn
+    from zs3_amd import functional as Fz
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(c + h)
+    cin = 64
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(c, cin, 1, 1, generator=g) / 8
+    r = torch.randn(n, c, h, w, generator=g)
+    bn = nn.BatchNorm2d(c)
+    bn.weight.data = torch.rand(c, generator=g) + 0.5
+    bn.bias.data = torch.randn(c, generator=g) * 0.1
+    bn.running_mean.data = torch.randn(c, generator=g) * 0.1
+    bn.running_var.data = torch.rand(c, generator=g) + 0.5
+    bn.train(train)
+    import copy
+    bn64 = copy.deepcopy(bn).double()
+    x64, w64, r64 = x.double().requires_grad_(True), wt.double().requires_grad_(True), r.double().requires_grad_(True)
+    o = bn64(F.conv2d(x64, w64))
+    if res:
+        o = o + r64
+    if relu:
+        o = F.relu(o)
+    up = torch.randn(o.shape, generator=g)
+    o.backward(up.double())
+    bng = copy.deepcopy(bn).to(dev)
+    xg = x.to(dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    wg = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = r.to(dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    og = Fz.conv_bn_act(xg, wg, bn=bng, residual=rg if res else None, act=Fz.ACT_RELU if relu else Fz.ACT_NONE)
+    og.backward(up.to(dev).permute(0, 2, 3, 1).contiguous())
+    assert rel(og.permute(0, 3, 1, 2), o) < 1e-4
+    assert rel(xg.grad.permute(0, 3, 1, 2), x64.grad) < 2e-4
+    assert rel(wg.grad, w64.grad) < 2e-4
+    assert rel(bng.weight.grad, bn64.weight.grad) < 2e-4
+    assert rel(bng.bias.grad, bn64.bias.grad) < 2e-4
+    if res:
+        assert rel(rg.grad.permute(0, 3, 1, 2), r64.grad) < 1e-5
+    if train:
+        assert rel(bng.running_mean, bn64.running_mean) < 1e-4
+        assert rel(bng.running_var, bn64.running_var) < 1e-4
+
+
+def test_maxpool_bilinear(dev):
+    from zs3_amd import functional as Fz
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 33, 35, generator=g)
+    x[0, 0, 4:7, 4:7] = 1.5  # ties: first maximum must win
+    x64 = x.double().requires_grad_(True)
+    o = F.max_pool2d(x64, 3, 2, 1)
+    up = torch.randn(o.shape, generator=g)
+    o.backward(up.double())
+    xg = x.to(dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    og = Fz.max_pool(xg, 3, 2, 1)
+    og.backward(up.to(dev).permute(0, 2, 3, 1).contiguous())
+    assert rel(og.permute(0, 3, 1, 2), o) == 0.0
+    assert rel(xg.grad.permute(0, 3, 1, 2), x64.grad) < 1e-6
+    for (c, hin, win, hout, wout) in [(256, 9, 9, 33, 33), (21, 17, 17, 65, 65), (256, 1, 1, 9, 9), (8, 5, 7, 11, 30)]:
+        x = torch.randn(2, c, hin, win, generator=g)
+        x64 = x.double().requires_grad_(True)
+        o = F.interpolate(x64, size=(hout, wout), mode="bilinear", align_corners=True)
+        up = torch.randn(o.shape, generator=g)
+        o.backward(up.double())
+        xg = x.to(dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+        og = Fz.bilinear(xg, (hout, wout))
+        og.backward(up.to(dev).permute(0, 2, 3, 1).contiguous())
+        assert rel(og.permute(0, 3, 1, 2), o) < 2e-6
+        assert rel(xg.grad.permute(0, 3, 1, 2), x64.grad) < 2e-6
+
+
+def test_cross_entropy(dev):
+    import zs3_oracle as zo
+    from zs3_amd.utils.loss import SegmentationLosses
+    g = torch.Generator().manual_seed(5)
+    for c in (21, 60):
+        logit = torch.randn(3, c, 33, 37, generator=g) * 3
+        tgt = torch.randint(0, c, (3, 33, 37), generator=g).float()
+        tgt[:, :4] = 255
+        w = torch.ones(c)
+        w[[10, 14]] = 100.0
+        for weight in (None, w):
+            for mode in ("ce", "focal", "ce_finetune"):
+                l64 = logit.double().requires_grad_(True)
+                ref = zo.SegmentationLosses(weight=None if weight is None else weight.double()).build_loss(mode)(l64, tgt)
+                ref.backward()
+                lg = logit.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                out = SegmentationLosses(weight=None if weight is None else weight.to(dev), cuda=True).build_loss(mode)(lg, tgt.to(dev))
+                out.backward()
+                assert abs(out.item() - ref.item()) < 2e-6 * abs(ref.item()) + 1e-7, (c, mode)
+                assert rel(lg.grad, l64.grad) < 2e-5, (c, mode)
+        # int64 targets and NCHW-contiguous logits are accepted too
+        lg = logit.to(dev)
+        out = SegmentationLosses(cuda=True).build_loss("ce")(lg, tgt.long().to(dev))
+        ref = zo.SegmentationLosses().build_loss("ce")(logit.double(), tgt)
+        assert abs(out.item() - ref.item()) < 2e-6 * abs(ref.item())
+
+
+def test_mmd_against_golden_and_oracle(dev, golden):
+    import zs3_oracle as zo
+    from zs3_amd.utils.loss import GMMNLoss
+    g = golden("mmd.npz")
+    crit = GMMNLoss(cuda=True).build_loss()
+    for name in ("rand128", "far128", "small4", "near128"):
+        gen = torch.from_numpy(g[f"{name}_gen"]).to(dev).requires_grad_(True)
+        real = torch.from_numpy(g[f"{name}_real"]).to(dev)
+        loss = crit(gen, real)
+        loss.backward()
+        ref = float(g[f"{name}_loss"])
+        assert abs(loss.item() ** 2 - ref ** 2) <= 2e-6, name  # absolute on loss^2: E_ij cancels catastrophically
+        g64 = torch.from_numpy(g[f"{name}_gen"]).double().requires_grad_(True)
+        zo.mmd_loss(g64, torch.from_numpy(g[f"{name}_real"]).double()).backward()
+        assert rel(gen.grad, g64.grad) < 5e-4, name
+    real = torch.randn(128, 256, generator=torch.Generator().manual_seed(5)).to(dev)
+    assert crit(real.clone(), real).item() == 0.0  # identical inputs -> exactly 0, like the reference
+
+
+def test_dropout_statistics_and_backward(dev):
+    from zs3_amd import functional as Fz
+    Fz.manual_seed(123)
+    x = torch.ones(4, 33, 33, 256, device=dev, requires_grad=True)
+    y = Fz.dropout(x, 0.5, True)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.5) < 5e-3
+    assert torch.all((y == 0) | (y == 2.0))
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad, y.detach())
+    assert Fz.dropout(x, 0.5, False) is x
+    Fz.manual_seed(123)
+    y2 = Fz.dropout(x, 0.5, True)
+    assert torch.equal(y2, y)  # the mask is a pure function of the seed

@@ -1,0 +1,378 @@
+// BatchNorm (+ReLU, +residual) forward/backward around the conv kernels -- HBM-bound passes over NHWC
+// fp32 activations, float4-vectorised, deterministic two-level reductions (per-row-chunk partials in
+// fp32, cross-chunk combine in fp64).
+//
+// Forward (train): conv epilogue or zs3_colstats -> partial sums -> zs3_bn_fwd_finalize (mean, invstd,
+// fused scale/shift, running-stat update with unbiased variance) -> zs3_affine_act (normalise + residual
+// + ReLU, optionally into a channel slice of a concat buffer).
+// Backward: zs3_bn_bwd_stats (sum dz, sum dz*xhat) -> zs3_bn_bwd_finalize (dgamma, dbeta, c1, c2) ->
+// zs3_bn_act_bwd (dy = gamma*invstd*(dz - c1 - xhat*c2), and dz to the residual branch).
+//
+// Replaces native_batch_norm fwd/bwd + relu_/threshold_backward + residual add_ at resnet.py:33-53,
+// aspp.py:25-29,111-116, decoder.py:30-32,15-24 (113 BN layers; numerics of F.batch_norm, i.e.
+// invstd = 1/sqrt(var_biased + eps), running_var uses the unbiased variance).
+#include "common.h"
+#include "zs3hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Column statistics over rows of x[M][ld] (C channels): partial[chunk][2][C].
+// MODE 0: (sum x, sum x^2).   MODE 1: BN backward sums (sum dz, sum dz*xhat), dz = relu'(a) * dA.
+struct ColArgs {
+  const float* x;     // MODE0: x ; MODE1: dA
+  const float* a;     // MODE1: post-activation output (ReLU mask) or null
+  const float* y;     // MODE1: conv output (pre-BN)
+  const float* mean;  // MODE1
+  const float* invstd;
+  float* partial;
+  int M, C, ldx, lda, ldy, rows_per_block;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
+  __shared__ float red[2][256 * 4];
+  const int c4n = p.C >> 2;                       // channel quads
+  const int tx_n = c4n < 256 ? c4n : 256;         // threads along channels
+  const int ty_n = 256 / tx_n;                    // row groups
+  const int tid = threadIdx.x;
+  const int tx = tid % tx_n, ty = tid / tx_n;
+  const int row0 = blockIdx.x * p.rows_per_block;
+  const int row1 = min(p.M, row0 + p.rows_per_block);
+  for (int cb = 0; cb < c4n; cb += tx_n) {  // uniform trip count: the body contains barriers
+    const int cq = cb + tx;
+    const bool active = ty < ty_n && cq < c4n;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 1) {
+        mu = *reinterpret_cast<const f32x4*>(p.mean + cq * 4);
+        is = *reinterpret_cast<const f32x4*>(p.invstd + cq * 4);
+      }
+      for (int r = row0 + ty; r < row1; r += ty_n) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)r * p.ldx + cq * 4);
+        if (MODE == 0) {
+          s += v;
+          q += v * v;
+        } else {
+          if (p.a) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(p.a + (size_t)r * p.lda + cq * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = av[k] > 0.f ? v[k] : 0.f;
+          }
+          f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + (size_t)r * p.ldy + cq * 4);
+          s += v;
+          q += v * ((yv - mu) * is);
+        }
+      }
+    }
+    // reduce over ty through LDS (fixed order)
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[0][(ty * tx_n + tx) * 4 + k] = s[k];
+        red[1][(ty * tx_n + tx) * 4 + k] = q[k];
+      }
+    }
+    __syncthreads();
+    if (active && ty == 0) {
+      f32x4 ts = {0.f, 0.f, 0.f, 0.f}, tq = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < ty_n; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ts[k] += red[0][(g * tx_n + tx) * 4 + k];
+          tq[k] += red[1][(g * tx_n + tx) * 4 + k];
+        }
+      float* o0 = p.partial + ((size_t)blockIdx.x * 2 + 0) * p.C + cq * 4;
+      float* o1 = p.partial + ((size_t)blockIdx.x * 2 + 1) * p.C + cq * 4;
+      *reinterpret_cast<f32x4*>(o0) = ts;
+      *reinterpret_cast<f32x4*>(o1) = tq;
+    }
+  }
+}
+
+// one wave per channel: combine `chunks` partials in fp64
+__device__ __forceinline__ void combine_partials(const float* partial, int chunks, int C, int c, double& s, double& q) {
+  const int lane = threadIdx.x & 63;
+  double ls = 0.0, lq = 0.0;
+  for (int k = lane; k < chunks; k += 64) {
+    ls += (double)partial[((size_t)k * 2 + 0) * C + c];
+    lq += (double)partial[((size_t)k * 2 + 1) * C + c];
+  }
+  s = wave_sum_d(ls);
+  q = wave_sum_d(lq);
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* partial, int chunks, int C, double count,
+                                                             const float* gamma, const float* beta, float eps,
+                                                             float momentum, float* running_mean, float* running_var,
+                                                             float* mean_out, float* invstd_out, float* scale_out,
+                                                             float* shift_out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s, q;
+  combine_partials(partial, chunks, C, c, s, q);
+  if ((threadIdx.x & 63) == 0) {
+    double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    double invstd = 1.0 / sqrt(var + (double)eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)invstd;
+    float sc = g * (float)invstd;
+    scale_out[c] = sc;
+    shift_out[c] = b - (float)mean * sc;
+    if (running_mean) {
+      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+// eval-mode affine from running statistics
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* mean_out, float* invstd_out, float* scale_out, float* shift_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.f / sqrtf(rv[c] + eps);
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_out[c] = rm[c];
+  invstd_out[c] = invstd;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b - rm[c] * g * invstd;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int chunks, int C, double count,
+                                                             float* dgamma, float* dbeta, float* c1, float* c2,
+                                                             int use_batch_stats) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double s, q;
+  combine_partials(partial, chunks, C, c, s, q);
+  if ((threadIdx.x & 63) == 0) {
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    c1[c] = use_batch_stats ? (float)(s / count) : 0.f;
+    c2[c] = use_batch_stats ? (float)(q / count) : 0.f;
+  }
+}
+
+// out[m][c] = act(alpha * (x[m / div][c] * scale[c] + shift[c]) + res[m][c]) (+ out[m][c] if accumulate)
+struct AffArgs {
+  const float* x;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* out;
+  long M;
+  int C, ldx, ldr, ldo, div, act, accumulate;
+  float alpha, leak;
+};
+__global__ __launch_bounds__(256) void affine_act_kernel(const AffArgs p) {
+  const int c4n = p.C >> 2;
+  const long total = p.M * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c4n;
+    const int cq = (int)(i - m * c4n) * 4;
+    const long ms = p.div > 1 ? m / p.div : m;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ms * p.ldx + cq);
+    if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + cq);
+    if (p.shift) v = v + *reinterpret_cast<const f32x4*>(p.shift + cq);
+    v = v * p.alpha;
+    if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + cq);
+    if (p.act == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.leak;
+    }
+    float* dst = p.out + m * p.ldo + cq;
+    if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+}
+
+struct BnBwdArgs {
+  const float* dA;
+  const float* a;
+  const float* y;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* c1;
+  const float* c2;
+  float* dy;
+  float* dres;
+  long M;
+  int C, ldd, lda, ldy, ldo, ldr, dres_accumulate, act;
+  float leak;
+};
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
+  const int c4n = p.C >> 2;
+  const long total = p.M * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c4n;
+    const int cq = (int)(i - m * c4n) * 4;
+    f32x4 dz = *reinterpret_cast<const f32x4*>(p.dA + m * p.ldd + cq);
+    if (p.a) {
+      f32x4 av = *reinterpret_cast<const f32x4*>(p.a + m * p.lda + cq);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
+    }
+    if (p.dres) {
+      float* dr = p.dres + m * p.ldr + cq;
+      f32x4 o = dz;
+      if (p.dres_accumulate) o = o + *reinterpret_cast<const f32x4*>(dr);
+      *reinterpret_cast<f32x4*>(dr) = o;
+    }
+    if (p.dy) {
+      f32x4 is = *reinterpret_cast<const f32x4*>(p.invstd + cq);
+      f32x4 g = p.gamma ? *reinterpret_cast<const f32x4*>(p.gamma + cq) : f32x4{1.f, 1.f, 1.f, 1.f};
+      f32x4 out;
+      if (p.c1) {
+        f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
+        f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + cq);
+        f32x4 xhat = (yv - mu) * is;
+        out = g * is * (dz - *reinterpret_cast<const f32x4*>(p.c1 + cq) - xhat * *reinterpret_cast<const f32x4*>(p.c2 + cq));
+      } else {
+        out = g * is * dz;
+      }
+      *reinterpret_cast<f32x4*>(p.dy + m * p.ldo + cq) = out;
+    }
+  }
+}
+
+// out[g][c] = scale * sum_{r<R} x[(g*R + r)][c]     (global average pool, pooled-branch backward)
+__global__ __launch_bounds__(256) void group_colsum_kernel(const float* x, int ldx, int R, int C, float scale, float* out,
+                                                          int ldo) {
+  __shared__ float red[256 * 4];
+  const int c4n = C >> 2;
+  const int tx_n = c4n < 64 ? c4n : 64;
+  const int ty_n = 256 / tx_n;
+  const int tid = threadIdx.x, tx = tid % tx_n, ty = tid / tx_n;
+  const int g = blockIdx.y;
+  const int cq = blockIdx.x * tx_n + tx;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const bool ok = ty < ty_n && cq < c4n;
+  if (ok)
+    for (int r = ty; r < R; r += ty_n) s += *reinterpret_cast<const f32x4*>(x + ((size_t)g * R + r) * ldx + cq * 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[tid * 4 + k] = ok ? s[k] : 0.f;
+  __syncthreads();
+  if (ty == 0 && cq < c4n) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int gg = 0; gg < ty_n; ++gg)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] += red[((gg * tx_n) + tx) * 4 + k];
+    *reinterpret_cast<f32x4*>(out + (size_t)g * ldo + cq * 4) = t * scale;
+  }
+}
+
+inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int zs3_colstats_plan(int M, int C, int* chunks, int* rows_per_block) {
+  int c4n = C / 4;
+  int tx_n = c4n < 256 ? c4n : 256;
+  int ty_n = 256 / (tx_n > 0 ? tx_n : 1);
+  int rpb = (M + 2047) / 2048;
+  int minr = ty_n * 4;
+  if (rpb < minr) rpb = minr;
+  *rows_per_block = rpb;
+  *chunks = (M + rpb - 1) / rpb;
+  return 0;
+}
+
+extern "C" int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, void* stream) {
+  if (C % 4 || ldx % 4) return -1;
+  ColArgs a{};
+  a.x = x; a.partial = partial; a.M = M; a.C = C; a.ldx = ldx;
+  int chunks;
+  zs3_colstats_plan(M, C, &chunks, &a.rows_per_block);
+  hipLaunchKernelGGL(colstats_kernel<0>, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
+                                const float* mean, const float* invstd, int M, int C, float* partial, void* stream) {
+  if (C % 4 || ldd % 4 || ldy % 4 || (a_out && lda % 4)) return -1;
+  ColArgs a{};
+  a.x = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.partial = partial;
+  a.M = M; a.C = C; a.ldx = ldd; a.lda = lda; a.ldy = ldy;
+  int chunks;
+  zs3_colstats_plan(M, C, &chunks, &a.rows_per_block);
+  hipLaunchKernelGGL(colstats_kernel<1>, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* mean_out, float* invstd_out, float* scale_out,
+                                   float* shift_out, void* stream) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
+                     shift_out);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* mean_out, float* invstd_out,
+                                  float* scale_out, float* shift_out, void* stream) {
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, mean_out, invstd_out, scale_out, shift_out);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, float* dgamma, float* dbeta,
+                                   float* c1, float* c2, int use_batch_stats, void* stream) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+                     count, dgamma, dbeta, c1, c2, use_batch_stats);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shift, float alpha,
+                              const float* res, int ldr, float* out, int ldo, long M, int C, int div, int act,
+                              float leak, int accumulate, void* stream) {
+  if (C % 4 || ldx % 4 || ldo % 4 || (res && ldr % 4)) return -1;
+  if (M <= 0) return 0;
+  AffArgs a;
+  a.x = x; a.scale = scale; a.shift = shift; a.res = res; a.out = out; a.M = M; a.C = C; a.ldx = ldx; a.ldr = ldr;
+  a.ldo = ldo; a.div = div; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.leak = leak;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
+                              const float* mean, const float* invstd, const float* gamma, const float* c1,
+                              const float* c2, float* dy, int ldo, float* dres, int ldr, int dres_accumulate, long M,
+                              int C, int act, float leak, void* stream) {
+  if (C % 4 || ldd % 4 || (dy && ldo % 4) || (a_out && lda % 4) || (dres && ldr % 4)) return -1;
+  if (M <= 0) return 0;
+  BnBwdArgs a;
+  a.dA = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.c1 = c1; a.c2 = c2;
+  a.dy = dy; a.dres = dres; a.M = M; a.C = C; a.ldd = ldd; a.lda = lda; a.ldy = ldy; a.ldo = ldo; a.ldr = ldr;
+  a.dres_accumulate = dres_accumulate; a.act = act; a.leak = leak;
+  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo,
+                                void* stream) {
+  if (C % 4 || ldx % 4 || ldo % 4) return -1;
+  if (G <= 0) return 0;
+  int c4n = C / 4;
+  int tx_n = c4n < 64 ? c4n : 64;
+  dim3 grid((c4n + tx_n - 1) / tx_n, G);
+  hipLaunchKernelGGL(group_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, scale, out, ldo);
+  return ZS3_LAUNCH_CHECK();
+}

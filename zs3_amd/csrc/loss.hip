@@ -1,0 +1,270 @@
+// Losses of the ZS3 hot path on gfx950:
+//   * weighted cross-entropy with ignore_index over NHWC logits (zs3/utils/loss.py:31-46) fwd/bwd,
+//   * multi-bandwidth Gaussian MMD of the GMMN (zs3/utils/loss.py:92-115) fwd/bwd, Gram matrices on the
+//     exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32) because E_ij = <xi,xj> - |xi|^2/2 - |xj|^2/2 cancels.
+#include "common.h"
+#include "zs3hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ CE
+template <typename TT>
+__device__ __forceinline__ int load_target(const TT* t, long i) { return (int)(long)t[i]; }
+
+template <typename TT>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, int ld, const TT* target, const float* weight,
+                                                    long P, int C, int ignore_index, double* partial) {
+  double lsum = 0.0, wsum = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long)gridDim.x * blockDim.x) {
+    const int t = load_target(target, i);
+    if (t == ignore_index || t < 0 || t >= C) continue;
+    const float* z = logits + i * ld;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    const float nll = (mx + logf(se)) - z[t];
+    const float w = weight ? weight[t] : 1.f;
+    lsum += (double)(w * nll);
+    wsum += (double)w;
+  }
+  __shared__ double red[2][4];
+  lsum = wave_sum_d(lsum);
+  wsum = wave_sum_d(wsum);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = lsum;
+    red[1][wave] = wsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// out[0] = loss, out[1] = sum of weights over valid pixels
+__global__ void ce_finalize_kernel(const double* partial, int nblk, float inv_batch, float* out) {
+  double l = 0.0, w = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 64) {
+    l += partial[2 * k];
+    w += partial[2 * k + 1];
+  }
+  l = wave_sum_d(l);
+  w = wave_sum_d(w);
+  if (threadIdx.x == 0) {
+    out[0] = (float)(l / w) * inv_batch;
+    out[1] = (float)w;
+  }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int ld, const TT* target, const float* weight,
+                                                    long P, int C, int ignore_index, const float* loss_ws,
+                                                    const float* gout, float inv_batch, float* dlogits, int ldo) {
+  const float coef = gout[0] * inv_batch / loss_ws[1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long)gridDim.x * blockDim.x) {
+    const int t = load_target(target, i);
+    float* d = dlogits + i * ldo;
+    if (t == ignore_index || t < 0 || t >= C) {
+      for (int c = 0; c < C; ++c) d[c] = 0.f;
+      continue;
+    }
+    const float* z = logits + i * ld;
+    float mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+    const float w = (weight ? weight[t] : 1.f) * coef;
+    const float inv = 1.f / se;
+    for (int c = 0; c < C; ++c) d[c] = w * (expf(z[c] - mx) * inv - (c == t ? 1.f : 0.f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ MMD
+// X = [gen ; real] (2N rows, D cols).  One wave per 32x32 tile of the 2N x 2N kernel matrix.
+struct MmdArgs {
+  const float* gen;
+  const float* real;
+  int ldg, ldr, N, D;
+  float* G;        // [2N][2N]: S_ij * sum_v exp(E_ij/v)/v  (for backward)
+  double* tile;    // [tiles][2]: (+) and (-) sums
+  float sig[8];
+  int nsig;
+};
+
+__device__ __forceinline__ const float* mmd_row(const MmdArgs& p, int r) {
+  return r < p.N ? p.gen + (size_t)r * p.ldg : p.real + (size_t)(r - p.N) * p.ldr;
+}
+
+__global__ __launch_bounds__(64) void mmd_tile_kernel(const MmdArgs p) {
+  __shared__ float nrm[2][32];
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int T = (2 * p.N + 31) / 32;
+  const int ti = blockIdx.x / T, tj = blockIdx.x % T;
+  const int ra = ti * 32 + r, rb = tj * 32 + r;
+  const bool va = ra < 2 * p.N, vb = rb < 2 * p.N;
+  const float* pa = mmd_row(p, va ? ra : 0);
+  const float* pb = mmd_row(p, vb ? rb : 0);
+  const int half = p.D / 2;  // lane-half h owns k in [h*half, (h+1)*half)
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  float na = 0.f, nb = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < half; ++s) {
+    const float a = va ? pa[h * half + s] : 0.f;
+    const float b = vb ? pb[h * half + s] : 0.f;
+    na = fmaf(a, a, na);
+    nb = fmaf(b, b, nb);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  na += __shfl_xor(na, 32, 64);
+  nb += __shfl_xor(nb, 32, 64);
+  if (h == 0) {
+    nrm[0][r] = na;
+    nrm[1][r] = nb;
+  }
+  __syncthreads();
+  const int j = tj * 32 + r;  // column owned by this lane
+  const float nj = nrm[1][r];
+  const float invN2 = 1.f / ((float)p.N * (float)p.N);
+  double pos = 0.0, neg = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int il = (q & 3) + 8 * (q >> 2) + 4 * h;
+    const int i = ti * 32 + il;
+    if (i < 2 * p.N && j < 2 * p.N) {
+      const float e = acc[q] - 0.5f * nrm[0][il] - 0.5f * nj;
+      float ks = 0.f, kd = 0.f;
+      for (int v = 0; v < p.nsig; ++v) {
+        const float k = expf(e / p.sig[v]);
+        ks += k;
+        kd += k / p.sig[v];
+      }
+      const bool same = (i < p.N) == (j < p.N);
+      if (same) pos += (double)ks; else neg += (double)ks;
+      if (p.G) p.G[(size_t)i * (2 * p.N) + j] = (same ? kd : -kd) * invN2;
+    }
+  }
+  pos = wave_sum_d(pos);
+  neg = wave_sum_d(neg);
+  if (lane == 0) {
+    p.tile[2 * blockIdx.x + 0] = pos;
+    p.tile[2 * blockIdx.x + 1] = neg;
+  }
+}
+
+__global__ void mmd_finalize_kernel(const double* tile, int ntiles, int N, float* loss) {
+  if (threadIdx.x == 0) {
+    double pos = 0.0, neg = 0.0;  // same summation pattern for both => exact 0 when gen == real
+    for (int k = 0; k < ntiles; ++k) {
+      pos += tile[2 * k];
+      neg += tile[2 * k + 1];
+    }
+    const double q = (pos - neg) / ((double)N * (double)N);
+    loss[0] = sqrtf((float)q);
+  }
+}
+
+// dgen[k][d] = gout/L * ( sum_j G[k][j] X[j][d] - rowsum_k(G) * gen[k][d] ),  k < N.  One wave per 32x32 tile.
+__global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const float* loss, const float* gout, float* dgen,
+                                                    int ldo) {
+  __shared__ float rs[32];
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int TD = (p.D + 31) / 32;
+  const int tk = blockIdx.x / TD, td = blockIdx.x % TD;
+  const int k = tk * 32 + r;
+  const int d = td * 32 + r;
+  const int twoN = 2 * p.N;
+  const bool vk = k < p.N, vd = d < p.D;
+  const float* grow = p.G + (size_t)(vk ? k : 0) * twoN;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  float rsum = 0.f;
+  const int half = twoN / 2;  // = N
+#pragma unroll 8
+  for (int s = 0; s < half; ++s) {
+    const int j = h * half + s;
+    const float a = vk ? grow[j] : 0.f;
+    const float b = vd ? mmd_row(p, j)[d] : 0.f;
+    rsum += a;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  rsum += __shfl_xor(rsum, 32, 64);
+  if (h == 0) rs[r] = rsum;
+  __syncthreads();
+  const float coef = gout[0] / loss[0];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int kl = (q & 3) + 8 * (q >> 2) + 4 * h;
+    const int kk = tk * 32 + kl;
+    if (kk < p.N && vd) dgen[(size_t)kk * ldo + d] = coef * (acc[q] - rs[kl] * p.gen[(size_t)kk * p.ldg + d]);
+  }
+}
+
+}  // namespace
+
+extern "C" int zs3_ce_fwd(const float* logits, int ld, const void* target, int target_is_i64, const float* weight,
+                          long P, int C, int ignore_index, int batch, double* partial_ws, float* loss_ws, void* stream) {
+  const int nblk = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (target_is_i64)
+    hipLaunchKernelGGL(ce_fwd_kernel<long>, dim3(nblk), dim3(256), 0, st, logits, ld, (const long*)target, weight, P, C,
+                       ignore_index, partial_ws);
+  else
+    hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(nblk), dim3(256), 0, st, logits, ld, (const float*)target, weight, P,
+                       C, ignore_index, partial_ws);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)partial_ws, nblk,
+                     batch > 0 ? 1.f / (float)batch : 1.f, loss_ws);
+  return ZS3_LAUNCH_CHECK();
+}
+extern "C" int zs3_ce_ws_doubles(void) { return 2 * 1024; }
+
+extern "C" int zs3_ce_bwd(const float* logits, int ld, const void* target, int target_is_i64, const float* weight,
+                          long P, int C, int ignore_index, int batch, const float* loss_ws, const float* gout,
+                          float* dlogits, int ldo, void* stream) {
+  long blocks = (P + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) return 0;
+  const float inv_batch = batch > 0 ? 1.f / (float)batch : 1.f;
+  hipStream_t st = (hipStream_t)stream;
+  if (target_is_i64)
+    hipLaunchKernelGGL(ce_bwd_kernel<long>, dim3((int)blocks), dim3(256), 0, st, logits, ld, (const long*)target,
+                       weight, P, C, ignore_index, loss_ws, gout, inv_batch, dlogits, ldo);
+  else
+    hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, st, logits, ld, (const float*)target,
+                       weight, P, C, ignore_index, loss_ws, gout, inv_batch, dlogits, ldo);
+  return ZS3_LAUNCH_CHECK();
+}
+
+static int mmd_fill(MmdArgs& a, const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* sigma,
+                    int nsig, float* G, double* tile) {
+  if (nsig > 8 || nsig < 1 || D % 2 || N < 1) return -1;
+  a.gen = gen; a.real = real; a.ldg = ldg; a.ldr = ldr; a.N = N; a.D = D; a.G = G; a.tile = tile; a.nsig = nsig;
+  for (int i = 0; i < nsig; ++i) a.sig[i] = sigma[i];
+  return 0;
+}
+
+/* sigma: HOST array of nsig bandwidths.  G: [2N][2N] floats (kept for backward), tile_ws: [T*T][2] doubles, T = ceil(2N/32). */
+extern "C" int zs3_mmd_fwd(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* sigma,
+                           int nsig, float* G, double* tile_ws, float* loss, void* stream) {
+  MmdArgs a;
+  if (mmd_fill(a, gen, ldg, real, ldr, N, D, sigma, nsig, G, tile_ws)) return -1;
+  const int T = (2 * N + 31) / 32;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mmd_tile_kernel, dim3(T * T), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)tile_ws, T * T, N, loss);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
+                           const float* loss, const float* gout, float* dgen, int ldo, void* stream) {
+  MmdArgs a;
+  float one = 1.f;
+  if (mmd_fill(a, gen, ldg, real, ldr, N, D, &one, 1, (float*)G, nullptr)) return -1;
+  const int TK = (N + 31) / 32, TD = (D + 31) / 32;
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(TK * TD), dim3(64), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo);
+  return ZS3_LAUNCH_CHECK();
+}

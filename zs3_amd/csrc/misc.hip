@@ -1,0 +1,189 @@
+// Small HBM/latency-bound kernels of the GMMN step and the optimisers: counter-based dropout, uniform
+// noise, nearest-neighbour down-sampling into pixel rows, row gather / scatter / deterministic
+// index-add, fused SGD(momentum, weight decay) and Adam updates.
+#include "common.h"
+#include "zs3hip.h"
+
+namespace {
+
+// splitmix64-style counter hash -> 24-bit uniform in [0,1)
+__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// y[m][c] = keep(seed, m*C + c) ? x[m][c] / (1-p) : 0      (same kernel serves backward with x = dy)
+__global__ void dropout_kernel(const float* x, int ldx, float* y, int ldy, long M, int C, float p, float inv_keep,
+                               unsigned long long seed) {
+  const long total = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C;
+    const int c = (int)(i - m * C);
+    const float v = x[m * ldx + c];
+    y[m * ldy + c] = u01(seed, (unsigned long long)i) >= p ? v * inv_keep : 0.f;
+  }
+}
+
+__global__ void uniform_kernel(float* out, long n, unsigned long long seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = u01(seed, (unsigned long long)i);
+}
+
+// src: [C][H][W] (one NCHW image) -> rows[(oh*ow)][ldo] with rows[p][c] = src[c][ih(p)][iw(p)], nearest:
+// ih = min(floor(oh * (H/ho)), H-1) in fp32 as ATen's upsample_nearest does.
+__global__ void nearest_rows_kernel(const float* src, int C, int H, int W, int ho, int wo, float sh, float sw,
+                                    float* rows, int ldo) {
+  const long total = (long)ho * wo * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int pix = (int)(i % ((long)ho * wo));  // pixel fastest: reads of one channel plane stay local
+    const int c = (int)(i / ((long)ho * wo));
+    const int oh = pix / wo, ow = pix - oh * wo;
+    int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
+    ih = ih < H - 1 ? ih : H - 1;
+    iw = iw < W - 1 ? iw : W - 1;
+    rows[(long)pix * ldo + c] = src[((long)c * H + ih) * W + iw];
+  }
+}
+
+// out[r][0:Ca] = a[idx[r]][0:Ca]; out[r][Ca:Ca+Cb] = b[r][0:Cb]; out[r][Ca+Cb:ldo] = 0
+__global__ void gather_cat_kernel(const float* a, int lda, const long* idx, int Ca, const float* b, int ldb, int Cb,
+                                  float* out, int ldo, long n) {
+  const long total = n * ldo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / ldo;
+    const int c = (int)(i - r * ldo);
+    float v = 0.f;
+    if (c < Ca) v = a[(idx ? idx[r] : r) * lda + c];
+    else if (c < Ca + Cb) v = b[r * ldb + (c - Ca)];
+    out[i] = v;
+  }
+}
+
+// mode 0: out[r][:] = src[idx[r]][:] (gather); mode 1: out[idx[r]][:] = src[r][:] (scatter, idx unique)
+__global__ void rows_kernel(const float* src, int lds, const long* idx, float* out, int ldo, long n, int C, int mode) {
+  const long total = n * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    if (mode == 0) out[r * ldo + c] = src[idx[r] * lds + c];
+    else out[idx[r] * ldo + c] = src[r * lds + c];
+  }
+}
+
+// out[idx[r]][c] += src[r][c] for r = 0..n-1 in order; thread c owns its column => deterministic with duplicates
+__global__ void index_add_rows_kernel(const float* src, int lds, const long* idx, float* out, int ldo, int n, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  for (int r = 0; r < n; ++r) out[idx[r] * ldo + c] += src[(long)r * lds + c];
+}
+
+__global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
+                           int nesterov, int first) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float d = g[i] + wd * p[i];
+    if (momentum != 0.f) {
+      float b = first ? d : momentum * buf[i] + d;
+      buf[i] = b;
+      d = nesterov ? d + momentum * b : b;
+    }
+    p[i] -= lr * d;
+  }
+}
+
+// torch.optim.Adam (no amsgrad, eps outside sqrt/bias-correction as in torch): step_size = lr / bc1,
+// denom = sqrt(v)/sqrt(bc2) + eps
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                            float wd, float bc1, float bc2_sqrt) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] + wd * p[i];
+    float mi = m[i] + (1.f - b1) * (gi - m[i]);        // lerp form used by torch
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
+                           void* stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, p,
+                     1.f / (1.f - p), seed);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_uniform(float* out, long n, unsigned long long seed, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(uniform_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_nearest_rows(const float* src, int C, int H, int W, int ho, int wo, float* rows, int ldo,
+                                void* stream) {
+  const float sh = (float)H / (float)ho, sw = (float)W / (float)wo;
+  hipLaunchKernelGGL(nearest_rows_kernel, dim3(ew_blocks((long)ho * wo * C)), dim3(256), 0, (hipStream_t)stream, src, C,
+                     H, W, ho, wo, sh, sw, rows, ldo);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_gather_cat(const float* a, int lda, const long* idx, int Ca, const float* b, int ldb, int Cb,
+                              float* out, int ldo, long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gather_cat_kernel, dim3(ew_blocks(n * ldo)), dim3(256), 0, (hipStream_t)stream, a, lda, idx, Ca, b,
+                     ldb, Cb, out, ldo, n);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_gather_rows(const float* src, int lds, const long* idx, float* out, int ldo, long n, int C,
+                               void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(rows_kernel, dim3(ew_blocks(n * C)), dim3(256), 0, (hipStream_t)stream, src, lds, idx, out, ldo, n,
+                     C, 0);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_scatter_rows(const float* src, int lds, const long* idx, float* out, int ldo, long n, int C,
+                                void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(rows_kernel, dim3(ew_blocks(n * C)), dim3(256), 0, (hipStream_t)stream, src, lds, idx, out, ldo, n,
+                     C, 1);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_index_add_rows(const float* src, int lds, const long* idx, float* out, int ldo, int n, int C,
+                                  void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(index_add_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, lds, idx, out,
+                     ldo, n, C);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
+                            int nesterov, int first, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum, wd,
+                     nesterov, first);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                             float eps, float wd, int step, void* stream) {
+  if (n <= 0) return 0;
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps,
+                     wd, (float)bc1, (float)sqrt(bc2));
+  return ZS3_LAUNCH_CHECK();
+}

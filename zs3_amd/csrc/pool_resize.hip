@@ -1,0 +1,238 @@
+// Max-pool 3x3/s2 (resnet.py:82,190) and bilinear align_corners=True resize (aspp.py:109,
+// decoder.py:34-36, deeplab.py:44,55) on NHWC fp32, forward and backward.  HBM-bound; float4 over
+// channels; backward passes are written in gather form (one thread owns an input element), so they
+// need no atomics and are deterministic.
+#include "common.h"
+#include "zs3hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int ldx, float* out, int ldo,
+                                                         unsigned char* idx, int N, int H, int W, int Ho, int Wo, int C,
+                                                         int K, int stride, int pad) {
+  const int c4n = C >> 2;
+  const long total = (long)N * Ho * Wo * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n) * 4;
+    long m = i / c4n;
+    const int ow = (int)(m % Wo);
+    long r = m / Wo;
+    const int oh = (int)(r % Ho), n = (int)(r / Ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    for (int kh = 0; kh < K; ++kh) {
+      const int h = oh * stride - pad + kh;
+      if (h < 0 || h >= H) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int w = ow * stride - pad + kw;
+        if (w < 0 || w >= W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + h) * W + w) * ldx + cq);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (v[k] > best[k] || v[k] != v[k]) {  // first maximum wins, NaN propagates (ATen semantics)
+            best[k] = v[k];
+            bi[k] = kh * K + kw;
+          }
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + m * ldo + cq) = best;
+    if (idx) {
+      unsigned pk = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+      *reinterpret_cast<unsigned*>(idx + m * C + cq) = pk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, int ldd, const unsigned char* idx, float* dx,
+                                                         int ldo, int N, int H, int W, int Ho, int Wo, int C, int K,
+                                                         int stride, int pad) {
+  const int c4n = C >> 2;
+  const long total = (long)N * H * W * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n) * 4;
+    long m = i / c4n;
+    const int w = (int)(m % W);
+    long r = m / W;
+    const int h = (int)(r % H), n = (int)(r / H);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < K; ++kh) {
+      const int th = h + pad - kh;
+      if (th < 0 || th % stride) continue;
+      const int oh = th / stride;
+      if (oh >= Ho) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int tw = w + pad - kw;
+        if (tw < 0 || tw % stride) continue;
+        const int ow = tw / stride;
+        if (ow >= Wo) continue;
+        const long mo = ((long)n * Ho + oh) * Wo + ow;
+        const unsigned pk = *reinterpret_cast<const unsigned*>(idx + mo * C + cq);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + mo * ldd + cq);
+        const unsigned tap = (unsigned)(kh * K + kw);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (((pk >> (8 * k)) & 0xFFu) == tap) g[k] += d[k];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + m * ldo + cq) = g;
+  }
+}
+
+__device__ __forceinline__ void src_index(int o, float scale, int in, int& i0, int& i1, float& lam) {
+  const float s = scale * (float)o;  // align_corners=True: src = dst * (in-1)/(out-1), all in fp32 as ATen does
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = s - (float)i0;
+}
+
+struct ResizeArgs {
+  const float* x;
+  float* out;
+  int N, H, W, Ho, Wo, C, ldx, ldo, accumulate;
+  float sh, sw;
+};
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const ResizeArgs p) {
+  const int c4n = p.C >> 2;
+  const bool vec = (p.C & 3) == 0 && (p.ldx & 3) == 0 && (p.ldo & 3) == 0;
+  const int cn = vec ? c4n : p.C;
+  const long total = (long)p.N * p.Ho * p.Wo * cn;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cn);
+    long m = i / cn;
+    const int ow = (int)(m % p.Wo);
+    long r = m / p.Wo;
+    const int oh = (int)(r % p.Ho), n = (int)(r / p.Ho);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index(oh, p.sh, p.H, h0, h1, lh);
+    src_index(ow, p.sw, p.W, w0, w1, lw);
+    const float* b = p.x + (long)n * p.H * p.W * p.ldx;
+    const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
+    if (vec) {
+      const int c = ci * 4;
+      f32x4 v = w00 * *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w0) * p.ldx + c) +
+                w01 * *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w1) * p.ldx + c) +
+                w10 * *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w0) * p.ldx + c) +
+                w11 * *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w1) * p.ldx + c);
+      *reinterpret_cast<f32x4*>(p.out + m * p.ldo + c) = v;
+    } else {
+      float v = w00 * b[((long)h0 * p.W + w0) * p.ldx + ci] + w01 * b[((long)h0 * p.W + w1) * p.ldx + ci] +
+                w10 * b[((long)h1 * p.W + w0) * p.ldx + ci] + w11 * b[((long)h1 * p.W + w1) * p.ldx + ci];
+      p.out[m * p.ldo + ci] = v;
+    }
+  }
+}
+
+// gather-form backward: x = grad wrt the (Ho x Wo) output, out = grad wrt the (H x W) input
+__device__ __forceinline__ void cand_range(int i, float scale, int out_n, int& lo, int& hi) {
+  if (scale <= 0.f) {
+    lo = 0;
+    hi = out_n - 1;
+    return;
+  }
+  lo = (int)floorf((float)(i - 1) / scale) - 1;
+  hi = (int)ceilf((float)(i + 1) / scale) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_n - 1) hi = out_n - 1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const ResizeArgs p) {
+  const bool vec = (p.C & 3) == 0 && (p.ldx & 3) == 0 && (p.ldo & 3) == 0;
+  const int cn = vec ? (p.C >> 2) : p.C;
+  const long total = (long)p.N * p.H * p.W * cn;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cn);
+    long m = i / cn;
+    const int w = (int)(m % p.W);
+    long r = m / p.W;
+    const int h = (int)(r % p.H), n = (int)(r / p.H);
+    int olo, ohi, wlo, whi;
+    cand_range(h, p.sh, p.Ho, olo, ohi);
+    cand_range(w, p.sw, p.Wo, wlo, whi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* g = p.x + (long)n * p.Ho * p.Wo * p.ldx;
+    for (int oh = olo; oh <= ohi; ++oh) {
+      int h0, h1;
+      float lh;
+      src_index(oh, p.sh, p.H, h0, h1, lh);
+      const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+      if (wh == 0.f) continue;
+      for (int ow = wlo; ow <= whi; ++ow) {
+        int w0, w1;
+        float lw;
+        src_index(ow, p.sw, p.W, w0, w1, lw);
+        const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+        if (ww == 0.f) continue;
+        const float wt = wh * ww;
+        const float* src = g + ((long)oh * p.Wo + ow) * p.ldx;
+        if (vec)
+          acc += wt * *reinterpret_cast<const f32x4*>(src + ci * 4);
+        else
+          acc[0] += wt * src[ci];
+      }
+    }
+    if (vec) {
+      float* dst = p.out + m * p.ldo + ci * 4;
+      if (p.accumulate) acc += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = acc;
+    } else {
+      float* dst = p.out + m * p.ldo + ci;
+      *dst = (p.accumulate ? *dst : 0.f) + acc[0];
+    }
+  }
+}
+
+inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int zs3_maxpool_fwd(const float* x, int ldx, float* out, int ldo, void* idx, int N, int H, int W, int Ho,
+                               int Wo, int C, int K, int stride, int pad, void* stream) {
+  if (C % 4 || ldx % 4 || ldo % 4 || K * K > 255) return -1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, out, ldo, (unsigned char*)idx, N, H, W, Ho, Wo, C, K, stride, pad);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_maxpool_bwd(const float* dy, int ldd, const void* idx, float* dx, int ldo, int N, int H, int W,
+                               int Ho, int Wo, int C, int K, int stride, int pad, void* stream) {
+  if (C % 4 || ldd % 4 || ldo % 4) return -1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     dy, ldd, (const unsigned char*)idx, dx, ldo, N, H, W, Ho, Wo, C, K, stride, pad);
+  return ZS3_LAUNCH_CHECK();
+}
+
+static ResizeArgs make_resize(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int Ho, int Wo, int C,
+                              int accumulate) {
+  ResizeArgs a;
+  a.x = x; a.out = out; a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = C; a.ldx = ldx; a.ldo = ldo;
+  a.accumulate = accumulate;
+  a.sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  a.sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  return a;
+}
+
+/* x: [N,H,W,C] -> out: [N,Ho,Wo,C] */
+extern "C" int zs3_bilinear_fwd(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int Ho, int Wo,
+                                int C, void* stream) {
+  ResizeArgs a = make_resize(x, ldx, out, ldo, N, H, W, Ho, Wo, C, 0);
+  long total = (long)N * Ho * Wo * ((C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0) ? C / 4 : C);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+/* dout: [N,Ho,Wo,C] (grad of the resized map) -> dx: [N,H,W,C] */
+extern "C" int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int H, int W, int Ho, int Wo,
+                                int C, int accumulate, void* stream) {
+  ResizeArgs a = make_resize(dout, ldd, dx, ldo, N, H, W, Ho, Wo, C, accumulate);
+  long total = (long)N * H * W * ((C % 4 == 0 && ldd % 4 == 0 && ldo % 4 == 0) ? C / 4 : C);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}

@@ -1,0 +1,405 @@
+"""Differentiable ops of the hot path: torch.autograd.Function wrappers around the HIP kernels.
+
+All activations flowing between these functions are NHWC tensors [N, H, W, C] (fp32, channel
+contiguous).  Each Function is one *fused layer* (conv + BatchNorm + residual + ReLU, ...), so a
+training step is ~150 autograd nodes instead of ~700 ATen ops.  Nothing here falls back to torch
+compute: tensors must live on the GPU and libzs3hip.so must be present.
+"""
+import random
+import weakref
+
+import torch
+
+from . import ops
+from ._lib import require_gpu
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+# ---------------------------------------------------------------------------------- weight-plane cache
+_planes = {}
+
+
+def weight_planes(w, need_t=True):
+    """bf16 hi/lo planes of a parameter, recomputed only when the parameter changed (optimizer step,
+    load_state_dict): keyed on (storage pointer, autograd version counter)."""
+    key = id(w)
+    ver = (w.data_ptr(), w._version, tuple(w.shape), need_t)
+    hit = _planes.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is w:
+        return hit[1]
+    if hit is not None and hit[0][:3] == ver[:3] and hit[0][3] and not need_t and hit[2]() is w:
+        return hit[1]
+    wp = ops.prep_weight(w, need_t=need_t)
+    _planes[key] = (ver, wp, weakref.ref(w, lambda _r, k=key: _planes.pop(k, None)))
+    return wp
+
+
+# ---------------------------------------------------------------------------------- RNG for dropout
+_rng = None
+
+
+def manual_seed(seed):
+    global _rng
+    _rng = random.Random(int(seed))
+
+
+def next_seed():
+    global _rng
+    if _rng is None:
+        _rng = random.Random(torch.initial_seed())
+    return _rng.getrandbits(63)
+
+
+def _pad_channels(t, mult):
+    """NHWC/rows tensor -> same logical tensor whose row stride is a multiple of `mult` floats with zero
+    padding behind the last channel (what the dgrad/wgrad kernels need to read whole chunks)."""
+    c = t.shape[-1]
+    ld = ops._rows(t)[2] if t.stride(-1) == 1 else -1
+    if ld > 0 and ld % mult == 0 and (c % mult == 0):
+        return t
+    cp = (c + mult - 1) // mult * mult
+    buf = torch.zeros(t.shape[:-1] + (cp,), dtype=t.dtype, device=t.device)
+    buf[..., :c].copy_(t)
+    return buf[..., :c]
+
+
+def _dense_rows(t):
+    if t.stride(-1) != 1:
+        return t.contiguous()
+    try:
+        ops._rows(t)
+        return t
+    except AssertionError:
+        return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------- conv + BN + act
+class _ConvBnAct(torch.autograd.Function):
+    """y = conv(x, w) ; a = act(bn(y) + bias + residual).  One node for the whole fused layer.
+
+    reference: Bottleneck.forward (resnet.py:33-53), _ASPPModule.forward (aspp.py:25-29), ASPP.forward
+    (aspp.py:111-114), Decoder (decoder.py:30-32, last_conv), pred_conv (decoder.py:26), nn.Linear (gmmn.py)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bias, residual, cfg):
+        require_gpu(x, weight)
+        x = _dense_rows(x)
+        need_grad = cfg.get("need_grad", True)  # grad mode is always off inside Function.forward: decided by the caller
+        wp = weight_planes(weight, need_t=True)
+        stride, pad, dil, act = cfg["stride"], cfg["pad"], cfg["dil"], cfg["act"]
+        geom = cfg.get("geom")  # explicit (n,h,w,ldx,...) for the stem's overlapping-window view
+        bn = cfg.get("bn")
+        out = cfg.get("out")
+        leak = cfg.get("leak", 0.2)
+        prec = cfg.get("prec")
+        y = a = st = None
+        conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, **k)) if geom is None else (
+            lambda **k: ops.conv_igemm(x, wp.f_hi, wp.f_lo, prec=prec, **geom, **k))
+        if bn is not None and bn["training"]:
+            y, part = conv(want_stats=True)
+            count = y.shape[0] * y.shape[1] * y.shape[2]
+            if count <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size "
+                                 f"{(y.shape[0], y.shape[3], y.shape[1], y.shape[2])}")
+            st = ops.bn_fwd_finalize(part, count, gamma, beta, bn["eps"], bn["momentum"], bn["running_mean"],
+                                     bn["running_var"])
+            a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak)
+        elif bn is not None:
+            st = ops.bn_eval_affine(gamma, beta, bn["running_mean"], bn["running_var"], bn["eps"])
+            if need_grad:
+                y, _ = conv()
+                a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak)
+            else:
+                a, _ = conv(scale=st[2], shift=st[3], res=residual, act=act, leak=leak, out=out)
+        else:
+            a, _ = conv(shift=bias, res=residual, act=act, leak=leak, out=out)
+        ctx.cfg = cfg
+        ctx.has_bn = bn is not None
+        ctx.bn_training = bool(bn is not None and bn["training"])
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.x_shape = tuple(x.shape)
+        ctx.save_for_backward(x, weight, gamma, y, a if act != ACT_NONE else None, st)
+        return a
+
+    @staticmethod
+    def backward(ctx, dA):
+        x, weight, gamma, y, a, st = ctx.saved_tensors
+        cfg = ctx.cfg
+        stride, pad, dil, act = cfg["stride"], cfg["pad"], cfg["dil"], cfg["act"]
+        leak, prec, geom = cfg.get("leak", 0.2), cfg.get("prec"), cfg.get("geom")
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dA = _dense_rows(dA)
+        wp = weight_planes(weight, need_t=True)
+        dgamma = dbeta = dbias = dres = None
+        if ctx.has_res and ctx.needs_input_grad[5]:
+            dres = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+        m = dA.shape[0] * dA.shape[1] * dA.shape[2] if dA.dim() == 4 else dA.shape[0]
+        if ctx.has_bn:
+            part = ops.bn_bwd_stats(dA, a, y, st[0], st[1])
+            fin = ops.bn_bwd_finalize(part, m, ctx.bn_training)
+            dgamma, dbeta = fin[0], fin[1]
+            dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, fin[2] if ctx.bn_training else None,
+                                fin[3] if ctx.bn_training else None, dres=dres, act=act, leak=leak)
+        else:
+            cout = dA.shape[-1]
+            vec_ok = cout % 4 == 0 and ops._rows(dA)[2] % 4 == 0
+            if act != ACT_NONE:
+                if vec_ok:
+                    dz = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+                    ops.bn_act_bwd(dA, a, None, None, None, None, None, None, dres=dz, act=act, leak=leak, want_dy=False)
+                else:
+                    dz = dA * _act_grad(a, act, leak)
+            else:
+                dz = dA
+            if dres is not None:
+                dres = dz
+            dy = _pad_channels(dz, 8) if (need_x or need_w) else dz
+            if ctx.has_bias and ctx.needs_input_grad[4]:
+                dbias = ops.colstats(dz)[:, 0].sum(0) if vec_ok else dz.reshape(-1, cout).sum(0)
+        dx = dw = None
+        if need_x:
+            if geom is None:
+                dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec)
+                if dx.shape[-1] != ctx.x_shape[-1]:  # x carried pad channels
+                    full = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dx.device)
+                    full[..., : dx.shape[-1]].copy_(dx)
+                    dx = full
+            else:
+                raise RuntimeError("the stem convolution has no data gradient (its input is the image)")
+        if need_w:
+            if geom is None:
+                dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec)
+                dw = dw.permute(0, 3, 1, 2)  # logical OIHW, channels_last memory like the parameter
+                if weight.dim() == 2:
+                    dw = dw.reshape(weight.shape)
+            else:
+                dw = cfg["wgrad"](dy, x)
+        return dx, dw, dgamma, dbeta, dbias, dres, None
+
+
+def _act_grad(a, act, leak):
+    if act == ACT_RELU:
+        return (a > 0).to(a.dtype)
+    return torch.where(a > 0, torch.ones_like(a), torch.full_like(a, leak))
+
+
+def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
+                leak=0.2, prec=None, geom=None, wgrad=None):
+    """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None."""
+    cfg = {"stride": stride, "pad": pad, "dil": dil, "act": act, "out": out, "leak": leak, "prec": prec, "geom": geom,
+           "wgrad": wgrad,
+           "need_grad": torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
+                                                        (x, weight, bias, residual, getattr(bn, "weight", None)))}
+    gamma = beta = None
+    if bn is not None:
+        gamma, beta = bn.weight, bn.bias
+        use_batch = bn.training or bn.running_mean is None
+        mom = bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if mom is None:
+                mom = 1.0 / float(bn.num_batches_tracked)
+        cfg["bn"] = {"training": use_batch, "eps": bn.eps, "momentum": mom if mom is not None else 0.0,
+                     "running_mean": bn.running_mean if (bn.training and bn.track_running_stats) or not use_batch else None,
+                     "running_var": bn.running_var if (bn.training and bn.track_running_stats) or not use_batch else None}
+    return _ConvBnAct.apply(x, weight, gamma, beta, bias, residual, cfg)
+
+
+# ---------------------------------------------------------------------------------- standalone BN (+act)
+class _BnAct(torch.autograd.Function):
+    """BatchNorm (+ReLU) on an NHWC / [M, C] tensor that was not produced by one of our convs."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, cfg):
+        y = _dense_rows(y)
+        m = y.numel() // y.shape[-1]
+        if cfg["training"]:
+            if m <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
+            st = ops.bn_fwd_finalize(ops.colstats(y), m, gamma, beta, cfg["eps"], cfg["momentum"], cfg["running_mean"],
+                                     cfg["running_var"])
+        else:
+            st = ops.bn_eval_affine(gamma, beta, cfg["running_mean"], cfg["running_var"], cfg["eps"])
+        a = ops.affine_act(y, st[2], st[3], act=cfg["act"], out=cfg.get("out"))
+        ctx.cfg = cfg
+        ctx.save_for_backward(y, gamma, a if cfg["act"] != ACT_NONE else None, st)
+        return a
+
+    @staticmethod
+    def backward(ctx, dA):
+        y, gamma, a, st = ctx.saved_tensors
+        cfg = ctx.cfg
+        dA = _dense_rows(dA)
+        m = y.numel() // y.shape[-1]
+        part = ops.bn_bwd_stats(dA, a, y, st[0], st[1])
+        fin = ops.bn_bwd_finalize(part, m, cfg["training"])
+        dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, fin[2] if cfg["training"] else None,
+                            fin[3] if cfg["training"] else None, act=cfg["act"])
+        return dy.reshape(y.shape), fin[0], fin[1], None
+
+
+def bn_act(y, bn, act=ACT_NONE, out=None):
+    use_batch = bn.training or bn.running_mean is None
+    mom = bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if mom is None:
+            mom = 1.0 / float(bn.num_batches_tracked)
+    track = bn.training and bn.track_running_stats
+    cfg = {"training": use_batch, "eps": bn.eps, "momentum": mom if mom is not None else 0.0, "act": act, "out": out,
+           "running_mean": bn.running_mean if track or not use_batch else None,
+           "running_var": bn.running_var if track or not use_batch else None}
+    return _BnAct.apply(y, bn.weight, bn.bias, cfg)
+
+
+class _Relu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense_rows(x)
+        a = ops.affine_act(x, act=ACT_RELU)
+        ctx.save_for_backward(a)
+        return a
+
+    @staticmethod
+    def backward(ctx, dA):
+        (a,) = ctx.saved_tensors
+        dA = _dense_rows(dA)
+        out = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+        ops.bn_act_bwd(dA, a, None, None, None, None, None, None, dy=None, dres=out, act=ACT_RELU, want_dy=False)
+        return out
+
+
+def relu(x):
+    return _Relu.apply(x)
+
+
+# ---------------------------------------------------------------------------------- pooling / resize
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        x = _dense_rows(x)
+        out, idx = ops.maxpool_fwd(x, k, stride, pad)
+        ctx.save_for_backward(idx)
+        ctx.geom = (x.shape[1], x.shape[2], k, stride, pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        h, w, k, stride, pad = ctx.geom
+        return ops.maxpool_bwd(_dense_rows(dy), idx, (h, w), k, stride, pad), None, None, None
+
+
+def max_pool(x, k=3, stride=2, pad=1):
+    return _MaxPool.apply(x, k, stride, pad)
+
+
+class _Bilinear(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=True) on NHWC; `out` may be a channel slice of a concat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, size, out, grad_pad):
+        x = _dense_rows(x)
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        ctx.grad_pad = grad_pad
+        return ops.bilinear_fwd(x, size, out=out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _dense_rows(dout)
+        n, _, _, c = dout.shape
+        h, w = ctx.in_hw
+        out = None
+        if ctx.grad_pad and c % ctx.grad_pad:
+            cp = (c + ctx.grad_pad - 1) // ctx.grad_pad * ctx.grad_pad
+            out = torch.zeros((n, h, w, cp), dtype=torch.float32, device=dout.device)[..., :c]
+        return ops.bilinear_bwd(dout, (h, w), out=out), None, None, None
+
+
+def bilinear(x, size, out=None, grad_pad=8):
+    return _Bilinear.apply(x, tuple(int(s) for s in size), out, grad_pad)
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d((1,1)) (aspp.py:85): NHWC [N,H,W,C] -> [N,1,1,C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense_rows(x)
+        n, h, w, c = x.shape
+        ctx.shape = (n, h, w, c)
+        return ops.group_colsum(x, n, 1.0 / (h * w)).view(n, 1, 1, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c = ctx.shape
+        dy = dy.reshape(n, c).contiguous()
+        return ops.affine_act(dy, alpha=1.0 / (h * w), div=h * w, out_shape=(n, h, w, c))
+
+
+def global_avg_pool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+class _Broadcast(torch.autograd.Function):
+    """Bilinear resize of a 1x1 map (align_corners=True) = broadcast (aspp.py:109), written into `out`."""
+
+    @staticmethod
+    def forward(ctx, x, size, out):
+        n, _, _, c = x.shape
+        ctx.n = n
+        x2 = x.reshape(n, c).contiguous()
+        return ops.affine_act(x2, div=size[0] * size[1], out=out, out_shape=(n, size[0], size[1], c))
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _dense_rows(dout)
+        c = dout.shape[-1]
+        return ops.group_colsum(dout, ctx.n).view(ctx.n, 1, 1, c), None, None
+
+
+def broadcast_to(x, size, out=None):
+    return _Broadcast.apply(x, tuple(size), out)
+
+
+class _CatSlices(torch.autograd.Function):
+    """torch.cat along channels (aspp.py:110, decoder.py:37) without a copy: the producers wrote straight
+    into channel slices of `buffer`; this node only ties the slices to the buffer for autograd."""
+
+    @staticmethod
+    def forward(ctx, buffer, *parts):
+        ctx.widths = [p.shape[-1] for p in parts]
+        return buffer.view(buffer.shape)
+
+    @staticmethod
+    def backward(ctx, dbuf):
+        grads, c0 = [], 0
+        for w in ctx.widths:
+            grads.append(dbuf[..., c0:c0 + w])
+            c0 += w
+        return (None, *grads)
+
+
+def cat_slices(buffer, parts):
+    return _CatSlices.apply(buffer, *parts)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _dense_rows(x)
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(_dense_rows(dy), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    if p >= 1.0:
+        return x * 0.0
+    return _Dropout.apply(x, float(p), next_seed())

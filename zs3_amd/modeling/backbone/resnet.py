@@ -1,0 +1,121 @@
+"""Dilated ResNet-101 backbone on the HIP kernels.  Interface, state-dict keys and init follow
+zs3/modeling/backbone/resnet.py:9-242; the arithmetic runs as fused conv+BN(+residual)+ReLU layers."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from ... import functional as Fz
+from ... import ops
+from ..layers import BatchNorm2d, Conv2d, to_channels_last_
+
+_STAGES = {
+    16: ((64, 3, 1, (1, 1, 1)), (128, 4, 2, (1,) * 4), (256, 23, 2, (1,) * 23), (512, 3, 1, (2, 4, 8))),
+    8: ((64, 3, 1, (1, 1, 1)), (128, 4, 2, (1,) * 4), (256, 23, 1, (2,) * 23), (512, 3, 1, (4, 8, 16))),
+}
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, BatchNorm=None):
+        super().__init__()
+        BatchNorm = BatchNorm or BatchNorm2d
+        self.conv1 = Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = BatchNorm(planes)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=stride, dilation=dilation, padding=dilation, bias=False)
+        self.bn2 = BatchNorm(planes)
+        self.conv3 = Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward_nhwc(self, x):
+        y = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU)
+        y = self.conv2.forward_nhwc(y, self.bn2, act=Fz.ACT_RELU)
+        skip = x if self.downsample is None else self.downsample[0].forward_nhwc(x, self.downsample[1])
+        return self.conv3.forward_nhwc(y, self.bn3, residual=skip, act=Fz.ACT_RELU)  # bn3 + add + relu in one pass
+
+    def forward(self, x):
+        return ops.nchw(self.forward_nhwc(ops.nhwc(x)))
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, output_stride, BatchNorm, pretrained=True, imagenet_pretrained_path=""):
+        super().__init__()
+        if output_stride not in _STAGES:
+            raise NotImplementedError
+        self.inplanes = 64
+        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        for si, ((planes, _, stride, dils), nblk) in enumerate(zip(_STAGES[output_stride], layers), start=1):
+            blocks = []
+            for bi in range(nblk):
+                s = stride if bi == 0 else 1
+                down = None
+                if bi == 0 and (s != 1 or self.inplanes != planes * block.expansion):
+                    down = nn.Sequential(Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=s, bias=False),
+                                         BatchNorm(planes * block.expansion))
+                blocks.append(block(self.inplanes, planes, s, dils[bi], down, BatchNorm))
+                self.inplanes = planes * block.expansion
+            setattr(self, f"layer{si}", nn.Sequential(*blocks))
+        self._init_weight()
+        if pretrained:
+            self._load_pretrained_model(imagenet_pretrained_path)
+        to_channels_last_(self)
+
+    # -- stem: 7x7/s2 conv as a 7x1 conv over 32-float (8 pixels x 4 channels) windows of a padded NHWC4 image
+    def _stem(self, image):
+        from ..._lib import I, P, check, lib, stream
+        n, c, h, w = image.shape
+        assert c == 3, "the stem expects a 3-channel NCHW image"
+        image = image.contiguous().float()
+        ho, wo = ops.conv_out_size(h, 7, 2, 3, 1), ops.conv_out_size(w, 7, 2, 3, 1)
+        wp = max(w + 7, 2 * (wo - 1) + 8)
+        xp = torch.empty((n, h, wp, 4), dtype=torch.float32, device=image.device)
+        check(lib().zs3_nchw3_to_nhwc4(P(image), P(xp), I(n), I(h), I(w), I(wp), I(3), stream()), "zs3_nchw3_to_nhwc4")
+        w_eff = TF.pad(self.conv1.weight.permute(0, 2, 3, 1), (0, 1, 0, 1)).reshape(64, 7, 1, 32).permute(0, 3, 1, 2)
+        geom = dict(ho=ho, wo=wo, cin_pad=32, cin_valid=32, kh=7, kw=1, stride=2, pad_h=3, pad_w=0, dil=1, ncols=64)
+
+        def wgrad(dy, x):
+            return ops.conv2d_wgrad(dy, x, 64, 32, 7, 1, 2, 3, 0, 1, ci_read=32).permute(0, 3, 1, 2)
+
+        return Fz.conv_bn_act(xp, w_eff, bn=self.bn1, act=Fz.ACT_RELU, stride=2, geom=geom, wgrad=wgrad)
+
+    def forward_nhwc(self, image):
+        x = self._stem(image)
+        x = Fz.max_pool(x, 3, 2, 1)
+        for blk in self.layer1:
+            x = blk.forward_nhwc(x)
+        low = x
+        for layer in (self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                x = blk.forward_nhwc(x)
+        return x, low
+
+    def forward(self, input):
+        x, low = self.forward_nhwc(input)
+        return ops.nchw(x), ops.nchw(low)
+
+    def _init_weight(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _load_pretrained_model(self, imagenet_pretrained_path):
+        pretrain_dict = torch.load(imagenet_pretrained_path)["state_dict"]
+        state_dict = self.state_dict()
+        state_dict.update({k[7:]: v for k, v in pretrain_dict.items() if k[7:] in state_dict})
+        self.load_state_dict(state_dict)
+
+
+def ResNet101(output_stride, BatchNorm, pretrained=True, imagenet_pretrained_path=""):
+    return ResNet(Bottleneck, [3, 4, 23, 3], output_stride, BatchNorm, pretrained=pretrained,
+                  imagenet_pretrained_path=imagenet_pretrained_path)

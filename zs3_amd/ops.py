@@ -21,7 +21,11 @@ def _round_up(a, b):
 def nhwc(t):
     """Logical NCHW (channels_last memory) -> [N,H,W,C] view; copies only if the memory is not NHWC."""
     v = t.permute(0, 2, 3, 1)
-    if v.stride(3) != 1 or v.stride(2) % 4 != 0 and v.shape[3] > 1:
+    try:
+        if v.stride(3) != 1 and v.shape[3] > 1:
+            raise AssertionError
+        _check_nhwc(v)
+    except AssertionError:
         v = v.contiguous()
     return v
 
@@ -122,4 +126,220 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
     cin_valid = min(_round_up(wp.cout, 8), _check_nhwc(dy))
     out, _ = conv_igemm(dy, wp.t_hi, wp.t_lo, ho=h, wo=w_, cin_pad=wp.cout_pad, cin_valid=cin_valid, kh=wp.kh,
                         kw=wp.kw, stride=stride, pad_h=pad, pad_w=pad, dil=dil, ncols=wp.cin, dgrad=True, **kw)
+    return out
+
+
+def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1, prec=None, ci_read=None):
+    """dy: NHWC [N,Ho,Wo,>=cout]; x: NHWC [N,H,W,>=cin] -> dw [cout, kh, kw, cin] (channels_last weight storage)."""
+    require_gpu(dy, x)
+    prec = prec or PREC_DEFAULT
+    pad_w = pad_h if pad_w is None else pad_w
+    n, ho, wo, _ = dy.shape
+    _, h, w_, _ = x.shape
+    lddy, ldx = _check_nhwc(dy), _check_nhwc(x)
+    co_read = min(_round_up(cout, 4), lddy)
+    ci_read = ci_read or min(_round_up(cin, 4), ldx)
+    dw = torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
+    splitk, ws = ctypes.c_int(0), ctypes.c_long(0)
+    lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
+    work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
+    check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
+                               I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
+                               I(prec), stream()), "zs3_conv_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------- BN / elementwise
+def _rows(t):
+    """[..., C] tensor with contiguous channels and uniform row stride -> (M, C, ld)."""
+    c = t.shape[-1]
+    if t.dim() == 2:
+        return t.shape[0], c, (t.stride(0) if t.shape[0] > 1 else max(c, t.stride(0)))
+    ld = _check_nhwc(t)
+    return t.shape[0] * t.shape[1] * t.shape[2], c, ld
+
+
+def colstats(x):
+    require_gpu(x)
+    m, c, ld = _rows(x)
+    chunks, rpb = ctypes.c_int(0), ctypes.c_int(0)
+    lib().zs3_colstats_plan(I(m), I(c), ctypes.byref(chunks), ctypes.byref(rpb))
+    part = torch.empty((chunks.value, 2, c), dtype=torch.float32, device=x.device)
+    check(lib().zs3_colstats(P(x), I(ld), I(m), I(c), P(part), stream()), "zs3_colstats")
+    return part
+
+
+def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var):
+    c = partial.shape[2]
+    out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # mean, invstd, scale, shift
+    check(lib().zs3_bn_fwd_finalize(P(partial), I(partial.shape[0]), I(c), ctypes.c_double(count), P(gamma), P(beta),
+                                    F(eps), F(momentum), P(running_mean), P(running_var), P(out[0]), P(out[1]),
+                                    P(out[2]), P(out[3]), stream()), "zs3_bn_fwd_finalize")
+    return out
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
+    c = running_mean.shape[0]
+    out = torch.empty((4, c), dtype=torch.float32, device=running_mean.device)
+    check(lib().zs3_bn_eval_affine(P(gamma), P(beta), P(running_mean), P(running_var), F(eps), I(c), P(out[0]), P(out[1]),
+                                   P(out[2]), P(out[3]), stream()), "zs3_bn_eval_affine")
+    return out
+
+
+def affine_act(x, scale=None, shift=None, alpha=1.0, res=None, out=None, div=1, act=0, leak=0.2, accumulate=False,
+               out_shape=None):
+    require_gpu(x, scale, shift, res, out)
+    m_in, c, ldx = _rows(x)
+    if out is None:
+        out = torch.empty(out_shape if out_shape is not None else x.shape, dtype=torch.float32, device=x.device)
+    m, c2, ldo = _rows(out)
+    assert c2 == c and m == m_in * div
+    ldr = _rows(res)[2] if res is not None else 0
+    check(lib().zs3_affine_act(P(x), I(ldx), P(scale), P(shift), F(alpha), P(res), I(ldr), P(out), I(ldo),
+                               ctypes.c_long(m), I(c), I(div), I(act), F(leak), I(int(accumulate)), stream()),
+          "zs3_affine_act")
+    return out
+
+
+def bn_bwd_stats(dA, a_out, y, mean, invstd):
+    m, c, ldd = _rows(dA)
+    lda = _rows(a_out)[2] if a_out is not None else 0
+    ldy = _rows(y)[2]
+    chunks, rpb = ctypes.c_int(0), ctypes.c_int(0)
+    lib().zs3_colstats_plan(I(m), I(c), ctypes.byref(chunks), ctypes.byref(rpb))
+    part = torch.empty((chunks.value, 2, c), dtype=torch.float32, device=dA.device)
+    check(lib().zs3_bn_bwd_stats(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), I(m), I(c), P(part),
+                                 stream()), "zs3_bn_bwd_stats")
+    return part
+
+
+def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True):
+    c = partial.shape[2]
+    out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # dgamma, dbeta, c1, c2
+    check(lib().zs3_bn_bwd_finalize(P(partial), I(partial.shape[0]), I(c), ctypes.c_double(count), P(out[0]), P(out[1]),
+                                    P(out[2]), P(out[3]), I(int(use_batch_stats)), stream()), "zs3_bn_bwd_finalize")
+    return out
+
+
+def bn_act_bwd(dA, a_out, y, mean, invstd, gamma, c1, c2, dy=None, dres=None, dres_accumulate=False, act=1, leak=0.2,
+               want_dy=True):
+    require_gpu(dA, a_out, y, dy, dres)
+    m, c, ldd = _rows(dA)
+    if want_dy and dy is None:
+        dy = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+    lda = _rows(a_out)[2] if a_out is not None else 0
+    ldy = _rows(y)[2] if y is not None else 0
+    ldo = _rows(dy)[2] if dy is not None else 0
+    ldr = _rows(dres)[2] if dres is not None else 0
+    check(lib().zs3_bn_act_bwd(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), P(gamma), P(c1), P(c2),
+                               P(dy), I(ldo), P(dres), I(ldr), I(int(dres_accumulate)), ctypes.c_long(m), I(c), I(act),
+                               F(leak), stream()), "zs3_bn_act_bwd")
+    return dy
+
+
+def group_colsum(x, groups, scale=1.0, out=None):
+    m, c, ld = _rows(x)
+    r = m // groups
+    if out is None:
+        out = torch.empty((groups, c), dtype=torch.float32, device=x.device)
+    check(lib().zs3_group_colsum(P(x), I(ld), I(groups), I(r), I(c), F(scale), P(out), I(_rows(out)[2]), stream()),
+          "zs3_group_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- pool / resize
+def maxpool_fwd(x, k=3, stride=2, pad=1):
+    n, h, w_, c = x.shape
+    ho, wo = conv_out_size(h, k, stride, pad, 1), conv_out_size(w_, k, stride, pad, 1)
+    out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    check(lib().zs3_maxpool_fwd(P(x), I(_check_nhwc(x)), P(out), I(c), P(idx), I(n), I(h), I(w_), I(ho), I(wo), I(c), I(k),
+                                I(stride), I(pad), stream()), "zs3_maxpool_fwd")
+    return out, idx
+
+
+def maxpool_bwd(dy, idx, in_hw, k=3, stride=2, pad=1):
+    n, ho, wo, c = dy.shape
+    h, w_ = in_hw
+    dx = torch.empty((n, h, w_, c), dtype=torch.float32, device=dy.device)
+    check(lib().zs3_maxpool_bwd(P(dy), I(_check_nhwc(dy)), P(idx), P(dx), I(c), I(n), I(h), I(w_), I(ho), I(wo), I(c),
+                                I(k), I(stride), I(pad), stream()), "zs3_maxpool_bwd")
+    return dx
+
+
+def bilinear_fwd(x, size, out=None):
+    n, h, w_, c = x.shape
+    ho, wo = size
+    if out is None:
+        out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    check(lib().zs3_bilinear_fwd(P(x), I(_check_nhwc(x)), P(out), I(_check_nhwc(out)), I(n), I(h), I(w_), I(ho), I(wo),
+                                 I(c), stream()), "zs3_bilinear_fwd")
+    return out
+
+
+def bilinear_bwd(dout, in_hw, out=None, accumulate=False):
+    n, ho, wo, c = dout.shape
+    h, w_ = in_hw
+    if out is None:
+        out = torch.empty((n, h, w_, c), dtype=torch.float32, device=dout.device)
+    check(lib().zs3_bilinear_bwd(P(dout), I(_check_nhwc(dout)), P(out), I(_check_nhwc(out)), I(n), I(h), I(w_), I(ho),
+                                 I(wo), I(c), I(int(accumulate)), stream()), "zs3_bilinear_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- misc
+def dropout(x, p, seed, out=None):
+    m, c, ld = _rows(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().zs3_dropout(P(x), I(ld), P(out), I(_rows(out)[2]), ctypes.c_long(m), I(c), F(p),
+                            ctypes.c_ulonglong(seed), stream()), "zs3_dropout")
+    return out
+
+
+def uniform(shape, seed, device):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib().zs3_uniform(P(out), ctypes.c_long(out.numel()), ctypes.c_ulonglong(seed), stream()), "zs3_uniform")
+    return out
+
+
+def nearest_rows(src_chw, size, ld=None):
+    c, h, w_ = src_chw.shape
+    ho, wo = size
+    assert src_chw.is_contiguous()
+    ld = ld or c
+    rows = torch.zeros((ho * wo, ld), dtype=torch.float32, device=src_chw.device) if ld != c else torch.empty(
+        (ho * wo, ld), dtype=torch.float32, device=src_chw.device)
+    check(lib().zs3_nearest_rows(P(src_chw), I(c), I(h), I(w_), I(ho), I(wo), P(rows), I(ld), stream()), "zs3_nearest_rows")
+    return rows
+
+
+def gather_cat(a, idx, ca, b, cb, ldo):
+    n = b.shape[0]
+    out = torch.empty((n, ldo), dtype=torch.float32, device=a.device)
+    check(lib().zs3_gather_cat(P(a), I(a.stride(0)), P(idx), I(ca), P(b), I(b.stride(0)), I(cb), P(out), I(ldo),
+                               ctypes.c_long(n), stream()), "zs3_gather_cat")
+    return out
+
+
+def gather_rows(src, idx, c=None):
+    c = c or src.shape[1]
+    n = idx.shape[0]
+    out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    check(lib().zs3_gather_rows(P(src), I(src.stride(0)), P(idx), P(out), I(c), ctypes.c_long(n), I(c), stream()),
+          "zs3_gather_rows")
+    return out
+
+
+def scatter_rows(src, idx, out, c=None):
+    c = c or src.shape[1]
+    check(lib().zs3_scatter_rows(P(src), I(src.stride(0)), P(idx), P(out), I(out.stride(0)), ctypes.c_long(idx.shape[0]),
+                                 I(c), stream()), "zs3_scatter_rows")
+    return out
+
+
+def index_add_rows(src, idx, out, c=None):
+    c = c or src.shape[1]
+    check(lib().zs3_index_add_rows(P(src), I(src.stride(0)), P(idx), P(out), I(out.stride(0)), I(idx.shape[0]), I(c),
+                                   stream()), "zs3_index_add_rows")
     return out

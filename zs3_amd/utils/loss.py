@@ -1,0 +1,126 @@
+"""Losses -- drop-in for zs3.utils.loss (loss.py:5-115): SegmentationLosses(...).build_loss(mode) and
+GMMNLoss(...).build_loss(), computed by the HIP kernels in csrc/loss.hip."""
+import ctypes
+
+import torch
+
+from .. import ops
+from .._lib import F, I, P, check, lib, require_gpu, stream
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """sum_i w[t_i] * nll_i / sum_i w[t_i] over t_i != ignore_index, then / B (loss.py:31-46)."""
+
+    @staticmethod
+    def forward(ctx, logit, target, weight, ignore_index, batch):
+        require_gpu(logit, target, weight)
+        b, c, h, w = logit.shape
+        z = ops.nhwc(logit)                       # free view for channels_last logits
+        ld = ops._check_nhwc(z)
+        if target.dtype not in (torch.float32, torch.int64):
+            target = target.float()
+        target = target.contiguous()
+        pix = b * h * w
+        part = torch.empty(lib().zs3_ce_ws_doubles(), dtype=torch.float64, device=logit.device)
+        loss_ws = torch.empty(2, dtype=torch.float32, device=logit.device)
+        check(lib().zs3_ce_fwd(P(z), I(ld), P(target), I(int(target.dtype == torch.int64)), P(weight), ctypes.c_long(pix),
+                               I(c), I(ignore_index), I(batch), P(part), P(loss_ws), stream()), "zs3_ce_fwd")
+        ctx.save_for_backward(z, target, weight, loss_ws)
+        ctx.meta = (b, c, h, w, ld, ignore_index, batch)
+        return loss_ws[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        z, target, weight, loss_ws = ctx.saved_tensors
+        b, c, h, w, ld, ignore_index, batch = ctx.meta
+        gout = gout.contiguous().float()
+        dz = torch.empty((b, h, w, c), dtype=torch.float32, device=z.device)
+        check(lib().zs3_ce_bwd(P(z), I(ld), P(target), I(int(target.dtype == torch.int64)), P(weight),
+                               ctypes.c_long(b * h * w), I(c), I(ignore_index), I(batch), P(loss_ws), P(gout), P(dz), I(c),
+                               stream()), "zs3_ce_bwd")
+        return ops.nchw(dz), None, None, None, None
+
+
+def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True):
+    if weight is not None:
+        weight = weight.to(device=logit.device, dtype=torch.float32).contiguous()
+    return _CrossEntropy.apply(logit, target, weight, ignore_index, logit.shape[0] if batch_average else 0)
+
+
+class SegmentationLosses:
+    def __init__(self, weight=None, size_average=True, batch_average=True, ignore_index=255, cuda=False):
+        self.ignore_index = ignore_index
+        self.weight = weight
+        self.size_average = size_average
+        self.batch_average = batch_average
+        self.cuda = cuda
+        if not size_average:
+            raise NotImplementedError("size_average=False (sum reduction) is not used by any ZS3 script")
+
+    def build_loss(self, mode="ce"):
+        if mode == "ce":
+            return self.CrossEntropyLoss
+        elif mode == "focal":
+            return self.FocalLoss
+        elif mode == "ce_finetune":
+            return self.CrossEntropyLossFinetune
+        raise NotImplementedError
+
+    def CrossEntropyLoss(self, logit, target):
+        return cross_entropy_2d(logit, target, self.weight, self.ignore_index, self.batch_average)
+
+    def CrossEntropyLossFinetune(self, logit, target):
+        return cross_entropy_2d(logit, target, None, self.ignore_index, self.batch_average)
+
+    def FocalLoss(self, logit, target, gamma=2, alpha=0.5):
+        # focal weighting of the *scalar* CE, as the reference does (loss.py:62-81); scalar math on a 0-dim tensor
+        logpt = -cross_entropy_2d(logit, target, self.weight, self.ignore_index, False)
+        pt = torch.exp(logpt)
+        if alpha is not None:
+            logpt = logpt * alpha
+        loss = -((1 - pt) ** gamma) * logpt
+        if self.batch_average:
+            loss = loss / logit.shape[0]
+        return loss
+
+
+class _MMD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gen, real, sigma):
+        require_gpu(gen, real)
+        if gen.shape != real.shape:
+            raise NotImplementedError("GMMNLoss on MI355X requires as many generated as real samples (every ZS3 call "
+                                      "site samples batch_size_generator of each, train_pascal_GMMN.py:229-237)")
+        gen, real = gen.contiguous().float(), real.contiguous().float()
+        n, d = gen.shape
+        t = (2 * n + 31) // 32
+        g = torch.empty((2 * n, 2 * n), dtype=torch.float32, device=gen.device)
+        tile = torch.empty(2 * t * t, dtype=torch.float64, device=gen.device)
+        loss = torch.empty(1, dtype=torch.float32, device=gen.device)
+        sig = (ctypes.c_float * len(sigma))(*[float(s) for s in sigma])
+        check(lib().zs3_mmd_fwd(P(gen), I(d), P(real), I(d), I(n), I(d), sig, I(len(sigma)), P(g), P(tile), P(loss),
+                                stream()), "zs3_mmd_fwd")
+        ctx.save_for_backward(gen, real, g, loss)
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        gen, real, g, loss = ctx.saved_tensors
+        n, d = gen.shape
+        dgen = torch.empty_like(gen)
+        gout = gout.contiguous().float()
+        check(lib().zs3_mmd_bwd(P(gen), I(d), P(real), I(d), I(n), I(d), P(g), P(loss), P(gout), P(dgen), I(d), stream()),
+              "zs3_mmd_bwd")
+        return dgen, None, None
+
+
+class GMMNLoss:
+    def __init__(self, sigma=[2, 5, 10, 20, 40, 80], cuda=False):
+        self.sigma = list(sigma)
+        self.cuda = cuda
+
+    def build_loss(self):
+        return self.moment_loss
+
+    def moment_loss(self, gen_samples, x):
+        return _MMD.apply(gen_samples, x, tuple(self.sigma))
