@@ -111,9 +111,10 @@ int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr, int N, in
 
 /* ---- GMMN step helpers and optimisers (misc.hip) ---------------------------------------------- */
 /* nn.Dropout (aspp.py:100, decoder.py:19,23, gmmn.py:20): y = keep ? x/(1-p) : 0 with a counter-based mask
- * that is a pure function of (seed, element index); the backward is the same call on dy. */
+ * that is a pure function of (seed, element index); the backward is the same call on dy.  row_idx (optional,
+ * int64[M]): row m of x is row row_idx[m] of the tensor the mask was drawn for (sampled-row backward). */
 int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
-                void* stream);
+                const long* row_idx, void* stream);
 int zs3_uniform(float* out, long n, unsigned long long seed, void* stream);
 /* F.interpolate(mode="nearest") of one [C][H][W] image into pixel rows [ho*wo][ldo] (train_pascal_GMMN.py:175-195) */
 int zs3_nearest_rows(const float* src, int C, int H, int W, int ho, int wo, float* rows, int ldo, void* stream);

@@ -15,9 +15,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // ---- split-bf16 ("bf16x3") arithmetic ---------------------------------------------------------
 // An fp32 value x is carried through the matrix cores as hi + lo with hi = bf16(x) and
 // lo = bf16(x - hi); a product is hi*hi + hi*lo + lo*hi (three bf16 MFMAs, fp32 accumulate), the
-// dropped lo*lo term is <= 2^-16 |a b|.  Activations are split while they are staged into LDS
-// (hi by truncation: one bit-op, the remainder x - hi is exact in fp32 and lo rounds it to
-// nearest-even); weights are split once per step by zs3_prep_weight (both halves round-to-nearest).
+// dropped lo*lo term is <= 2^-18 |a b|.  Activations are split while they are staged into LDS (two
+// v_cvt_pk_bf16_f32 per pair of values: the remainder x - hi is exact in fp32); weights are split once
+// per step by zs3_prep_weight.  Both halves round to nearest even.
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // {bf16(a) low half, bf16(b) high half}, RNE
   unsigned r;
@@ -35,8 +35,8 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     hi = cvt_pk_bf16(a, b);
     lo = 0u;
   } else {
-    hi = pack_hi_trunc(a, b);
-    lo = cvt_pk_bf16(a - trunc_bf16_f32(a), b - trunc_bf16_f32(b));
+    hi = cvt_pk_bf16(a, b);  // round-to-nearest hi: |x - hi| <= 2^-9 |x|, remainder exact in fp32
+    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
   }
 }
 

@@ -24,13 +24,14 @@ inline int ew_blocks(long total) {
 
 // y[m][c] = keep(seed, m*C + c) ? x[m][c] / (1-p) : 0      (same kernel serves backward with x = dy)
 __global__ void dropout_kernel(const float* x, int ldx, float* y, int ldy, long M, int C, float p, float inv_keep,
-                               unsigned long long seed) {
+                               unsigned long long seed, const long* row_idx) {
   const long total = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / C;
     const int c = (int)(i - m * C);
     const float v = x[m * ldx + c];
-    y[m * ldy + c] = u01(seed, (unsigned long long)i) >= p ? v * inv_keep : 0.f;
+    const unsigned long long e = row_idx ? (unsigned long long)(row_idx[m] * C + c) : (unsigned long long)i;
+    y[m * ldy + c] = u01(seed, e) >= p ? v * inv_keep : 0.f;
   }
 }
 
@@ -118,10 +119,10 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
 }  // namespace
 
 extern "C" int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
-                           void* stream) {
+                           const long* row_idx, void* stream) {
   if (M <= 0) return 0;
   hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, p,
-                     1.f / (1.f - p), seed);
+                     1.f / (1.f - p), seed, row_idx);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -34,6 +34,12 @@ def weight_planes(w, need_t=True):
     return wp
 
 
+def invalidate_planes(*params):
+    """Drop cached planes of parameters that were updated through raw pointers (our fused optimizers)."""
+    for w in params:
+        _planes.pop(id(w), None)
+
+
 # ---------------------------------------------------------------------------------- RNG for dropout
 _rng = None
 

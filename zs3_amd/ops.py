@@ -288,12 +288,12 @@ def bilinear_bwd(dout, in_hw, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------- misc
-def dropout(x, p, seed, out=None):
+def dropout(x, p, seed, out=None, row_idx=None):
     m, c, ld = _rows(x)
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     check(lib().zs3_dropout(P(x), I(ld), P(out), I(_rows(out)[2]), ctypes.c_long(m), I(c), F(p),
-                            ctypes.c_ulonglong(seed), stream()), "zs3_dropout")
+                            ctypes.c_ulonglong(seed), P(row_idx), stream()), "zs3_dropout")
     return out
 
 
