@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- train images/sec of the ZS3 hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          # N>1: launched by torch.distributed.run
+
+Workload (config.workload): configs[1] of BASELINE.json -- the supervised DeepLabv3+ ResNet-101 training step of
+train_pascal.py (forward, CE, backward, SGD; base_trainer.py:16-20) on synthetic 513x513 batches, 16 images per GPU,
+21 classes, fp32 semantics computed as bf16x3 splits on the MFMA cores.  Weak scaling: every rank owns 16 images;
+gradients are SUM all-reduced over RCCL while backward runs (zs3_amd.parallel.GradSync).  The GMMN step
+(configs[2], train_pascal_GMMN.py:139-268) is timed after the main loop and reported under "gmmn".
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the 128x128 implicit-GEMM convolution)
+with HIP events recorded around every launch inside the timed region; `cpu_baseline` times the CPU oracle
+(oracle/zs3_oracle, the checked restatement of the reference) on the host cores for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FWD_GFLOP_PER_IMG = {21: 185.64, 60: 185.97}          # BASELINE.md section 3 (2*MAC, convs only)
+TRAIN_GFLOP_PER_IMG = {21: 555.7, 60: 556.7}          # fwd + dgrad + wgrad, no dgrad for the stem
+PEAK_BF16_TF = 2500.0                                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=513)
+    ap.add_argument("--classes", type=int, default=21)
+    ap.add_argument("--workload", choices=["supervised", "gmmn"], default="supervised")
+    ap.add_argument("--gmmn-steps", type=int, default=2)
+    ap.add_argument("--sync-bn", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from zs3_amd import ops
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.modeling.gmmn import GMMNnetwork
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.parallel import GradSync, broadcast_parameters, enable_sync_bn
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.lr_scheduler import LR_Scheduler
+    from zs3_amd.utils.synthetic import make_batch
+    from zs3_amd.gmmn_trainer import GMMNStep
+
+    unseen = [10, 14]
+    seen = [c for c in range(args.classes) if c not in unseen]
+    torch.manual_seed(1)
+    model = DeepLab(num_classes=args.classes, pretrained=False, sync_bn=bool(args.sync_bn)).to(dev).train()
+    broadcast_parameters(model)
+    if args.sync_bn and world > 1:
+        enable_sync_bn(model)
+    groups = [{"params": model.get_1x_lr_params(), "lr": 0.007}, {"params": model.get_10x_lr_params(), "lr": 0.07}]
+    opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
+    crit = SegmentationLosses(cuda=True, group=True if world > 1 else None).build_loss("ce")
+    sched = LR_Scheduler("poly", 0.007, 50, 1000, verbose=False)
+    sync = GradSync(list(model.parameters())) if world > 1 else None
+    batch = make_batch(args.batch, args.size, args.classes, unseen, seed=1 + rank, device=dev)
+    image, label = batch["image"], batch["label"]
+
+    def supervised_step(i):
+        sched(opt, i, 0, 0.0)
+        opt.zero_grad()
+        out = model(image)
+        loss = crit(out, label)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def run(step, steps, warmup):
+        for i in range(warmup):
+            step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = step(warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, last
+
+    gmmn_info = None
+
+    def build_gmmn():
+        gen = GMMNnetwork(300, 300, 256, 256).to(dev).train()
+        opt_g = Adam(gen.parameters(), lr=2e-4)
+        w = torch.ones(args.classes, device=dev)
+        w[unseen] = 100.0
+        crit_g = SegmentationLosses(weight=w, cuda=True).build_loss("ce")
+        gb = make_batch(args.batch, args.size, args.classes, unseen, seed=101 + rank, with_label_emb=True, device=dev)
+        stepper = GMMNStep(model, gen, opt, opt_g, crit_g, seen=seen, unseen=unseen, noise="device")
+        return lambda i: stepper(gb["image"], gb["label"], gb["label_emb"])
+
+    if args.workload == "supervised":
+        if not args.no_roofline:
+            ops.PROFILE = []
+            for i in range(args.warmup):
+                supervised_step(i)
+            ops.PROFILE = []
+            dt, last = run(supervised_step, args.steps, 0)
+            prof, ops.PROFILE = ops.PROFILE, None
+        else:
+            dt, last = run(supervised_step, args.steps, args.warmup)
+            prof = []
+        gflop_img = TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7)
+        if args.gmmn_steps > 0 and world == 1:
+            gstep = build_gmmn()
+            gdt, _ = run(gstep, args.gmmn_steps, 1)
+            gmmn_info = {"value": args.batch * args.gmmn_steps / gdt, "unit": "images/sec", "ms_per_step": 1e3 * gdt / args.gmmn_steps,
+                         "steps": args.gmmn_steps, "workload": "train_pascal_GMMN.py step (configs[2]), device noise"}
+    else:
+        gstep = build_gmmn()
+        prof = []
+        dt, last = run(gstep, args.steps, args.warmup)
+        gflop_img = 193.5
+
+    value = world * args.batch * args.steps / dt
+    result = {
+        "metric": "train images/sec, DeepLabv3+ (ResNet-101 dilated, ASPP, decoder) 513x513",
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate; fp32 storage)", "data": "synthetic",
+        "config": {"workload": ("train_pascal.py supervised step: DeepLabv3+ ResNet-101 fwd+CE+bwd+SGD (BASELINE configs[1])"
+                                if args.workload == "supervised" else "train_pascal_GMMN.py step (BASELINE configs[2])"),
+                   "image": f"{args.size}x{args.size}", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "classes": args.classes, "parallelism": f"dp{world}", "sync_bn": bool(args.sync_bn)},
+        "model_tflops": value * gflop_img / 1e3,
+        "model_frac_of_bf16_peak": value * gflop_img / 1e3 / (PEAK_BF16_TF * world),
+    }
+    if gmmn_info:
+        result["gmmn"] = gmmn_info
+    if rank == 0 and prof:
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, flops, e0, e1 in prof:
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        tag = max(agg, key=lambda k: agg[k][2])
+        n, fl, sec = agg[tag]
+        ach = fl / sec / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TF,
+            "traffic": None, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
+            "note": "achieved = algorithmic 2*M*N*K flops of the launches / HIP-event time; each product costs 3 bf16 MFMAs "
+                    "(bf16x3), so MFMA-issue utilisation is 3x this fraction",
+            "all_conv_igemm": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms_per_step": 1e3 * v[2] / args.steps}
+                               for k, v in agg.items()},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """The checked CPU restatement of the reference (oracle/, kind "port") on this node's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import zs3_oracle as zo
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    torch.manual_seed(1)
+    m = zo.DeepLab(num_classes=args.classes, pretrained=False).train()
+    groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+    opt = torch.optim.SGD(groups, momentum=0.9, weight_decay=5e-4)
+    crit = zo.SegmentationLosses().build_loss("ce")
+    bsz = 2
+    b = zo.make_synthetic_batch(bsz, args.size, args.classes, seed=1, with_label_emb=False)
+    zo.supervised_step(m, opt, crit, b["image"], b["label"])  # warm-up (oneDNN primitive creation)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        zo.supervised_step(m, opt, crit, b["image"], b["label"])
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": bsz / t, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle supervised step (fwd+CE+bwd+SGD), B={bsz} at {args.size}x{args.size}, 1 warm-up + 2 timed steps, "
+                      f"median; torch CPU fp32 with {threads} threads on a {cores}-core host"}
+
+
+if __name__ == "__main__":
+    main()

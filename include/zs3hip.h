@@ -94,7 +94,7 @@ int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int 
 
 /* ---- losses (loss.hip) ------------------------------------------------------------------------ */
 /* SegmentationLosses.CrossEntropyLoss (zs3/utils/loss.py:31-46): logits [P][ld] (P = B*H*W pixels, C classes),
- * target float32 or int64 [P]; loss_ws[0] = loss, loss_ws[1] = sum of weights; partial_ws: zs3_ce_ws_doubles()
+ * target float32 or int64 [P]; loss_ws (3 floats) = {loss, sum of weights, sum of w*nll}; partial_ws: zs3_ce_ws_doubles()
  * doubles.  batch = B for batch_average, 0 for none.  gout: device scalar (upstream gradient). */
 int zs3_ce_ws_doubles(void);
 int zs3_ce_fwd(const float* logits, int ld, const void* target, int target_is_i64, const float* weight, long P, int C,

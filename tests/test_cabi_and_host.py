@@ -1,0 +1,135 @@
+"""CPU-side checks: the C-ABI library loads and exports exactly what include/zs3hip.h declares, the product
+refuses to run without a GPU (no CPU fallback), host logic (LR schedule, synthetic batches, module surface)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from zs3_amd import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    header = open(os.path.join(ROOT, "include", "zs3hip.h")).read()
+    declared = set(re.findall(r"^int\s+(zs3_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(libpath)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in zs3hip.h but not exported"
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (zs3_\w+)", out))
+    assert exported == declared, (exported ^ declared)
+
+
+def test_host_side_planners_need_no_gpu(libpath):
+    lib = ctypes.CDLL(libpath)
+    assert lib.zs3_conv_igemm_mtiles(266256, 256, 1) == (266256 + 127) // 128
+    assert lib.zs3_conv_igemm_mtiles(100, 256, 4) == 2
+    sk, ws = ctypes.c_int(0), ctypes.c_long(0)
+    assert lib.zs3_conv_wgrad_plan(266256, 256, 256, 9, ctypes.byref(sk), ctypes.byref(ws)) == 0
+    assert sk.value >= 1 and (ws.value == 0 or ws.value == sk.value * 256 * 9 * 256)
+    ch, rpb = ctypes.c_int(0), ctypes.c_int(0)
+    lib.zs3_colstats_plan(1000, 64, ctypes.byref(ch), ctypes.byref(rpb))
+    assert ch.value * rpb.value >= 1000
+    assert lib.zs3_ce_ws_doubles() == 2048
+    # argument validation happens before any launch
+    assert lib.zs3_conv_igemm(None, None, None, None, None, None, None, None, 1, 8, 8, 8, 8, 30, 8, 8, 1, 1, 1, 0, 0, 1, 8, 8, 0, 0,
+                              ctypes.c_float(0.2), 0, 0, 3, 0, None) == -1
+
+
+def test_product_has_no_cpu_fallback():
+    from zs3_amd._lib import Zs3HipError
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.utils.loss import GMMNLoss, SegmentationLosses
+    torch.manual_seed(0)
+    m = DeepLab(num_classes=21, pretrained=False, sync_bn=False).eval()
+    with pytest.raises((Zs3HipError, RuntimeError)):
+        m(torch.randn(1, 3, 33, 33))
+    with pytest.raises(Zs3HipError):
+        SegmentationLosses().build_loss("ce")(torch.randn(1, 21, 9, 9), torch.zeros(1, 9, 9))
+    with pytest.raises(Zs3HipError):
+        GMMNLoss().build_loss()(torch.randn(8, 16), torch.randn(8, 16))
+    import zs3_amd
+    src = "".join(open(os.path.join(ROOT, "zs3_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "zs3_amd")) if f.endswith(".py"))
+    assert "zs3_oracle" not in src and "import oracle" not in src  # the checker is never reachable from the product
+
+
+def test_module_surface_matches_reference_interface(golden):
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.modeling.gmmn import GMMNnetwork
+    from zs3_amd.modeling.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
+    from zs3_amd.modeling.sync_batchnorm.replicate import patch_replication_callback
+    g = golden("init.npz")
+    torch.manual_seed(1)
+    m = DeepLab(num_classes=21, pretrained=False, sync_bn=False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["names21"]]
+    for k, r in zip(g["names21"], g["stats21"]):   # same seed => same weights as the reference constructor
+        t = sd[str(k)].double().reshape(-1)
+        assert abs(t.sum().item() - r[0]) <= 1e-9 * max(1.0, r[1]) and abs(t.abs().sum().item() - r[1]) <= 1e-9 * max(1.0, r[1]), k
+    assert sum(p.numel() for p in m.get_1x_lr_params()) == 42500160
+    assert sum(p.numel() for p in m.get_10x_lr_params()) == 16844149
+    for attr in ("backbone", "aspp", "decoder", "forward_before_class_prediction", "forward_class_prediction",
+                 "forward_before_last_conv_finetune", "forward_class_last_conv_finetune", "freeze_bn"):
+        assert hasattr(m, attr)
+    assert hasattr(m.decoder, "forward_class_prediction") and hasattr(m.decoder, "pred_conv")
+    torch.manual_seed(1)
+    m60 = DeepLab(num_classes=60, pretrained=False, sync_bn=True, global_avg_pool_bn=False)
+    assert list(m60.state_dict().keys()) == [str(k) for k in g["names60"]]
+    assert isinstance(m60.backbone.bn1, SynchronizedBatchNorm2d) and isinstance(m60.backbone.bn1, torch.nn.BatchNorm2d)
+    m60.train()
+    m60.freeze_bn()
+    assert not m60.backbone.bn1.training and m60.backbone.conv1.training
+    torch.manual_seed(1)
+    gen = GMMNnetwork(300, 300, 256, 256)
+    assert list(gen.state_dict().keys()) == [str(k) for k in g["names_g"]]
+    for k, r in zip(g["names_g"], g["stats_g"]):
+        assert abs(gen.state_dict()[str(k)].double().abs().sum().item() - r[1]) <= 1e-9 * max(1.0, r[1])
+    torch.manual_seed(3)
+    gen2 = GMMNnetwork(300, 300, 0, 256, semantic_reconstruction=True)
+    assert list(gen2.state_dict().keys()) == [str(k) for k in g["names_g2"]]
+    patch_replication_callback(torch.nn.DataParallel(torch.nn.Linear(2, 2), device_ids=None) if torch.cuda.is_available()
+                               else _FakeDP())
+    with pytest.raises(AssertionError):
+        patch_replication_callback(torch.nn.Linear(2, 2))
+    # a "pretrained" ImageNet checkpoint with the 7-character `module.` prefix loads (resnet.py:211-226)
+    import tempfile
+    ck = {"state_dict": {"module." + k: torch.full_like(v, 0.5) for k, v in m.backbone.state_dict().items() if "layer1.0.conv1" in k}}
+    with tempfile.NamedTemporaryFile(suffix=".pth") as f:
+        torch.save(ck, f.name)
+        m2 = DeepLab(num_classes=21, pretrained=True, sync_bn=False, imagenet_pretrained_path=f.name)
+    assert torch.all(m2.backbone.layer1[0].conv1.weight == 0.5)
+    assert m2.backbone.layer1[0].conv2.weight.is_contiguous(memory_format=torch.channels_last)
+
+
+class _FakeDP(torch.nn.DataParallel):
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+
+
+def test_lr_scheduler_and_synthetic_batch(golden):
+    from zs3_amd.utils.lr_scheduler import LR_Scheduler
+    from zs3_amd.utils.synthetic import make_batch
+    import zs3_oracle as zo
+    g = golden("misc.npz")
+    sch = LR_Scheduler("poly", 0.007, 3, 11, verbose=False)
+    opt = torch.optim.SGD([{"params": [torch.nn.Parameter(torch.zeros(1))]}, {"params": [torch.nn.Parameter(torch.zeros(1))]}], lr=0.1)
+    lrs = []
+    for ep in range(3):
+        for it in range(11):
+            sch(opt, it, ep, 0.0)
+            lrs.append([pg["lr"] for pg in opt.param_groups])
+    assert np.allclose(lrs, g["poly_lrs"], rtol=1e-12)
+    a = make_batch(4, 65, seed=5, with_label_emb=True, device="cpu")
+    b = zo.make_synthetic_batch(4, 65, seed=5, with_label_emb=True)
+    for k in ("image", "label", "table", "label_emb"):
+        assert torch.equal(a[k], b[k]), k   # the product's generator and the oracle's produce identical batches

@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests of the N>1 path (zs3_amd.parallel): bucketed gradient SUM all-reduce driven by
+grad hooks + end-of-backward callback, parameter broadcast, SyncBN partial-sum combination."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from zs3_amd.parallel import GradSync, broadcast_parameters, combine_bn_partials
+        torch.manual_seed(100 + rank)  # different init per rank: broadcast must fix it
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1), torch.nn.Flatten(),
+                                  torch.nn.Linear(4 * 6 * 6, 5), torch.nn.Linear(5, 3))
+        net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)
+        unused = torch.nn.Parameter(torch.zeros(7))  # never receives a gradient
+        broadcast_parameters(net)
+        ref = [p.detach().clone() for p in net.parameters()]
+        gathered = [torch.zeros_like(ref[0]) for _ in range(world)]
+        dist.all_gather(gathered, ref[0].contiguous())
+        assert torch.equal(gathered[0], gathered[1])
+        sync = GradSync(list(net.parameters()) + [unused], bucket_mb=0.0005)  # several buckets
+        assert len(sync.buckets) > 2
+        for it in range(2):
+            torch.manual_seed(7 + it)
+            xs = [torch.randn(2, 3, 6, 6) for _ in range(world)]
+            net.zero_grad()
+            loss = net(xs[rank]).square().sum()
+            loss.backward()   # hooks launch the all-reduces; the queued callback joins them
+            got = [p.grad.clone() for p in net.parameters()]
+            # reference: sum of the per-rank gradients computed locally without hooks
+            want = [torch.zeros_like(p) for p in net.parameters()]
+            for r in range(world):
+                clone = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+                h = torch.nn.functional.conv2d(xs[r], clone[0], clone[1], padding=1).relu()
+                h = torch.nn.functional.conv2d(h, clone[2], clone[3]).flatten(1)
+                h = torch.nn.functional.linear(torch.nn.functional.linear(h, clone[4], clone[5]), clone[6], clone[7])
+                gs = torch.autograd.grad(h.square().sum(), clone)
+                want = [w + g for w, g in zip(want, gs)]
+            for g_, w_ in zip(got, want):
+                assert torch.allclose(g_, w_, rtol=1e-5, atol=1e-6)
+            assert net[0].weight.grad.is_contiguous(memory_format=torch.channels_last)
+        assert sync.bytes_reduced > 0
+        # SyncBN statistics: global sums / count from per-rank chunk partials
+        part = torch.arange(2 * 2 * 4, dtype=torch.float32).reshape(2, 2, 4) * (rank + 1)
+        tot, cnt = combine_bn_partials(part, 10 * (rank + 1))
+        assert cnt == 30.0 and torch.equal(tot, (torch.arange(16.).reshape(2, 2, 4).sum(0, keepdim=True)) * 3)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

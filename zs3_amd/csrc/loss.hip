@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, int ld
   }
 }
 
-// out[0] = loss, out[1] = sum of weights over valid pixels
+// out[0] = loss, out[1] = sum of weights over valid pixels, out[2] = sum of w*nll (raw numerator, for multi-rank normalisation)
 __global__ void ce_finalize_kernel(const double* partial, int nblk, float inv_batch, float* out) {
   double l = 0.0, w = 0.0;
   for (int k = threadIdx.x; k < nblk; k += 64) {
@@ -55,6 +55,7 @@ __global__ void ce_finalize_kernel(const double* partial, int nblk, float inv_ba
   if (threadIdx.x == 0) {
     out[0] = (float)(l / w) * inv_batch;
     out[1] = (float)w;
+    out[2] = (float)l;
   }
 }
 

@@ -107,6 +107,9 @@ class _ConvBnAct(torch.autograd.Function):
             if count <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size "
                                  f"{(y.shape[0], y.shape[3], y.shape[1], y.shape[2])}")
+            if bn.get("sync") is not None:
+                from .parallel import combine_bn_partials
+                part, count = combine_bn_partials(part, count, None if bn["sync"] is True else bn["sync"])
             st = ops.bn_fwd_finalize(part, count, gamma, beta, bn["eps"], bn["momentum"], bn["running_mean"],
                                      bn["running_var"])
             a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak)
@@ -143,10 +146,18 @@ class _ConvBnAct(torch.autograd.Function):
         m = dA.shape[0] * dA.shape[1] * dA.shape[2] if dA.dim() == 4 else dA.shape[0]
         if ctx.has_bn:
             part = ops.bn_bwd_stats(dA, a, y, st[0], st[1])
-            fin = ops.bn_bwd_finalize(part, m, ctx.bn_training)
-            dgamma, dbeta = fin[0], fin[1]
-            dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, fin[2] if ctx.bn_training else None,
-                                fin[3] if ctx.bn_training else None, dres=dres, act=act, leak=leak)
+            sync = (cfg.get("bn") or {}).get("sync") if ctx.bn_training else None
+            if sync is not None:
+                from .parallel import combine_bn_partials
+                gpart, gcount = combine_bn_partials(part, m, None if sync is True else sync)
+                fin_l = ops.bn_bwd_finalize(part, m, False)       # per-rank dgamma / dbeta (summed later by GradSync)
+                fin_g = ops.bn_bwd_finalize(gpart, gcount, True)  # c1, c2 from the global sums and count
+                dgamma, dbeta, c1, c2 = fin_l[0], fin_l[1], fin_g[2], fin_g[3]
+            else:
+                fin = ops.bn_bwd_finalize(part, m, ctx.bn_training)
+                dgamma, dbeta = fin[0], fin[1]
+                c1, c2 = (fin[2], fin[3]) if ctx.bn_training else (None, None)
+            dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, dres=dres, act=act, leak=leak)
         else:
             cout = dA.shape[-1]
             vec_ok = cout % 4 == 0 and ops._rows(dA)[2] % 4 == 0
@@ -207,6 +218,7 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
             if mom is None:
                 mom = 1.0 / float(bn.num_batches_tracked)
         cfg["bn"] = {"training": use_batch, "eps": bn.eps, "momentum": mom if mom is not None else 0.0,
+                     "sync": getattr(bn, "_zs3_sync_group", None),
                      "running_mean": bn.running_mean if (bn.training and bn.track_running_stats) or not use_batch else None,
                      "running_var": bn.running_var if (bn.training and bn.track_running_stats) or not use_batch else None}
     return _ConvBnAct.apply(x, weight, gamma, beta, bias, residual, cfg)

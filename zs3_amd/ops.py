@@ -12,6 +12,14 @@ import torch
 from ._lib import F, I, P, check, lib, require_gpu, stream
 
 PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs
+PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event) per conv launch
+
+
+def pick_tile(m, ncols):
+    """Block-tile choice for the implicit-GEMM kernel (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64)."""
+    if ncols > 64:
+        return 1 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 160 else 3
+    return 2 if (m + 127) // 128 >= 160 else 4
 
 
 def _round_up(a, b):
@@ -99,14 +107,23 @@ def conv_igemm(x, w_hi, w_lo, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad
     ldy = _check_nhwc(out)
     ldr = _check_nhwc(res) if res is not None else 0
     m = n * ho * wo
+    if tile_cfg == 0:
+        tile_cfg = pick_tile(m, ncols)
     stat = None
     if want_stats:
         mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
         stat = torch.empty((mt, 2, ncols), dtype=torch.float32, device=x.device)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().zs3_conv_igemm(P(x), P(w_hi), P(w_lo), P(out), P(scale), P(shift), P(res), P(stat), I(n), I(h), I(w_),
                                I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h),
                                I(pad_w), I(dil), I(ncols), I(ldy), I(ldr), I(act), F(leak), I(int(accumulate)),
                                I(int(dgrad)), I(prec), I(tile_cfg), stream()), "zs3_conv_igemm")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg - 1]},{prec}>",
+                        2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1))
     return out, stat
 
 

@@ -1,0 +1,145 @@
+"""Data parallelism for one-process-per-GPU runs: RCCL (torch.distributed backend "nccl" on ROCm) over xGMI.
+
+The reference's multi-GPU path is single-process nn.DataParallel + a thread-based SyncBN
+(train_pascal.py:90-93, sync_batchnorm/*: collectives C1-C4 of SURVEY.md section 2.2).  Here every rank owns
+one MI355X and a shard of the batch; the only data-path exchange of the supervised step is the gradient
+all-reduce (237 MB fp32), issued per bucket from grad hooks while backward is still running -- RCCL
+executes on its own HIP stream, so the exchange overlaps with the remaining backward kernels -- and
+joined by an end-of-backward callback.  Reduction is SUM: the loss is already normalised by the *global*
+batch and valid-pixel weight (utils/loss.py, `group=`), which reproduces the reference's single-process
+loss exactly.  Works unchanged on CPU tensors with the gloo backend (tests/test_distributed_cpu.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, params, process_group=None, bucket_mb=64.0, average=False):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.average = average
+        self.params = [p for p in params if p.requires_grad]
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        # buckets follow REVERSE registration order: that is roughly the order in which backward produces grads
+        self.buckets, cur, cur_n = [], [], 0
+        for p in reversed(self.params):
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.where = [], {}
+        for bi, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for p in bucket)
+            self.flat.append(torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device))
+            off = 0
+            for p in bucket:
+                self.where[p] = (bi, off)
+                off += p.numel()
+        self._pending = [len(b) for b in self.buckets]
+        self._ready = [set() for _ in self.buckets]
+        self._works = [None] * len(self.buckets)
+        self._armed = False
+        self.bytes_reduced = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    # ---- hooks
+    def _hook(self, p):
+        if self.world == 1:
+            return
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        bi, off = self.where[p]
+        if p in self._ready[bi]:
+            return
+        self.flat[bi][off:off + p.numel()].copy_(_as_flat(p.grad, p))
+        self._ready[bi].add(p)
+        if len(self._ready[bi]) == len(self.buckets[bi]):
+            self._launch(bi)
+
+    def _launch(self, bi):
+        self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.bytes_reduced += self.flat[bi].numel() * 4
+
+    def finish(self):
+        """End of backward: flush incomplete buckets (parameters that received no gradient contribute zeros, so
+        every rank issues the same collectives), wait, and scatter the reduced values back into .grad."""
+        if self.world == 1:
+            return
+        for bi, bucket in enumerate(self.buckets):
+            if self._works[bi] is None and self._ready[bi]:
+                for p in bucket:
+                    if p not in self._ready[bi]:
+                        _, off = self.where[p]
+                        self.flat[bi][off:off + p.numel()].zero_()
+                self._launch(bi)
+        for bi, bucket in enumerate(self.buckets):
+            if self._works[bi] is None:
+                continue
+            self._works[bi].wait()
+            if self.average:
+                self.flat[bi].div_(self.world)
+            for p in bucket:
+                _, off = self.where[p]
+                src = self.flat[bi][off:off + p.numel()]
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                _as_flat(p.grad, p).copy_(src)
+            self._works[bi] = None
+            self._ready[bi] = set()
+        self._armed = False
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+
+
+def _as_flat(t, like):
+    """1-D view of a dense tensor in its own memory order (channels_last conv grads included)."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(-1)
+    return t.contiguous().view(-1)
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters and buffers (DataParallel.replicate, C1)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.is_contiguous() or t.dim() != 4:
+            dist.broadcast(t.data, src, group=group)
+        else:
+            flat = _as_flat(t.data, t).clone()
+            dist.broadcast(flat, src, group=group)
+            _as_flat(t.data, t).copy_(flat)
+
+
+def combine_bn_partials(partial, count, group=None):
+    """SyncBN statistics (batchnorm.py:60-67,101-122 of the vendored module: sum / sum-of-squares reduced
+    over replicas): collapse the per-chunk partial sums [chunks,2,C] to one row, all-reduce it together with
+    the sample count.  Returns ([1,2,C] global sums, global count)."""
+    tot = partial.sum(0, keepdim=True)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return tot, count
+    cnt = torch.tensor([float(count)], dtype=torch.float64, device=partial.device)
+    dist.all_reduce(tot, group=group)
+    dist.all_reduce(cnt, group=group)
+    return tot, float(cnt.item())
+
+
+def enable_sync_bn(module, group=None):
+    """Honour sync_bn=True across ranks: batch statistics (forward) and their gradients (backward) of every
+    SynchronizedBatchNorm2d are all-reduced.  Uses (var + eps)^-1/2 like F.batch_norm, not the vendored
+    clamp(var, eps)^-1/2 ('SyncBN semantics')."""
+    from .modeling.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
+    n = 0
+    for m in module.modules():
+        if isinstance(m, SynchronizedBatchNorm2d):
+            m._zs3_sync_group = group if group is not None else True
+            n += 1
+    return n

@@ -12,7 +12,7 @@ class _CrossEntropy(torch.autograd.Function):
     """sum_i w[t_i] * nll_i / sum_i w[t_i] over t_i != ignore_index, then / B (loss.py:31-46)."""
 
     @staticmethod
-    def forward(ctx, logit, target, weight, ignore_index, batch):
+    def forward(ctx, logit, target, weight, ignore_index, batch, group):
         require_gpu(logit, target, weight)
         b, c, h, w = logit.shape
         z = ops.nhwc(logit)                       # free view for channels_last logits
@@ -22,12 +22,22 @@ class _CrossEntropy(torch.autograd.Function):
         target = target.contiguous()
         pix = b * h * w
         part = torch.empty(lib().zs3_ce_ws_doubles(), dtype=torch.float64, device=logit.device)
-        loss_ws = torch.empty(2, dtype=torch.float32, device=logit.device)
+        loss_ws = torch.empty(3, dtype=torch.float32, device=logit.device)
         check(lib().zs3_ce_fwd(P(z), I(ld), P(target), I(int(target.dtype == torch.int64)), P(weight), ctypes.c_long(pix),
                                I(c), I(ignore_index), I(batch), P(part), P(loss_ws), stream()), "zs3_ce_fwd")
+        loss = loss_ws[0].clone()
+        if group is not None:
+            # exact multi-rank normalisation: global sum(w*nll) / global sum(w) / global batch (loss.py:33-46 on the
+            # gathered batch of DataParallel); gradients are then SUM-reduced by GradSync
+            import torch.distributed as dist
+            pg = None if group is True else group
+            dist.all_reduce(loss_ws[1:3], group=pg)
+            world = dist.get_world_size(pg)
+            batch = batch * world
+            loss = loss_ws[2] / loss_ws[1] / (batch if batch > 0 else 1)
         ctx.save_for_backward(z, target, weight, loss_ws)
         ctx.meta = (b, c, h, w, ld, ignore_index, batch)
-        return loss_ws[0].clone()
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
@@ -38,17 +48,19 @@ class _CrossEntropy(torch.autograd.Function):
         check(lib().zs3_ce_bwd(P(z), I(ld), P(target), I(int(target.dtype == torch.int64)), P(weight),
                                ctypes.c_long(b * h * w), I(c), I(ignore_index), I(batch), P(loss_ws), P(gout), P(dz), I(c),
                                stream()), "zs3_ce_bwd")
-        return ops.nchw(dz), None, None, None, None
+        return ops.nchw(dz), None, None, None, None, None
 
 
-def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True):
+def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True, group=None):
+    """group: None (single process) | True (default process group) | a torch.distributed group."""
     if weight is not None:
         weight = weight.to(device=logit.device, dtype=torch.float32).contiguous()
-    return _CrossEntropy.apply(logit, target, weight, ignore_index, logit.shape[0] if batch_average else 0)
+    return _CrossEntropy.apply(logit, target, weight, ignore_index, logit.shape[0] if batch_average else 0, group)
 
 
 class SegmentationLosses:
-    def __init__(self, weight=None, size_average=True, batch_average=True, ignore_index=255, cuda=False):
+    def __init__(self, weight=None, size_average=True, batch_average=True, ignore_index=255, cuda=False, group=None):
+        self.group = group
         self.ignore_index = ignore_index
         self.weight = weight
         self.size_average = size_average
@@ -67,14 +79,14 @@ class SegmentationLosses:
         raise NotImplementedError
 
     def CrossEntropyLoss(self, logit, target):
-        return cross_entropy_2d(logit, target, self.weight, self.ignore_index, self.batch_average)
+        return cross_entropy_2d(logit, target, self.weight, self.ignore_index, self.batch_average, self.group)
 
     def CrossEntropyLossFinetune(self, logit, target):
-        return cross_entropy_2d(logit, target, None, self.ignore_index, self.batch_average)
+        return cross_entropy_2d(logit, target, None, self.ignore_index, self.batch_average, self.group)
 
     def FocalLoss(self, logit, target, gamma=2, alpha=0.5):
         # focal weighting of the *scalar* CE, as the reference does (loss.py:62-81); scalar math on a 0-dim tensor
-        logpt = -cross_entropy_2d(logit, target, self.weight, self.ignore_index, False)
+        logpt = -cross_entropy_2d(logit, target, self.weight, self.ignore_index, False, self.group)
         pt = torch.exp(logpt)
         if alpha is not None:
             logpt = logpt * alpha
