@@ -15,11 +15,13 @@ extern "C" {
 #endif
 
 /* ---- operand preparation ------------------------------------------------------------------ */
-/* Split a conv / linear weight [cout][taps][cin] fp32 into bf16 hi/lo planes [cout][taps][cin_pad]
- * (f_*) and, when t_hi != NULL, the dgrad planes [cin][taps][cout_pad] (t_*).  cin_pad, cout_pad:
- * multiples of 32.  Replaces nothing in the reference (cuDNN consumed fp32 weights directly). */
-int zs3_prep_weight(const float* w, void* f_hi, void* f_lo, void* t_hi, void* t_lo, int cout, int taps, int cin,
-                    int cin_pad, int cout_pad, void* stream);
+/* Split a conv / linear weight [cout][taps][cin] fp32 into bf16 hi/lo halves, stored
+ * [row][K/32][{hi,lo}][32] (one 128-byte line per row and 32-wide K chunk): f_pk rows = cout with
+ * K = taps*cin_pad (forward operand), and when t_pk != NULL rows = cin with K = taps*cout_pad (dgrad
+ * operand).  cin_pad, cout_pad: multiples of 32.  Byte size of each: rows*K*4.  Replaces nothing in the
+ * reference (cuDNN consumed fp32 weights directly). */
+int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
+                    void* stream);
 /* NCHW 3-channel image -> [N][H][Wp][4] zero-padded NHWC4 (image at columns [left,left+W)).  Feeds
  * the 7x7/s2 stem (resnet.py:79) as a 7x1 conv over 32-float (8 pixel x 4 ch) windows. */
 int zs3_nchw3_to_nhwc4(const float* img, float* out, int N, int H, int W, int Wp, int left, void* stream);
@@ -27,20 +29,20 @@ int zs3_nchw3_to_nhwc4(const float* img, float* out, int N, int H, int W, int Wp
 /* ---- implicit-GEMM convolution (forward and data-gradient) --------------------------------- */
 /* y[m,co] (+)= act(scale[co]*conv(x,w)[m,co] + shift[co] + res[m,co]),  m = (n,ho,wo).
  * x: NHWC fp32, spatial N x H x W, pixel stride ldx; K axis per tap = cin_pad channels of which
- * cin_valid (multiple of 8) are read, the rest are zeros.  w_hi/w_lo: planes from zs3_prep_weight
- * with row stride KH*KW*cin_pad.  stat_partial (optional): [mtiles][2][ncols] per-row-tile sums and
+ * cin_valid (multiple of 4) are read, the rest are zeros.  w_pk: operand from zs3_prep_weight (K = KH*KW*cin_pad).  stat_partial (optional): [mtiles][2][ncols] per-row-tile sums and
  * sums of squares of the raw conv output (BatchNorm batch statistics), mtiles = zs3_conv_igemm_mtiles.
  * dgrad=1: rows are input-gradient pixels (N x Ho x Wo = the conv's input extent), x is dy (N x H x W
- * = the conv's output extent), w planes are the transposed t_* planes.
+ * = the conv's output extent), w_pk is the t_pk operand.
  * act: 0 none, 1 ReLU, 2 LeakyReLU(leak).  prec: 3 = bf16x3 split (fp32-class), 1 = plain bf16.
- * tile_cfg: 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64.
+ * tile_cfg: 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64 (+10: two-deep register prefetch).  zero_page: >= 256 bytes of
+ * device zeros (16-byte aligned) that masked loads are redirected to; stride must be a power of two.
  * Replaces nn.Conv2d fwd / convolution_backward(input) at resnet.py:16-28,79,125-131; aspp.py:11-19,
  * 86,97; decoder.py:12,16,20,26; and nn.Linear of gmmn.py:18,33. */
-int zs3_conv_igemm(const float* x, const void* w_hi, const void* w_lo, float* y, const float* scale,
+int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scale,
                    const float* shift, const float* res, float* stat_partial, int N, int H, int W, int Ho, int Wo,
                    int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w, int dil,
                    int ncols, int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec,
-                   int tile_cfg, void* stream);
+                   int tile_cfg, const void* zero_page, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
 
 /* ---- weight gradient ------------------------------------------------------------------------- */

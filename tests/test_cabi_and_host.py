@@ -42,8 +42,8 @@ def test_host_side_planners_need_no_gpu(libpath):
     assert ch.value * rpb.value >= 1000
     assert lib.zs3_ce_ws_doubles() == 2048
     # argument validation happens before any launch
-    assert lib.zs3_conv_igemm(None, None, None, None, None, None, None, None, 1, 8, 8, 8, 8, 30, 8, 8, 1, 1, 1, 0, 0, 1, 8, 8, 0, 0,
-                              ctypes.c_float(0.2), 0, 0, 3, 0, None) == -1
+    assert lib.zs3_conv_igemm(None, None, None, None, None, None, None, 1, 8, 8, 8, 8, 30, 8, 8, 1, 1, 1, 0, 0, 1, 8, 8, 0, 0,
+                              ctypes.c_float(0.2), 0, 0, 3, 0, None, None) == -1
 
 
 def test_product_has_no_cpu_fallback():

@@ -4,7 +4,8 @@
 //
 // GEMM view: M = N*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin.  Activations are NHWC fp32 in HBM
 // (channel-contiguous => the K axis of one filter tap is a contiguous 128-byte run per pixel, so
-// the A gather is coalesced); weights arrive pre-split as two bf16 planes [Cout][K] (zs3_prep_weight).
+// the A gather is coalesced); weights arrive pre-split as bf16 hi/lo, interleaved per 32-wide K chunk
+// ([Cout][K/32][{hi,lo}][32], zs3_prep_weight) so that a (row, chunk) is one 128-byte line as well.
 // The A tile is split into bf16 hi/lo while it is staged into LDS, and every 32x32x16 MFMA is issued
 // three times (lo*hi, hi*lo, hi*hi) into one fp32 accumulator ("bf16x3", common.h) -- fp32-class
 // accuracy on the bf16 matrix cores.  PREC=1 issues only hi*hi (plain bf16 inputs).
@@ -26,25 +27,24 @@ namespace {
 
 struct ConvArgs {
   const float* x;
-  const unsigned short* w_hi;
-  const unsigned short* w_lo;
+  const unsigned short* w_pk;   // [ncols][K/32][{hi,lo}][32] bf16 (zs3_prep_weight)
   float* y;
   const float* scale;
   const float* shift;
   const float* res;
   float* stat_partial;
+  const float* zero;   // >= 256 B of zeros: source of every masked (padding / out-of-range) load
   int N, H, W, Ho, Wo;
   int cin_pad, cin_valid, ldx;
   int KH, KW, stride, pad_h, pad_w, dil;
   int ncols, ldw, ldy, ldr, M;
-  int act, accumulate, dgrad;
+  int act, accumulate, dgrad, stride_log2;
   float leak;
 };
 
-template <int BM, int BN, int PREC>
+template <int BM, int BN, int PREC, int PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int ROW = 72;               // bf16 per LDS row (144 B)
-  constexpr int RA = BM / 64, RB = BN / 64;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int STAGE = (BM + BN) * ROW;
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
@@ -56,14 +56,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int mt = bid / ntn, nt = bid - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  // ---- per-thread staging coordinates
-  const int srow = tid >> 2, kc = (tid & 3) * 8;
+  // ---- per-thread staging coordinates.  Every global load instruction covers whole 128-byte lines: 8 lanes
+  // x 16 B walk one tile row (32 fp32 of A, or the 64 B hi + 64 B lo of B that zs3_prep_weight interleaves per
+  // 32-wide K chunk), 8 rows per wave instruction.  Row group g = tid>>3 is bit-swapped (bits 0 <-> 2) so that the
+  // lanes serviced together by one LDS write cycle land on rows 4 apart (144-byte rows => disjoint bank halves).
+  const int q = tid & 7, tg = tid >> 3;
+  const int srow = (tg & ~5) | ((tg & 1) << 2) | ((tg >> 2) & 1);   // 0..31
+  constexpr int RA = BM / 32, RB = BN / 32;                          // rows of A / B staged per thread
   const float* xrow[RA];
   int bh[RA], bw[RA];
   bool rvalid[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    int m = m0 + srow + 64 * i;
+    int m = m0 + srow + 32 * i;
     rvalid[i] = m < p.M;
     int mm = rvalid[i] ? m : 0;
     int hw = p.Ho * p.Wo;
@@ -78,57 +83,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       bw[i] = ow * p.stride - p.pad_w;
     }
   }
-  const unsigned short* wrow_hi[RB];
-  const unsigned short* wrow_lo[RB];
-  bool cvalid[RB];
+  const unsigned short* wrow[RB];
+  int wstep[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
-    int col = n0 + srow + 64 * j;
-    cvalid[j] = col < p.ncols;
-    size_t off = (size_t)(cvalid[j] ? col : 0) * p.ldw + kc;
-    wrow_hi[j] = p.w_hi + off;
-    wrow_lo[j] = p.w_lo + off;
+    int col = n0 + srow + 32 * j;
+    bool ok = col < p.ncols;
+    wrow[j] = ok ? p.w_pk + (size_t)col * (2 * p.ldw) + q * 8 : reinterpret_cast<const unsigned short*>(p.zero);
+    wstep[j] = ok ? 1 : 0;   // masked columns keep re-reading the zero page
   }
 
-  f32x4 areg[RA][2];
-  u32x4 breg_hi[RB], breg_lo[RB];
+  struct Stage {
+    f32x4 areg[RA];
+    u32x4 breg[RB];
+  };
   int kh = 0, kw = 0, c0 = 0, kofs = 0;
 
-  auto load_tile = [&]() {
+  // Branch-free tile loads: masked lanes read the zero page, so the loop body is straight-line code.  The
+  // per-row gather address (bounds checks, 64-bit pointer) is recomputed only when a new filter tap
+  // starts (c0 == 0, a wave-uniform test); inside a tap the pointer just advances by 32 channels.
+  const float* abase[RA];
+  int astep[RA];
+  auto load_tile = [&](Stage& S) {
+    if (c0 == 0) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        int hi, wi;
+        bool ok = rvalid[i];
+        if (p.dgrad) {
+          const int th = bh[i] - kh * p.dil, tw = bw[i] - kw * p.dil;
+          const int mask = (1 << p.stride_log2) - 1;
+          hi = th >> p.stride_log2;
+          wi = tw >> p.stride_log2;
+          ok = ok && ((th | tw) >= 0) && (((th | tw) & mask) == 0);
+        } else {
+          hi = bh[i] + kh * p.dil;
+          wi = bw[i] + kw * p.dil;
+          ok = ok && ((hi | wi) >= 0);
+        }
+        ok = ok && hi < p.H && wi < p.W;
+        abase[i] = ok ? xrow[i] + ((hi * p.W + wi) * p.ldx + q * 4) : p.zero;
+        astep[i] = ok ? 1 : 0;
+      }
+    }
+    const bool cok = c0 + q * 4 < p.cin_valid;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      int hi, wi;
-      bool ok = rvalid[i] && (c0 + kc < p.cin_valid);
-      if (p.dgrad) {
-        int th = bh[i] - kh * p.dil, tw = bw[i] - kw * p.dil;
-        hi = th / p.stride;
-        wi = tw / p.stride;
-        ok = ok && th >= 0 && tw >= 0 && (hi * p.stride == th) && (wi * p.stride == tw);
-      } else {
-        hi = bh[i] + kh * p.dil;
-        wi = bw[i] + kw * p.dil;
-        ok = ok && hi >= 0 && wi >= 0;
-      }
-      ok = ok && hi < p.H && wi < p.W;
-      if (ok) {
-        const float* ptr = xrow[i] + ((size_t)hi * p.W + wi) * p.ldx + c0 + kc;
-        areg[i][0] = *reinterpret_cast<const f32x4*>(ptr);
-        areg[i][1] = *reinterpret_cast<const f32x4*>(ptr + 4);
-      } else {
-        areg[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        areg[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      const float* ptr = cok ? abase[i] + c0 * astep[i] : p.zero;
+      S.areg[i] = *reinterpret_cast<const f32x4*>(ptr);
     }
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      if (cvalid[j]) {
-        breg_hi[j] = *reinterpret_cast<const u32x4*>(wrow_hi[j] + kofs);
-        if (PREC == 3) breg_lo[j] = *reinterpret_cast<const u32x4*>(wrow_lo[j] + kofs);
-      } else {
-        breg_hi[j] = u32x4{0u, 0u, 0u, 0u};
-        breg_lo[j] = u32x4{0u, 0u, 0u, 0u};
-      }
-    }
+    for (int j = 0; j < RB; ++j) S.breg[j] = *reinterpret_cast<const u32x4*>(wrow[j] + 2 * kofs * wstep[j]);
   };
   auto advance = [&]() {
     kofs += 32;
@@ -141,27 +146,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       }
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](Stage& S, int stage) {
     unsigned short* As = smem + stage * STAGE;
     unsigned short* Bs = As + BM * ROW;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      u32x4 hi, lo;
+      u32x2 hi, lo;
       unsigned h, l;
-      split_pair<PREC>(areg[i][0][0], areg[i][0][1], h, l); hi[0] = h; lo[0] = l;
-      split_pair<PREC>(areg[i][0][2], areg[i][0][3], h, l); hi[1] = h; lo[1] = l;
-      split_pair<PREC>(areg[i][1][0], areg[i][1][1], h, l); hi[2] = h; lo[2] = l;
-      split_pair<PREC>(areg[i][1][2], areg[i][1][3], h, l); hi[3] = h; lo[3] = l;
-      unsigned short* dst = As + (srow + 64 * i) * ROW + kc;
-      *reinterpret_cast<u32x4*>(dst) = hi;
-      if (PREC == 3) *reinterpret_cast<u32x4*>(dst + 32) = lo;
+      split_pair<PREC>(S.areg[i][0], S.areg[i][1], h, l); hi[0] = h; lo[0] = l;
+      split_pair<PREC>(S.areg[i][2], S.areg[i][3], h, l); hi[1] = h; lo[1] = l;
+      unsigned short* dst = As + (srow + 32 * i) * ROW + q * 4;
+      *reinterpret_cast<u32x2*>(dst) = hi;
+      if (PREC == 3) *reinterpret_cast<u32x2*>(dst + 32) = lo;
     }
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      unsigned short* dst = Bs + (srow + 64 * j) * ROW + kc;
-      *reinterpret_cast<u32x4*>(dst) = breg_hi[j];
-      if (PREC == 3) *reinterpret_cast<u32x4*>(dst + 32) = breg_lo[j];
-    }
+    for (int j = 0; j < RB; ++j)
+      *reinterpret_cast<u32x4*>(Bs + (srow + 32 * j) * ROW + (q & 3) * 8 + (q >> 2) * 32) = S.breg[j];
   };
 
   f32x16 acc[TM][TN];
@@ -188,33 +188,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         b_hi[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROW + kk * 16);
         if (PREC == 3) b_lo[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROW + kk * 16 + 32);
       }
+      if (PREC == 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (PREC == 3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-          }
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-        }
     }
   };
 
   const int KT = p.KH * p.KW * (p.cin_pad / 32);
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) {
-      advance();
-      load_tile();
-    }
-    compute(cur);
-    if (more) store_tile(cur ^ 1);
+  if (PIPE == 1) {
+    // one register stage: loads of step k+1 fly during the MFMAs of step k
+    Stage s0;
+    load_tile(s0);
+    store_tile(s0, 0);
     __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < KT;
+      if (more) {
+        advance();
+        load_tile(s0);
+      }
+      compute(cur);
+      if (more) store_tile(s0, cur ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // two register stages: a tile's global loads are issued two K steps before they are written to LDS
+    Stage s0, s1;
+    load_tile(s0);
+    if (KT > 1) {
+      advance();
+      load_tile(s1);
+    }
+    store_tile(s0, 0);
+    if (KT > 2) {
+      advance();
+      load_tile(s0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+      compute(0);
+      if (kt + 1 < KT) store_tile(s1, 1);
+      if (kt + 3 < KT) {
+        advance();
+        load_tile(s1);
+      }
+      __syncthreads();
+      if (kt + 1 >= KT) break;
+      compute(1);
+      if (kt + 2 < KT) store_tile(s0, 0);
+      if (kt + 4 < KT) {
+        advance();
+        load_tile(s0);
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue 1: per-channel partial sums of the raw conv output (BatchNorm batch statistics)
@@ -278,14 +320,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PIPE>
 int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   int mt = (a.M + BM - 1) / BM, nt = (a.ncols + BN - 1) / BN;
   dim3 grid(mt * nt), block(256);
   if (prec == 1)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, PIPE>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 3>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 3, PIPE>), grid, block, 0, st, a);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -298,26 +340,31 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
     long blocks = (long)((M + 127) / 128) * ((ncols + bn - 1) / bn);
     if (blocks < 512) bm = 64;
   } else {
-    bm = (tile_cfg == 3 || tile_cfg == 4) ? 64 : 128;
+    int t = tile_cfg % 10;
+    bm = (t == 3 || t == 4) ? 64 : 128;
   }
   return (M + bm - 1) / bm;
 }
 
-extern "C" int zs3_conv_igemm(const float* x, const void* w_hi, const void* w_lo, float* y, const float* scale,
+extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scale,
                               const float* shift, const float* res, float* stat_partial, int N, int H, int W,
                               int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
                               int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int act, float leak,
-                              int accumulate, int dgrad, int prec, int tile_cfg, void* stream) {
-  if (cin_pad % 32 != 0 || cin_valid % 8 != 0 || ldx % 4 != 0 || (prec != 1 && prec != 3)) return -1;
-  if (((uintptr_t)x & 15) || ((uintptr_t)w_hi & 15) || ((uintptr_t)w_lo & 15)) return -2;
+                              int accumulate, int dgrad, int prec, int tile_cfg, const void* zero_page, void* stream) {
+  if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 1 && prec != 3)) return -1;
+  if (stride < 1 || (stride & (stride - 1)) != 0 || zero_page == nullptr) return -1;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w_pk & 15) || ((uintptr_t)zero_page & 15)) return -2;
   ConvArgs a;
-  a.x = x; a.w_hi = (const unsigned short*)w_hi; a.w_lo = (const unsigned short*)w_lo; a.y = y;
+  a.x = x; a.w_pk = (const unsigned short*)w_pk; a.y = y;
   a.scale = scale; a.shift = shift; a.res = res; a.stat_partial = stat_partial;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
   a.cin_pad = cin_pad; a.cin_valid = cin_valid; a.ldx = ldx;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil;
   a.ncols = ncols; a.ldw = KH * KW * cin_pad; a.ldy = ldy; a.ldr = ldr; a.M = N * Ho * Wo;
   a.act = act; a.accumulate = accumulate; a.dgrad = dgrad; a.leak = leak;
+  a.zero = (const float*)zero_page;
+  a.stride_log2 = 0;
+  while ((1 << a.stride_log2) < stride) ++a.stride_log2;
   if (a.M <= 0 || ncols <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int cfg = tile_cfg;
@@ -328,10 +375,14 @@ extern "C" int zs3_conv_igemm(const float* x, const void* w_hi, const void* w_lo
     cfg = bn == 128 ? (small ? 3 : 1) : (small ? 4 : 2);
   }
   switch (cfg) {
-    case 1: return launch_cfg<128, 128>(a, prec, st);
-    case 2: return launch_cfg<128, 64>(a, prec, st);
-    case 3: return launch_cfg<64, 128>(a, prec, st);
-    case 4: return launch_cfg<64, 64>(a, prec, st);
+    case 1: return launch_cfg<128, 128, 1>(a, prec, st);
+    case 2: return launch_cfg<128, 64, 1>(a, prec, st);
+    case 3: return launch_cfg<64, 128, 1>(a, prec, st);
+    case 4: return launch_cfg<64, 64, 1>(a, prec, st);
+    case 11: return launch_cfg<128, 128, 2>(a, prec, st);
+    case 12: return launch_cfg<128, 64, 2>(a, prec, st);
+    case 13: return launch_cfg<64, 128, 2>(a, prec, st);
+    case 14: return launch_cfg<64, 64, 2>(a, prec, st);
   }
   return -3;
 }

@@ -6,14 +6,18 @@
 namespace {
 
 // w: [cout][taps][cin] fp32 (the channels_last storage of an OIHW parameter).
-// fwd planes : [cout][taps][cin_pad]            (k = (tap, ci), zero padded channels)
-// dgrad planes: [cin][taps][cout_pad]           (k = (tap, co))
-__global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ f_hi,
-                                   unsigned short* __restrict__ f_lo, unsigned short* __restrict__ t_hi,
-                                   unsigned short* __restrict__ t_lo, int cout, int taps, int cin, int cin_pad,
+// forward operand: rows = cout, k = (tap, ci) with ci zero-padded to cin_pad
+// dgrad operand  : rows = cin,  k = (tap, co) with co zero-padded to cout_pad
+// Both are stored [row][k/32][{hi,lo}][32] bf16: the hi and lo halves of one 32-wide K chunk are adjacent,
+// so a (row, chunk) is one 128-byte line for the conv kernel's staging loads.
+__device__ __forceinline__ long packed_index(long row, long k, long ktot, int half) {
+  return ((row * (ktot >> 5) + (k >> 5)) * 2 + half) * 32 + (k & 31);
+}
+__global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ f_pk,
+                                   unsigned short* __restrict__ t_pk, int cout, int taps, int cin, int cin_pad,
                                    int cout_pad) {
   const long nf = (long)cout * taps * cin_pad;
-  const long nt = t_hi ? (long)cin * taps * cout_pad : 0;
+  const long nt = t_pk ? (long)cin * taps * cout_pad : 0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nt; i += (long)gridDim.x * blockDim.x) {
     float v = 0.f;
     unsigned short *dh, *dl;
@@ -22,16 +26,18 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* 
       long r = i / cin_pad;
       int tap = (int)(r % taps), co = (int)(r / taps);
       if (ci < cin) v = w[((long)co * taps + tap) * cin + ci];
-      dh = f_hi + i;
-      dl = f_lo + i;
+      const long ktot = (long)taps * cin_pad, k = (long)tap * cin_pad + ci;
+      dh = f_pk + packed_index(co, k, ktot, 0);
+      dl = f_pk + packed_index(co, k, ktot, 1);
     } else {
-      long k = i - nf;
-      int co = (int)(k % cout_pad);
-      long r = k / cout_pad;
+      long kk = i - nf;
+      int co = (int)(kk % cout_pad);
+      long r = kk / cout_pad;
       int tap = (int)(r % taps), ci = (int)(r / taps);
       if (co < cout) v = w[((long)co * taps + tap) * cin + ci];
-      dh = t_hi + k;
-      dl = t_lo + k;
+      const long ktot = (long)taps * cout_pad, k = (long)tap * cout_pad + co;
+      dh = t_pk + packed_index(ci, k, ktot, 0);
+      dl = t_pk + packed_index(ci, k, ktot, 1);
     }
     unsigned short h = f32_to_bf16_rne(v);
     *dh = h;
@@ -62,15 +68,14 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __re
 
 }  // namespace
 
-extern "C" int zs3_prep_weight(const float* w, void* f_hi, void* f_lo, void* t_hi, void* t_lo, int cout, int taps,
-                               int cin, int cin_pad, int cout_pad, void* stream) {
-  long total = (long)cout * taps * cin_pad + (t_hi ? (long)cin * taps * cout_pad : 0);
+extern "C" int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad,
+                               int cout_pad, void* stream) {
+  long total = (long)cout * taps * cin_pad + (t_pk ? (long)cin * taps * cout_pad : 0);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) return 0;
-  hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)f_hi,
-                     (unsigned short*)f_lo, (unsigned short*)t_hi, (unsigned short*)t_lo, cout, taps, cin, cin_pad,
-                     cout_pad);
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)f_pk,
+                     (unsigned short*)t_pk, cout, taps, cin, cin_pad, cout_pad);
   return ZS3_LAUNCH_CHECK();
 }
 

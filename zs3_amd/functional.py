@@ -100,7 +100,7 @@ class _ConvBnAct(torch.autograd.Function):
         prec = cfg.get("prec")
         y = a = st = None
         conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, **k)) if geom is None else (
-            lambda **k: ops.conv_igemm(x, wp.f_hi, wp.f_lo, prec=prec, **geom, **k))
+            lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, **geom, **k))
         if bn is not None and bn["training"]:
             y, part = conv(want_stats=True)
             count = y.shape[0] * y.shape[1] * y.shape[2]
