@@ -54,7 +54,7 @@ int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
 int zs3_conv_wgrad_plan(int M, int co, int ci, int taps, int* splitk_out, long* workspace_floats);
 int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int Ho, int Wo,
                    int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read, int co_write, int ci_read,
-                   int ci_write, int lddy, int ldx, int prec, void* stream);
+                   int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream);
 
 /* ---- BatchNorm / ReLU / residual (bn.hip) ---------------------------------------------------- */
 /* Replaces native_batch_norm fwd/bwd, relu_, threshold_backward, residual add_ at resnet.py:33-53,

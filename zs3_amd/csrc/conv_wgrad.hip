@@ -24,6 +24,7 @@ struct WgradArgs {
   const float* dy;
   const float* x;
   float* dw;
+  const float* zero;   // >= 256 B of zeros for masked loads
   int N, H, W, Ho, Wo;
   int KH, KW, stride, pad_h, pad_w, dil;
   int co_read, co_write, ci_read, ci_write;
@@ -62,36 +63,65 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
   f32x4 areg[PA][2], breg[PB][2];
 
-  auto load_tile = [&](int mbase) {
+  // Per-thread pixel slots.  A slot's pixel index advances by 32 every K step; (n, oh, ow) are carried
+  // incrementally (one division when the block starts, none in the loop) and masked loads read the zero page,
+  // so the loop body is branch-free apart from the wave-uniform trip count.
+  const float* aptr[PA][2];
+  int am[PA][2];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
+  for (int i = 0; i < PA; ++i)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        int m = mbase + 2 * (pra + SA * i) + e;
-        if (a_cok && m < m_end)
-          areg[i][e] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + co0 + cqa);
-        else
-          areg[i][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int e = 0; e < 2; ++e) {
+      am[i][e] = m_begin + 2 * (pra + SA * i) + e;
+      aptr[i][e] = p.dy + (size_t)am[i][e] * p.lddy + co0 + cqa;
     }
+  int bm[PB][2], bn[PB][2], boh[PB][2], bow[PB][2];
+  {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
+    for (int i = 0; i < PB; ++i)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        int m = mbase + 2 * (prb + SB * i) + e;
-        bool ok = b_cok && m < m_end;
-        int mm = ok ? m : 0;
+        int m = m_begin + 2 * (prb + SB * i) + e;
+        bm[i][e] = m;
+        int mm = m < p.M ? m : 0;
         int n = mm / hw, rem = mm - n * hw;
-        int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-        int hi = oh * p.stride - p.pad_h + kh * p.dil, wi = ow * p.stride - p.pad_w + kw * p.dil;
-        ok = ok && hi >= 0 && wi >= 0 && hi < p.H && wi < p.W;
-        if (ok)
-          breg[i][e] = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H + hi) * p.W + wi) * p.ldx + ci0 + cqb);
-        else
-          breg[i][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bn[i][e] = n;
+        boh[i][e] = rem / p.Wo;
+        bow[i][e] = rem - boh[i][e] * p.Wo;
       }
-    }
+  }
+  const int tap_h = kh * p.dil - p.pad_h, tap_w = kw * p.dil - p.pad_w;
+
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float* ptr = (a_cok && am[i][e] < m_end) ? aptr[i][e] : p.zero;
+        areg[i][e] = *reinterpret_cast<const f32x4*>(ptr);
+        am[i][e] += 32;
+        aptr[i][e] += (size_t)32 * p.lddy;
+      }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int hi = boh[i][e] * p.stride + tap_h, wi = bow[i][e] * p.stride + tap_w;
+        const bool ok = b_cok && bm[i][e] < m_end && ((hi | wi) >= 0) && hi < p.H && wi < p.W;
+        const float* ptr = ok ? p.x + ((((size_t)bn[i][e] * p.H + hi) * p.W + wi) * p.ldx + ci0 + cqb) : p.zero;
+        breg[i][e] = *reinterpret_cast<const f32x4*>(ptr);
+        // advance this slot by 32 pixels
+        bm[i][e] += 32;
+        bow[i][e] += 32;
+        while (bow[i][e] >= p.Wo) {
+          bow[i][e] -= p.Wo;
+          if (++boh[i][e] == p.Ho) {
+            boh[i][e] = 0;
+            ++bn[i][e];
+          }
+        }
+      }
   };
   auto store_tile = [&](int stage) {
     unsigned* As = smem + stage * STAGE;
@@ -171,13 +201,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
   const int KT = (m_end - m_begin + 31) / 32;
   if (KT > 0) {
-    load_tile(m_begin);
+    load_tile();
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
       const int cur = kt & 1;
       const bool more = kt + 1 < KT;
-      if (more) load_tile(m_begin + (kt + 1) * 32);
+      if (more) load_tile();
       compute(cur);
       if (more) store_tile(cur ^ 1);
       __syncthreads();
@@ -241,11 +271,12 @@ extern "C" int zs3_conv_wgrad_plan(int M, int co, int ci, int taps, int* splitk_
 
 extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int Ho,
                               int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read,
-                              int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec, void* stream) {
-  if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3)) return -1;
-  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return -2;
+                              int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
+                              const void* zero_page, void* stream) {
+  if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15)) return -2;
   WgradArgs a;
-  a.dy = dy; a.x = x;
+  a.dy = dy; a.x = x; a.zero = (const float*)zero_page;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil;
   a.co_read = co_read; a.co_write = co_write; a.ci_read = ci_read; a.ci_write = ci_write;

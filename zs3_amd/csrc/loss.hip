@@ -11,35 +11,74 @@ namespace {
 template <typename TT>
 __device__ __forceinline__ int load_target(const TT* t, long i) { return (int)(long)t[i]; }
 
-template <typename TT>
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, int ld, const TT* target, const float* weight,
-                                                    long P, int C, int ignore_index, double* partial) {
+// One block = 256 consecutive pixels.  Their logits ([256][C] floats, contiguous when ld == C) are staged through
+// LDS with fully coalesced loads / stores; thread t then owns pixel t (row stride C+1 => conflict-free).
+template <typename TT, bool BWD>
+__global__ __launch_bounds__(256) void ce_tile_kernel(const float* logits, int ld, const TT* target, const float* weight,
+                                                     long P, int C, int ignore_index, double* partial,
+                                                     const float* loss_ws, const float* gout, float inv_batch,
+                                                     float* dlogits, int ldo) {
+  extern __shared__ float tile[];  // [256][C+1]
+  const int CP = C + 1;
+  const float coef = BWD ? gout[0] * inv_batch / loss_ws[1] : 0.f;
   double lsum = 0.0, wsum = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long)gridDim.x * blockDim.x) {
-    const int t = load_target(target, i);
-    if (t == ignore_index || t < 0 || t >= C) continue;
-    const float* z = logits + i * ld;
-    float mx = z[0];
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
-    float se = 0.f;
-    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
-    const float nll = (mx + logf(se)) - z[t];
-    const float w = weight ? weight[t] : 1.f;
-    lsum += (double)(w * nll);
-    wsum += (double)w;
+  for (long p0 = (long)blockIdx.x * 256; p0 < P; p0 += (long)gridDim.x * 256) {
+    const int np = (int)min((long)256, P - p0);
+    const bool dense = (ld == C);
+    if (dense) {
+      const float* src = logits + p0 * C;
+      for (int e = threadIdx.x; e < np * C; e += 256) tile[(e / C) * CP + (e % C)] = src[e];
+    } else {
+      for (int e = threadIdx.x; e < np * C; e += 256) tile[(e / C) * CP + (e % C)] = logits[(p0 + e / C) * ld + (e % C)];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < np) {
+      float* z = tile + threadIdx.x * CP;
+      const int t = load_target(target, p0 + threadIdx.x);
+      const bool valid = !(t == ignore_index || t < 0 || t >= C);
+      if (valid) {
+        float mx = z[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+        const float w = weight ? weight[t] : 1.f;
+        if (BWD) {
+          const float inv = 1.f / se, wc = w * coef;
+          for (int c = 0; c < C; ++c) z[c] = wc * (expf(z[c] - mx) * inv - (c == t ? 1.f : 0.f));
+        } else {
+          const float nll = (mx + logf(se)) - z[t];
+          lsum += (double)(w * nll);
+          wsum += (double)w;
+        }
+      } else if (BWD) {
+        for (int c = 0; c < C; ++c) z[c] = 0.f;
+      }
+    }
+    if (BWD) {
+      __syncthreads();
+      if (ldo == C) {
+        float* dst = dlogits + p0 * C;
+        for (int e = threadIdx.x; e < np * C; e += 256) dst[e] = tile[(e / C) * CP + (e % C)];
+      } else {
+        for (int e = threadIdx.x; e < np * C; e += 256) dlogits[(p0 + e / C) * ldo + (e % C)] = tile[(e / C) * CP + (e % C)];
+      }
+    }
+    __syncthreads();
   }
-  __shared__ double red[2][4];
-  lsum = wave_sum_d(lsum);
-  wsum = wave_sum_d(wsum);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    red[0][wave] = lsum;
-    red[1][wave] = wsum;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    partial[2 * blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (!BWD) {
+    __shared__ double red[2][4];
+    lsum = wave_sum_d(lsum);
+    wsum = wave_sum_d(wsum);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      red[0][wave] = lsum;
+      red[1][wave] = wsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      partial[2 * blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+      partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
   }
 }
 
@@ -56,29 +95,6 @@ __global__ void ce_finalize_kernel(const double* partial, int nblk, float inv_ba
     out[0] = (float)(l / w) * inv_batch;
     out[1] = (float)w;
     out[2] = (float)l;
-  }
-}
-
-template <typename TT>
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int ld, const TT* target, const float* weight,
-                                                    long P, int C, int ignore_index, const float* loss_ws,
-                                                    const float* gout, float inv_batch, float* dlogits, int ldo) {
-  const float coef = gout[0] * inv_batch / loss_ws[1];
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (long)gridDim.x * blockDim.x) {
-    const int t = load_target(target, i);
-    float* d = dlogits + i * ldo;
-    if (t == ignore_index || t < 0 || t >= C) {
-      for (int c = 0; c < C; ++c) d[c] = 0.f;
-      continue;
-    }
-    const float* z = logits + i * ld;
-    float mx = z[0];
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
-    float se = 0.f;
-    for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
-    const float w = (weight ? weight[t] : 1.f) * coef;
-    const float inv = 1.f / se;
-    for (int c = 0; c < C; ++c) d[c] = w * (expf(z[c] - mx) * inv - (c == t ? 1.f : 0.f));
   }
 }
 
@@ -211,12 +227,14 @@ extern "C" int zs3_ce_fwd(const float* logits, int ld, const void* target, int t
                           long P, int C, int ignore_index, int batch, double* partial_ws, float* loss_ws, void* stream) {
   const int nblk = 1024;
   hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)256 * (C + 1) * sizeof(float);
+  if (lds > 64 * 1024) return -1;  // C <= 63 (ZS3: 21 and 60 classes)
   if (target_is_i64)
-    hipLaunchKernelGGL(ce_fwd_kernel<long>, dim3(nblk), dim3(256), 0, st, logits, ld, (const long*)target, weight, P, C,
-                       ignore_index, partial_ws);
+    hipLaunchKernelGGL((ce_tile_kernel<long, false>), dim3(nblk), dim3(256), lds, st, logits, ld, (const long*)target, weight,
+                       P, C, ignore_index, partial_ws, nullptr, nullptr, 0.f, nullptr, 0);
   else
-    hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(nblk), dim3(256), 0, st, logits, ld, (const float*)target, weight, P,
-                       C, ignore_index, partial_ws);
+    hipLaunchKernelGGL((ce_tile_kernel<float, false>), dim3(nblk), dim3(256), lds, st, logits, ld, (const float*)target,
+                       weight, P, C, ignore_index, partial_ws, nullptr, nullptr, 0.f, nullptr, 0);
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)partial_ws, nblk,
                      batch > 0 ? 1.f / (float)batch : 1.f, loss_ws);
   return ZS3_LAUNCH_CHECK();
@@ -227,16 +245,18 @@ extern "C" int zs3_ce_bwd(const float* logits, int ld, const void* target, int t
                           long P, int C, int ignore_index, int batch, const float* loss_ws, const float* gout,
                           float* dlogits, int ldo, void* stream) {
   long blocks = (P + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > 4096) blocks = 4096;
   if (blocks < 1) return 0;
   const float inv_batch = batch > 0 ? 1.f / (float)batch : 1.f;
   hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)256 * (C + 1) * sizeof(float);
+  if (lds > 64 * 1024) return -1;  // C <= 63 (ZS3: 21 and 60 classes)
   if (target_is_i64)
-    hipLaunchKernelGGL(ce_bwd_kernel<long>, dim3((int)blocks), dim3(256), 0, st, logits, ld, (const long*)target,
-                       weight, P, C, ignore_index, loss_ws, gout, inv_batch, dlogits, ldo);
+    hipLaunchKernelGGL((ce_tile_kernel<long, true>), dim3((int)blocks), dim3(256), lds, st, logits, ld, (const long*)target,
+                       weight, P, C, ignore_index, nullptr, loss_ws, gout, inv_batch, dlogits, ldo);
   else
-    hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3((int)blocks), dim3(256), 0, st, logits, ld, (const float*)target,
-                       weight, P, C, ignore_index, loss_ws, gout, inv_batch, dlogits, ldo);
+    hipLaunchKernelGGL((ce_tile_kernel<float, true>), dim3((int)blocks), dim3(256), lds, st, logits, ld, (const float*)target,
+                       weight, P, C, ignore_index, nullptr, loss_ws, gout, inv_batch, dlogits, ldo);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -167,7 +167,7 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
     work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
     check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
                                I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
-                               I(prec), stream()), "zs3_conv_wgrad")
+                               I(prec), P(zero_page(x.device)), stream()), "zs3_conv_wgrad")
     return dw
 
 
