@@ -17,10 +17,12 @@ PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event
 
 def pick_tile(m, ncols):
     """Block-tile choice for the implicit-GEMM kernel (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64)."""
-    # +10 selects the two-deep register prefetch variant (measured 2-3 % faster on every layer shape of the net)
-    if ncols > 64:
-        return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 160 else 13
-    return 12 if (m + 127) // 128 >= 160 else 14
+    # measured on MI355X over the 28 layer shapes of the network (tools/probe/conv_bench.py): the 128x128 tile wins when
+    # the launch has >= ~1000 of them (>= 2 resident per CU for several rounds), otherwise the 64x64 tile (4 blocks
+    # per CU, 16 waves) hides latency better.  +10 = two-deep register prefetch (2-3 % faster everywhere).
+    if ncols <= 64:
+        return 14
+    return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
 
 
 _zero_pages = {}
