@@ -61,8 +61,10 @@ int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace,
  * aspp.py:25-29,111-116, decoder.py:30-32,15-24.  Partial-sum buffers are [chunks][2][C] floats. */
 int zs3_colstats_plan(int M, int C, int* chunks, int* rows_per_block);
 int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, void* stream);
+/* ReLU mask: from a_out (> 0) when given, else recomputed as y*mask_scale + mask_shift > 0 (layers without residual) */
 int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
-                     const float* invstd, int M, int C, float* partial, void* stream);
+                     const float* invstd, const float* mask_scale, const float* mask_shift, int M, int C, float* partial,
+                     void* stream);
 int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const float* gamma, const float* beta,
                         float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
                         float* invstd_out, float* scale_out, float* shift_out, void* stream);
@@ -77,8 +79,9 @@ int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shi
                    void* stream);
 /* dz = act'(a_out)*dA; dres (=|+=) dz; dy = gamma*invstd*(dz - c1 - xhat*c2)  (c1==NULL: dy = gamma*invstd*dz) */
 int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
-                   const float* invstd, const float* gamma, const float* c1, const float* c2, float* dy, int ldo,
-                   float* dres, int ldr, int dres_accumulate, long M, int C, int act, float leak, void* stream);
+                   const float* invstd, const float* gamma, const float* c1, const float* c2, const float* mask_scale,
+                   const float* mask_shift, float* dy, int ldo, float* dres, int ldr, int dres_accumulate, long M, int C,
+                   int act, float leak, void* stream);
 /* out[g][c] = scale * sum_{r<R} x[g*R + r][c]: AdaptiveAvgPool2d((1,1)) of aspp.py:85 and its broadcast backward */
 int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo, void* stream);
 

@@ -25,6 +25,8 @@ struct ColArgs {
   const float* y;     // MODE1: conv output (pre-BN)
   const float* mean;  // MODE1
   const float* invstd;
+  const float* mscale;  // MODE1, optional: ReLU mask recomputed as y*mscale + mshift > 0 (no residual) instead of reading `a`
+  const float* mshift;
   float* partial;
   int M, C, ldx, lda, ldy, rows_per_block;
 };
@@ -45,9 +47,14 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (active) {
       f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
+      f32x4 msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
       if (MODE == 1) {
         mu = *reinterpret_cast<const f32x4*>(p.mean + cq * 4);
         is = *reinterpret_cast<const f32x4*>(p.invstd + cq * 4);
+        if (p.mscale) {
+          msc = *reinterpret_cast<const f32x4*>(p.mscale + cq * 4);
+          msh = *reinterpret_cast<const f32x4*>(p.mshift + cq * 4);
+        }
       }
       for (int r = row0 + ty; r < row1; r += ty_n) {
         f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)r * p.ldx + cq * 4);
@@ -55,12 +62,16 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
           s += v;
           q += v * v;
         } else {
+          f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + (size_t)r * p.ldy + cq * 4);
           if (p.a) {
             f32x4 av = *reinterpret_cast<const f32x4*>(p.a + (size_t)r * p.lda + cq * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = av[k] > 0.f ? v[k] : 0.f;
+          } else if (p.mscale) {
+            f32x4 av = yv * msc + msh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = av[k] > 0.f ? v[k] : 0.f;
           }
-          f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + (size_t)r * p.ldy + cq * 4);
           s += v;
           q += v * ((yv - mu) * is);
         }
@@ -205,6 +216,8 @@ struct BnBwdArgs {
   const float* gamma;
   const float* c1;
   const float* c2;
+  const float* mscale;
+  const float* mshift;
   float* dy;
   float* dres;
   long M;
@@ -218,10 +231,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
     const long m = i / c4n;
     const int cq = (int)(i - m * c4n) * 4;
     f32x4 dz = *reinterpret_cast<const f32x4*>(p.dA + m * p.ldd + cq);
+    f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+    if (p.y) yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
     if (p.a) {
       f32x4 av = *reinterpret_cast<const f32x4*>(p.a + m * p.lda + cq);
 #pragma unroll
       for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
+    } else if (p.mscale) {
+      f32x4 av = yv * *reinterpret_cast<const f32x4*>(p.mscale + cq) + *reinterpret_cast<const f32x4*>(p.mshift + cq);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
     }
     if (p.dres) {
       float* dr = p.dres + m * p.ldr + cq;
@@ -234,7 +253,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
       f32x4 g = p.gamma ? *reinterpret_cast<const f32x4*>(p.gamma + cq) : f32x4{1.f, 1.f, 1.f, 1.f};
       f32x4 out;
       if (p.c1) {
-        f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
         f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + cq);
         f32x4 xhat = (yv - mu) * is;
         out = g * is * (dz - *reinterpret_cast<const f32x4*>(p.c1 + cq) - xhat * *reinterpret_cast<const f32x4*>(p.c2 + cq));
@@ -285,7 +303,7 @@ extern "C" int zs3_colstats_plan(int M, int C, int* chunks, int* rows_per_block)
   int c4n = C / 4;
   int tx_n = c4n < 256 ? c4n : 256;
   int ty_n = 256 / (tx_n > 0 ? tx_n : 1);
-  int rpb = (M + 2047) / 2048;
+  int rpb = (M + 511) / 512;   // <= 512 partial rows: the [chunks][2][C] buffer stays small (it is re-read by the finalize kernels)
   int minr = ty_n * 4;
   if (rpb < minr) rpb = minr;
   *rows_per_block = rpb;
@@ -304,10 +322,12 @@ extern "C" int zs3_colstats(const float* x, int ldx, int M, int C, float* partia
 }
 
 extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
-                                const float* mean, const float* invstd, int M, int C, float* partial, void* stream) {
+                                const float* mean, const float* invstd, const float* mask_scale,
+                                const float* mask_shift, int M, int C, float* partial, void* stream) {
   if (C % 4 || ldd % 4 || ldy % 4 || (a_out && lda % 4)) return -1;
   ColArgs a{};
   a.x = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.partial = partial;
+  a.mscale = mask_scale; a.mshift = mask_shift;
   a.M = M; a.C = C; a.ldx = ldd; a.lda = lda; a.ldy = ldy;
   int chunks;
   zs3_colstats_plan(M, C, &chunks, &a.rows_per_block);
@@ -354,12 +374,14 @@ extern "C" int zs3_affine_act(const float* x, int ldx, const float* scale, const
 
 extern "C" int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
                               const float* mean, const float* invstd, const float* gamma, const float* c1,
-                              const float* c2, float* dy, int ldo, float* dres, int ldr, int dres_accumulate, long M,
-                              int C, int act, float leak, void* stream) {
+                              const float* c2, const float* mask_scale, const float* mask_shift, float* dy, int ldo,
+                              float* dres, int ldr, int dres_accumulate, long M, int C, int act, float leak,
+                              void* stream) {
   if (C % 4 || ldd % 4 || (dy && ldo % 4) || (a_out && lda % 4) || (dres && ldr % 4)) return -1;
   if (M <= 0) return 0;
   BnBwdArgs a;
   a.dA = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.c1 = c1; a.c2 = c2;
+  a.mscale = mask_scale; a.mshift = mask_shift;
   a.dy = dy; a.dres = dres; a.M = M; a.C = C; a.ldd = ldd; a.lda = lda; a.ldy = ldy; a.ldo = ldo; a.ldr = ldr;
   a.dres_accumulate = dres_accumulate; a.act = act; a.leak = leak;
   hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);

@@ -249,12 +249,12 @@ int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, hipStream_t
 
 int pick_splitk(int M, int tiles) {
   int chunks = (M + 31) / 32;
-  int want = (1024 + tiles - 1) / tiles;  // aim at >= ~1024 workgroups
+  int want = (768 + tiles - 1) / tiles;   // aim at >= ~768 workgroups (3 per CU); every split costs a [Cout][K] slab of traffic
   if (want < 1) want = 1;
-  int maxs = chunks / 8;                  // at least 8 K-steps (256 pixels) per split
+  int maxs = chunks / 16;                 // at least 16 K-steps (512 pixels) per split
   if (maxs < 1) maxs = 1;
   int s = want < maxs ? want : maxs;
-  if (s > 64) s = 64;
+  if (s > 32) s = 32;
   return s;
 }
 

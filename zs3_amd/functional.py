@@ -128,13 +128,20 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.x_shape = tuple(x.shape)
-        ctx.save_for_backward(x, weight, gamma, y, a if act != ACT_NONE else None, st)
+        # ReLU mask in backward: recomputed from y (y*scale + shift > 0) when there is no residual, so `a` is not re-read
+        ctx.mask_from_y = bool(bn is not None and y is not None and act == ACT_RELU and residual is None)
+        keep_a = act != ACT_NONE and not ctx.mask_from_y
+        ctx.save_for_backward(x, weight, gamma, y, a if keep_a else None, st)
+        ctx.pass_through = bool(cfg.get("pass_through"))
+        if ctx.pass_through:
+            return a, x.view(x.shape)   # the block input again, as the skip connection: its gradient comes back to us
         return a
 
     @staticmethod
-    def backward(ctx, dA):
+    def backward(ctx, dA, dskip=None):
         x, weight, gamma, y, a, st = ctx.saved_tensors
         cfg = ctx.cfg
+        msc, msh = (st[2], st[3]) if ctx.mask_from_y else (None, None)
         stride, pad, dil, act = cfg["stride"], cfg["pad"], cfg["dil"], cfg["act"]
         leak, prec, geom = cfg.get("leak", 0.2), cfg.get("prec"), cfg.get("geom")
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -145,7 +152,7 @@ class _ConvBnAct(torch.autograd.Function):
             dres = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
         m = dA.shape[0] * dA.shape[1] * dA.shape[2] if dA.dim() == 4 else dA.shape[0]
         if ctx.has_bn:
-            part = ops.bn_bwd_stats(dA, a, y, st[0], st[1])
+            part = ops.bn_bwd_stats(dA, a, y, st[0], st[1], msc, msh)
             sync = (cfg.get("bn") or {}).get("sync") if ctx.bn_training else None
             if sync is not None:
                 from .parallel import combine_bn_partials
@@ -157,7 +164,8 @@ class _ConvBnAct(torch.autograd.Function):
                 fin = ops.bn_bwd_finalize(part, m, ctx.bn_training)
                 dgamma, dbeta = fin[0], fin[1]
                 c1, c2 = (fin[2], fin[3]) if ctx.bn_training else (None, None)
-            dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, dres=dres, act=act, leak=leak)
+            dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, dres=dres, act=act, leak=leak, mask_scale=msc,
+                                mask_shift=msh)
         else:
             cout = dA.shape[-1]
             vec_ok = cout % 4 == 0 and ops._rows(dA)[2] % 4 == 0
@@ -177,13 +185,21 @@ class _ConvBnAct(torch.autograd.Function):
         dx = dw = None
         if need_x:
             if geom is None:
-                dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec)
+                fuse = (dskip is not None and tuple(dskip.shape) == ctx.x_shape and dskip.is_contiguous()
+                        and dskip.shape[-1] == wp.cin)
+                # identity blocks: the skip gradient is accumulated by the dgrad epilogue instead of a separate add kernel
+                dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec,
+                                      out=dskip if fuse else None, accumulate=fuse)
+                if dskip is not None and not fuse:
+                    dx = dx + dskip
                 if dx.shape[-1] != ctx.x_shape[-1]:  # x carried pad channels
                     full = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dx.device)
                     full[..., : dx.shape[-1]].copy_(dx)
                     dx = full
             else:
                 raise RuntimeError("the stem convolution has no data gradient (its input is the image)")
+        elif dskip is not None and ctx.needs_input_grad[0]:
+            dx = dskip
         if need_w:
             if geom is None:
                 dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec)
@@ -202,10 +218,10 @@ def _act_grad(a, act, leak):
 
 
 def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
-                leak=0.2, prec=None, geom=None, wgrad=None):
+                leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False):
     """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None."""
     cfg = {"stride": stride, "pad": pad, "dil": dil, "act": act, "out": out, "leak": leak, "prec": prec, "geom": geom,
-           "wgrad": wgrad,
+           "wgrad": wgrad, "pass_through": pass_through,
            "need_grad": torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
                                                         (x, weight, bias, residual, getattr(bn, "weight", None)))}
     gamma = beta = None

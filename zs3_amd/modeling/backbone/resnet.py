@@ -32,9 +32,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward_nhwc(self, x):
-        y = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU)
+        if self.downsample is None:
+            # identity block: conv1's node also hands the input through as the skip tensor, so that the skip gradient
+            # comes back to it and is accumulated inside its dgrad epilogue (no separate add kernel in backward)
+            y, skip = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU, pass_through=True)
+        else:
+            y = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU)
+            skip = self.downsample[0].forward_nhwc(x, self.downsample[1])
         y = self.conv2.forward_nhwc(y, self.bn2, act=Fz.ACT_RELU)
-        skip = x if self.downsample is None else self.downsample[0].forward_nhwc(x, self.downsample[1])
         return self.conv3.forward_nhwc(y, self.bn3, residual=skip, act=Fz.ACT_RELU)  # bn3 + add + relu in one pass
 
     def forward(self, x):

@@ -225,15 +225,15 @@ def affine_act(x, scale=None, shift=None, alpha=1.0, res=None, out=None, div=1, 
     return out
 
 
-def bn_bwd_stats(dA, a_out, y, mean, invstd):
+def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None):
     m, c, ldd = _rows(dA)
     lda = _rows(a_out)[2] if a_out is not None else 0
     ldy = _rows(y)[2]
     chunks, rpb = ctypes.c_int(0), ctypes.c_int(0)
     lib().zs3_colstats_plan(I(m), I(c), ctypes.byref(chunks), ctypes.byref(rpb))
     part = torch.empty((chunks.value, 2, c), dtype=torch.float32, device=dA.device)
-    check(lib().zs3_bn_bwd_stats(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), I(m), I(c), P(part),
-                                 stream()), "zs3_bn_bwd_stats")
+    check(lib().zs3_bn_bwd_stats(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), P(mask_scale), P(mask_shift),
+                                 I(m), I(c), P(part), stream()), "zs3_bn_bwd_stats")
     return part
 
 
@@ -246,7 +246,7 @@ def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True):
 
 
 def bn_act_bwd(dA, a_out, y, mean, invstd, gamma, c1, c2, dy=None, dres=None, dres_accumulate=False, act=1, leak=0.2,
-               want_dy=True):
+               want_dy=True, mask_scale=None, mask_shift=None):
     require_gpu(dA, a_out, y, dy, dres)
     m, c, ldd = _rows(dA)
     if want_dy and dy is None:
@@ -256,7 +256,7 @@ def bn_act_bwd(dA, a_out, y, mean, invstd, gamma, c1, c2, dy=None, dres=None, dr
     ldo = _rows(dy)[2] if dy is not None else 0
     ldr = _rows(dres)[2] if dres is not None else 0
     check(lib().zs3_bn_act_bwd(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), P(gamma), P(c1), P(c2),
-                               P(dy), I(ldo), P(dres), I(ldr), I(int(dres_accumulate)), ctypes.c_long(m), I(c), I(act),
+                               P(mask_scale), P(mask_shift), P(dy), I(ldo), P(dres), I(ldr), I(int(dres_accumulate)), ctypes.c_long(m), I(c), I(act),
                                F(leak), stream()), "zs3_bn_act_bwd")
     return dy
 
