@@ -15,13 +15,15 @@ PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs
 PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event) per conv launch
 
 
-def pick_tile(m, ncols):
+def pick_tile(m, ncols, k=0):
     """Block-tile choice for the implicit-GEMM kernel (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64)."""
     # measured on MI355X over the 28 layer shapes of the network (tools/probe/conv_bench.py): the 128x128 tile wins when
     # the launch has >= ~1000 of them (>= 2 resident per CU for several rounds), otherwise the 64x64 tile (4 blocks
     # per CU, 16 waves) hides latency better.  +10 = two-deep register prefetch (2-3 % faster everywhere).
     if ncols <= 64:
         return 14
+    if k >= 1152 and m >= 8192:
+        return 21   # wave-specialised 256x128 tile: wins on the K-heavy layers (3x3 and 2048-channel convs)
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
 
 
@@ -115,7 +117,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     ldr = _check_nhwc(res) if res is not None else 0
     m = n * ho * wo
     if tile_cfg == 0:
-        tile_cfg = pick_tile(m, ncols)
+        tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
     stat = None
     if want_stats:
         mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
@@ -129,7 +131,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
                                I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), stream()), "zs3_conv_igemm")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
+        PROFILE.append(("conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1))
     return out, stat
 
