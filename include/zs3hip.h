@@ -118,9 +118,12 @@ int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr, int N, in
 /* nn.Dropout (aspp.py:100, decoder.py:19,23, gmmn.py:20): y = keep ? x/(1-p) : 0 with a counter-based mask
  * that is a pure function of (seed, element index); the backward is the same call on dy.  row_idx (optional,
  * int64[M]): row m of x is row row_idx[m] of the tensor the mask was drawn for (sampled-row backward). */
+/* seed_dev (optional): device uint64 added to `seed`, so a launch captured in a hipGraph draws a fresh mask per replay */
 int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
-                const long* row_idx, void* stream);
-int zs3_uniform(float* out, long n, unsigned long long seed, void* stream);
+                const long* row_idx, const void* seed_dev, void* stream);
+int zs3_uniform(float* out, long n, unsigned long long seed, const void* seed_dev, void* stream);
+/* counter[0] += v (device int64 / uint64): advances the stream position / step count between graph replays */
+int zs3_counter_add(void* counter, long v, void* stream);
 /* F.interpolate(mode="nearest") of one [C][H][W] image into pixel rows [ho*wo][ldo] (train_pascal_GMMN.py:175-195) */
 int zs3_nearest_rows(const float* src, int C, int H, int W, int ho, int wo, float* rows, int ldo, void* stream);
 /* out[r] = [a[idx[r]][0:Ca] | b[r][0:Cb] | 0...]: torch.cat((embd, noise), 1) of gmmn.py:44 fused with the class mask */
@@ -132,8 +135,9 @@ int zs3_index_add_rows(const float* src, int lds, const long* idx, float* out, i
 /* torch.optim.SGD (train_pascal.py:55-60) and torch.optim.Adam (train_pascal_GMMN.py:65-67) update rules */
 int zs3_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, int nesterov,
                  int first, void* stream);
+/* step_dev (optional): device int64 holding the number of steps taken so far; overrides `step` (= step_dev[0] + 1) */
 int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                  float wd, int step, void* stream);
+                  float wd, int step, const void* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

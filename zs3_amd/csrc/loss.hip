@@ -128,13 +128,36 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const MmdArgs p) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   float na = 0.f, nb = 0.f;
+  if ((half & 31) == 0 && ((p.ldg | p.ldr) & 3) == 0) {
+    // each lane streams its own row in 128-byte pieces (8 x float4 for A and B), then feeds 32 MFMAs from registers
+    const float* qa = pa + h * half;
+    const float* qb = pb + h * half;
+    for (int c = 0; c < half; c += 32) {
+      f32x4 av[8], bv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        av[t] = va ? *reinterpret_cast<const f32x4*>(qa + c + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[t] = vb ? *reinterpret_cast<const f32x4*>(qb + c + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = av[t][e], b = bv[t][e];
+          na = fmaf(a, a, na);
+          nb = fmaf(b, b, nb);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+  } else {
 #pragma unroll 8
-  for (int s = 0; s < half; ++s) {
-    const float a = va ? pa[h * half + s] : 0.f;
-    const float b = vb ? pb[h * half + s] : 0.f;
-    na = fmaf(a, a, na);
-    nb = fmaf(b, b, nb);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int s = 0; s < half; ++s) {
+      const float a = va ? pa[h * half + s] : 0.f;
+      const float b = vb ? pb[h * half + s] : 0.f;
+      na = fmaf(a, a, na);
+      nb = fmaf(b, b, nb);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
   }
   na += __shfl_xor(na, 32, 64);
   nb += __shfl_xor(nb, 32, 64);
@@ -201,13 +224,31 @@ __global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const floa
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   float rsum = 0.f;
   const int half = twoN / 2;  // = N
+  if ((half & 31) == 0) {
+    for (int c = 0; c < half; c += 32) {
+      f32x4 av[8];
+      float bv[32];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        av[t] = vk ? *reinterpret_cast<const f32x4*>(grow + h * half + c + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 32; ++t) bv[t] = vd ? mmd_row(p, h * half + c + t)[d] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        const float a = av[t >> 2][t & 3];
+        rsum += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[t], acc, 0, 0, 0);
+      }
+    }
+  } else {
 #pragma unroll 8
-  for (int s = 0; s < half; ++s) {
-    const int j = h * half + s;
-    const float a = vk ? grow[j] : 0.f;
-    const float b = vd ? mmd_row(p, j)[d] : 0.f;
-    rsum += a;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int s = 0; s < half; ++s) {
+      const int j = h * half + s;
+      const float a = vk ? grow[j] : 0.f;
+      const float b = vd ? mmd_row(p, j)[d] : 0.f;
+      rsum += a;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
   }
   rsum += __shfl_xor(rsum, 32, 64);
   if (h == 0) rs[r] = rsum;

@@ -24,7 +24,8 @@ inline int ew_blocks(long total) {
 
 // y[m][c] = keep(seed, m*C + c) ? x[m][c] / (1-p) : 0      (same kernel serves backward with x = dy)
 __global__ void dropout_kernel(const float* x, int ldx, float* y, int ldy, long M, int C, float p, float inv_keep,
-                               unsigned long long seed, const long* row_idx) {
+                               unsigned long long seed, const long* row_idx, const unsigned long long* seed_dev) {
+  if (seed_dev) seed += seed_dev[0];   // device-resident stream position (captured launches replay with fresh masks)
   const long total = M * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / C;
@@ -35,7 +36,8 @@ __global__ void dropout_kernel(const float* x, int ldx, float* y, int ldy, long 
   }
 }
 
-__global__ void uniform_kernel(float* out, long n, unsigned long long seed) {
+__global__ void uniform_kernel(float* out, long n, unsigned long long seed, const unsigned long long* seed_dev) {
+  if (seed_dev) seed += seed_dev[0];
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     out[i] = u01(seed, (unsigned long long)i);
 }
@@ -104,7 +106,12 @@ __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float l
 // torch.optim.Adam (no amsgrad, eps outside sqrt/bias-correction as in torch): step_size = lr / bc1,
 // denom = sqrt(v)/sqrt(bc2) + eps
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                            float wd, float bc1, float bc2_sqrt) {
+                            float wd, float bc1, float bc2_sqrt, const long* step_dev) {
+  if (step_dev) {  // step count lives on the device (CUDA-graph replays): bias corrections for step_dev[0] + 1
+    const double t = (double)(step_dev[0] + 1);
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] + wd * p[i];
     float mi = m[i] + (1.f - b1) * (gi - m[i]);        // lerp form used by torch
@@ -119,16 +126,17 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
 }  // namespace
 
 extern "C" int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
-                           const long* row_idx, void* stream) {
+                           const long* row_idx, const void* seed_dev, void* stream) {
   if (M <= 0) return 0;
   hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, p,
-                     1.f / (1.f - p), seed, row_idx);
+                     1.f / (1.f - p), seed, row_idx, (const unsigned long long*)seed_dev);
   return ZS3_LAUNCH_CHECK();
 }
 
-extern "C" int zs3_uniform(float* out, long n, unsigned long long seed, void* stream) {
+extern "C" int zs3_uniform(float* out, long n, unsigned long long seed, const void* seed_dev, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(uniform_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed);
+  hipLaunchKernelGGL(uniform_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed,
+                     (const unsigned long long*)seed_dev);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -181,10 +189,18 @@ extern "C" int zs3_sgd_step(float* p, const float* g, float* buf, long n, float 
 }
 
 extern "C" int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                             float eps, float wd, int step, void* stream) {
+                             float eps, float wd, int step, const void* step_dev, void* stream) {
   if (n <= 0) return 0;
   const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps,
-                     wd, (float)bc1, (float)sqrt(bc2));
+                     wd, (float)bc1, (float)sqrt(bc2), (const long*)step_dev);
+  return ZS3_LAUNCH_CHECK();
+}
+
+__global__ void counter_add_kernel(long* c, long v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += v;
+}
+extern "C" int zs3_counter_add(void* counter, long v, void* stream) {
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long*)counter, v);
   return ZS3_LAUNCH_CHECK();
 }

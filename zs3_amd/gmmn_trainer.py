@@ -2,41 +2,44 @@
 (train_context_GMMN.py is identical).
 
 Semantics kept from the reference: frozen-backbone feature pass in train() mode under no_grad; per image,
-per class (ascending label order) one generator forward over *all* pixels of the class; an MMD + Adam step
-for seen classes of images without unseen pixels, on `batch_size_generator` rows sampled with replacement
-(the same indices for fake and real rows); generated features written back for every class; real features
-kept for images without unseen pixels (`real_seen_features`); one CE/SGD step of `pred_conv` on the stitched
-feature batch; generator_loss_batch divides by len(unique labels) including 255.
+per class (ascending label order) a generator call; an MMD + Adam step for seen classes of images without
+unseen pixels, on `batch_size_generator` rows sampled with replacement (the same indices for fake and real
+rows); generated features written back for images that contain an unseen class, real features kept otherwise
+(`real_seen_features`); one CE/SGD step of `pred_conv` on the stitched feature batch; generator_loss_batch
+divides by len(unique labels) including 255.
 
-What is MI355X-native here: the class masks are resolved with one device sort per image instead of
-boolean indexing (no per-class host sync), cat(embd, noise) is fused with the class gather, the MLP runs
-on the MFMA conv kernel, the generator backward touches only the sampled rows (rows of an MLP are
-independent, so this equals scatter-add + full backward), MMD fwd/bwd are two launches, and the scalar
-losses are read back once per step instead of `.item()` per (image, class).
+What is MI355X-native here:
+* class masks come from one stable device sort per batch instead of boolean indexing (no per-class host sync);
+* for images whose generated features are discarded anyway (no unseen pixel => real features are used) the
+  generator only runs on the *sampled* rows -- rows of an MLP are independent, so the Adam update is the one
+  the reference computes -- which makes the whole per-(image, class) update fixed-shape;
+* that fixed-shape update (gather + cat, two MFMA row-GEMMs, MMD fwd/bwd, MLP backward, fused Adam, weight
+  re-split) is captured ONCE into a hipGraph and replayed per (image, class): ~30 launches become one replay;
+  dropout / noise seeds and the Adam step count live in device memory so that replays differ;
+* the scalar losses are read back once per step instead of `.item()` per (image, class).
 
 noise="cpu" draws z and the sample indices from the CPU default generator exactly like the reference
 (:216,:229) -- bit-parity mode for tests; noise="device" draws z with the counter-based device RNG.
 """
+import ctypes
+
 import torch
 
 from . import functional as Fz
 from . import ops
-from ._lib import I, P, check, lib, require_gpu, stream
-from .utils.loss import _MMD  # noqa: F401  (kept importable for users)
-import ctypes
+from ._lib import F, I, P, check, lib, require_gpu, stream
 
 
-def _linear_rows(x, w, b, act=Fz.ACT_NONE, leak=0.2):
-    wp = Fz.weight_planes(w, need_t=True)
+def _rows_gemm(x, wp, b, act=Fz.ACT_NONE, leak=0.2):
     n, c = x.shape
     y, _ = ops.conv2d_fwd(x.view(1, 1, n, c), wp, shift=b, act=act, leak=leak)
-    return y.view(n, wp.cout), wp
+    return y.view(n, wp.cout)
 
 
 class GMMNStep:
     def __init__(self, model, generator, optimizer, optimizer_generator, criterion, *, seen, unseen, noise_dim=300,
                  embed_dim=300, feature_dim=256, batch_size_generator=128, real_seen_features=True,
-                 sigma=(2, 5, 10, 20, 40, 80), noise="device"):
+                 sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True):
         self.model = model.module if hasattr(model, "module") else model
         self.generator = generator
         self.optimizer, self.optimizer_generator = optimizer, optimizer_generator
@@ -48,24 +51,143 @@ class GMMNStep:
         self.noise = noise
         if not isinstance(generator.model, torch.nn.Sequential):
             raise NotImplementedError("GMMNStep needs the hidden-layer generator (hidden_size > 0)")
+        from .optim import Adam
+        self.fused_adam = isinstance(optimizer_generator, Adam)
+        self.use_graph = use_graph and self.fused_adam
+        self._st = None       # static buffers (allocated at first call)
+        self._graph = None
+        self._sig = (ctypes.c_float * len(self.sigma))(*self.sigma)
 
-    # ------------------------------------------------------------------ generator pieces
+    # ------------------------------------------------------------------ helpers
+    def _layers(self):
+        m = self.generator.model
+        return m[0], m[1], m[2], m[3]
+
+    def _resplit(self):
+        """bf16 hi/lo operands of the two Linear layers, rewritten in place (static addresses for the graph)."""
+        lin1, _, _, lin2 = self._layers()
+        st = self._st
+        for lin, wp in ((lin1, st["wp1"]), (lin2, st["wp2"])):
+            check(lib().zs3_prep_weight(P(lin.weight), P(wp.f_pk), P(wp.t_pk), I(wp.cout), I(1), I(wp.cin), I(wp.cin_pad),
+                                        I(wp.cout_pad), stream()), "zs3_prep_weight")
+
+    def _alloc(self, dev, b, npix):
+        lin1, _, _, lin2 = self._layers()
+        s, d, e, nz = self.bsg, self.feature_dim, self.embed_dim, self.noise_dim
+        i64 = dict(dtype=torch.int64, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = {
+            "emb": torch.zeros((npix, e), **f32), "real": torch.zeros((b * npix, d), **f32),
+            "pix_local": torch.zeros(s, **i64), "pix_global": torch.zeros(s, **i64), "ridx": torch.zeros(s, **i64),
+            "z": torch.zeros((s, nz), **f32), "loss": torch.zeros(1, **f32), "one": torch.ones(1, **f32),
+            "seed_dev": torch.zeros(1, **i64), "step_dev": torch.zeros(1, **i64),
+            "wp1": ops.prep_weight(lin1.weight, need_t=True), "wp2": ops.prep_weight(lin2.weight, need_t=True),
+            "ring": torch.zeros((512, s), dtype=torch.int64).pin_memory(), "ring_pos": 0,
+            "seed_base": Fz.next_seed(), "shape": (b, npix),
+        }
+        self._st = st
+        if self.fused_adam:
+            opt = self.optimizer_generator
+            opt._step_dev = None
+            for group in opt.param_groups:
+                for p in group["params"]:
+                    state = opt.state[p]
+                    if len(state) == 0:
+                        state["step"] = torch.tensor(0.0)
+                        state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            any_p = opt.param_groups[0]["params"][0]
+            st["step_dev"].fill_(int(opt.state[any_p]["step"]))
+
+    # ------------------------------------------------------------------ the fixed-shape sampled-row update
+    def _sampled_update(self, training):
+        """gather -> generator -> MMD -> generator backward -> Adam -> weight re-split, all on S = bsg rows that sit
+        in static buffers.  Captured into a hipGraph; every launch is on the current (capture) stream."""
+        st = self._st
+        lin1, lrelu, drop, lin2 = self._layers()
+        s, d = self.bsg, self.feature_dim
+        if self.noise != "cpu":
+            ops.uniform(None, st["seed_base"], None, out=st["z"], seed_dev=st["seed_dev"])
+        x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, self.embed_dim + self.noise_dim)
+        h = _rows_gemm(x, st["wp1"], lin1.bias, Fz.ACT_LEAKY, lrelu.negative_slope)
+        use_drop = training and drop.p > 0
+        hd = ops.dropout(h, drop.p, st["seed_base"] ^ 0x5DEECE66D, row_idx=st["ridx"], seed_dev=st["seed_dev"]) if use_drop else h
+        gen_s = _rows_gemm(hd, st["wp2"], lin2.bias)
+        real_s = ops.gather_rows(st["real"], st["pix_global"])
+        t = (2 * s + 31) // 32
+        gmat = torch.empty((2 * s, 2 * s), dtype=torch.float32, device=x.device)
+        tile = torch.empty(2 * t * t, dtype=torch.float64, device=x.device)
+        check(lib().zs3_mmd_fwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), self._sig, I(len(self.sigma)), P(gmat), P(tile),
+                                P(st["loss"]), stream()), "zs3_mmd_fwd")
+        dgen = torch.empty_like(gen_s)
+        check(lib().zs3_mmd_bwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(st["loss"]), P(st["one"]), P(dgen), I(d),
+                                stream()), "zs3_mmd_bwd")
+        # generator backward on the sampled rows
+        wp1, wp2 = st["wp1"], st["wp2"]
+        dw2 = ops.conv2d_wgrad(dgen.view(1, 1, s, -1), hd.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1)
+        db2 = ops.colstats(dgen)[:, 0].sum(0)
+        dhd = ops.conv2d_dgrad(dgen.view(1, 1, s, -1), wp2, (1, s)).view(s, -1)
+        if use_drop:
+            dhd = ops.dropout(dhd, drop.p, st["seed_base"] ^ 0x5DEECE66D, row_idx=st["ridx"], seed_dev=st["seed_dev"])
+        dpre = torch.empty_like(dhd)
+        ops.bn_act_bwd(dhd, h, None, None, None, None, None, None, dres=dpre, act=Fz.ACT_LEAKY, leak=lrelu.negative_slope,
+                       want_dy=False)
+        dw1 = ops.conv2d_wgrad(dpre.view(1, 1, s, -1), x.view(1, 1, s, -1), wp1.cout, wp1.cin, 1, 1)
+        db1 = ops.colstats(dpre)[:, 0].sum(0)
+        grads = {lin1.weight: dw1.view(lin1.weight.shape), lin1.bias: db1, lin2.weight: dw2.view(lin2.weight.shape),
+                 lin2.bias: db2}
+        opt = self.optimizer_generator
+        for group in opt.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                g = grads.get(p)
+                if g is None:
+                    continue
+                state = opt.state[p]
+                check(lib().zs3_adam_step(P(p), P(g.contiguous()), P(state["exp_avg"]), P(state["exp_avg_sq"]),
+                                          ctypes.c_long(p.numel()), F(group["lr"]), F(b1), F(b2), F(group["eps"]),
+                                          F(group["weight_decay"]), I(0), P(st["step_dev"]), stream()), "zs3_adam_step")
+        ops.counter_add(st["step_dev"], 1)
+        ops.counter_add(st["seed_dev"], 1 << 24)
+        self._resplit()
+
+    def _run_sampled_update(self, training):
+        if not self.use_graph:
+            self._sampled_update(training)
+        else:
+            key = (training, self.noise)
+            if self._graph is None or self._graph[0] != key:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    self._sampled_update(training)
+                self._graph = (key, g)
+            self._graph[1].replay()
+        # host-side mirror of the step count (state_dict compatibility with torch.optim.Adam)
+        opt = self.optimizer_generator
+        for group in opt.param_groups:
+            for p in group["params"]:
+                if p in opt.state and "step" in opt.state[p]:
+                    opt.state[p]["step"] += 1
+        Fz.invalidate_planes(*[p for g_ in opt.param_groups for p in g_["params"]])
+
+    # ------------------------------------------------------------------ eager generator pieces (fallback + unseen images)
     def _generator_forward(self, x, training):
-        lin1, lrelu, drop, lin2 = self.generator.model[0], self.generator.model[1], self.generator.model[2], self.generator.model[3]
-        h, _ = _linear_rows(x, lin1.weight, lin1.bias, Fz.ACT_LEAKY, lrelu.negative_slope)
-        seed = None
-        hd = h
+        lin1, lrelu, drop, lin2 = self._layers()
+        st = self._st
+        h = _rows_gemm(x, st["wp1"], lin1.bias, Fz.ACT_LEAKY, lrelu.negative_slope)
+        seed, hd = None, h
         if training and drop.p > 0:
             seed = Fz.next_seed()
             hd = ops.dropout(h, drop.p, seed)
-        out, _ = _linear_rows(hd, lin2.weight, lin2.bias)
-        return out, h, hd, seed
+        return _rows_gemm(hd, st["wp2"], lin2.bias), h, hd, seed
 
-    def _generator_backward_rows(self, x, h, hd, seed, ridx, d_out):
-        """Gradients of the two Linear layers from the sampled rows only (d_out: [S, feature_dim] for rows ridx)."""
-        lin1, lrelu, drop, lin2 = self.generator.model[0], self.generator.model[1], self.generator.model[2], self.generator.model[3]
+    def _eager_update_rows(self, x, h, hd, seed, ridx, d_out):
+        """Reference-order fallback (torch.optim.Adam supplied by the caller): gradients from the sampled rows."""
+        lin1, lrelu, drop, lin2 = self._layers()
+        st = self._st
         s = ridx.shape[0]
-        wp2 = Fz.weight_planes(lin2.weight, need_t=True)
+        wp1, wp2 = st["wp1"], st["wp2"]
         hd_s = ops.gather_rows(hd, ridx)
         dw2 = ops.conv2d_wgrad(d_out.view(1, 1, s, -1), hd_s.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1)
         db2 = ops.colstats(d_out)[:, 0].sum(0)
@@ -74,16 +196,15 @@ class GMMNStep:
             dhd = ops.dropout(dhd, drop.p, seed, row_idx=ridx)
         h_s = ops.gather_rows(h, ridx)
         dpre = torch.empty_like(dhd)
-        ops.bn_act_bwd(dhd, h_s, None, None, None, None, None, None, dres=dpre, act=Fz.ACT_LEAKY,
-                       leak=lrelu.negative_slope, want_dy=False)
+        ops.bn_act_bwd(dhd, h_s, None, None, None, None, None, None, dres=dpre, act=Fz.ACT_LEAKY, leak=lrelu.negative_slope,
+                       want_dy=False)
         x_s = ops.gather_rows(x, ridx)
-        wp1 = Fz.weight_planes(lin1.weight, need_t=True)
         dw1 = ops.conv2d_wgrad(dpre.view(1, 1, s, -1), x_s.view(1, 1, s, -1), wp1.cout, wp1.cin, 1, 1)
         db1 = ops.colstats(dpre)[:, 0].sum(0)
-        lin1.weight.grad = dw1.view(lin1.weight.shape)
-        lin1.bias.grad = db1
-        lin2.weight.grad = dw2.view(lin2.weight.shape)
-        lin2.bias.grad = db2
+        lin1.weight.grad, lin1.bias.grad = dw1.view(lin1.weight.shape), db1
+        lin2.weight.grad, lin2.bias.grad = dw2.view(lin2.weight.shape), db2
+        self.optimizer_generator.step()
+        self._resplit()
 
     # ------------------------------------------------------------------ one iteration
     def __call__(self, image, target, embedding):
@@ -94,27 +215,31 @@ class GMMNStep:
             real = ops.nhwc(model.forward_before_class_prediction(image))          # [B, fh, fw, D]
         fh, fw, d = real.shape[1], real.shape[2], real.shape[3]
         npix = fh * fw
+        if self._st is None or self._st["shape"] != (b, npix):
+            self._alloc(dev, b, npix)
+            self._graph = None
+        st = self._st
+        self._resplit()   # the generator may have been changed from outside (load_state_dict, another optimizer)
         real_rows = real.reshape(b, npix, d)
+        st["real"].copy_(real_rows.reshape(b * npix, d))
         fake = torch.empty((b, fh, fw, d), dtype=torch.float32, device=dev)
         fake_rows = fake.view(b, npix, d)
         # labels at feature resolution (nearest), per-image class histogram: one host sync per step
-        tgt = ops.nearest_rows(target.contiguous().float(), (fh, fw)).t().contiguous()       # [B, npix]
-        tgt_l = tgt.long()
+        tgt_l = ops.nearest_rows(target.contiguous().float(), (fh, fw)).t().contiguous().long()      # [B, npix]
         hist = torch.zeros((b, 256), dtype=torch.int64, device=dev).scatter_add_(1, tgt_l, torch.ones_like(tgt_l))
-        order = torch.argsort(tgt_l, dim=1, stable=True)                                      # pixels grouped by class
+        order = torch.argsort(tgt_l, dim=1, stable=True)                                          # pixels grouped by class
         hist_h = hist.cpu().tolist()
         training = self.generator.training
         n_mmd = int(sum(1 for i in range(b) for c in range(255) if hist_h[i][c] > 0))
         mmd_losses = torch.zeros(max(n_mmd, 1), dtype=torch.float32, device=dev)
-        mmd_slots = []  # (slot, image, n_unique)
-        slot = 0
-        one = torch.ones(1, dtype=torch.float32, device=dev)
-        sig = (ctypes.c_float * len(self.sigma))(*self.sigma)
+        mmd_slots, slot = [], 0
         for i in range(b):
             classes = [c for c in range(256) if hist_h[i][c] > 0]
             has_unseen = any(c in self.unseen for c in classes)
-            emb_rows = ops.nearest_rows(embedding[i].contiguous(), (fh, fw))                 # [npix, embed_dim]
             use_real = self.real_seen_features and not has_unseen
+            check(lib().zs3_nearest_rows(P(embedding[i].contiguous()), I(self.embed_dim), I(embedding.shape[2]),
+                                         I(embedding.shape[3]), I(fh), I(fw), P(st["emb"]), I(self.embed_dim), stream()),
+                  "zs3_nearest_rows")
             if use_real:
                 fake_rows[i].copy_(real_rows[i])
             else:
@@ -126,14 +251,30 @@ class GMMNStep:
                 off += n_c
                 if c == 255:
                     continue
-                if self.noise == "cpu":
-                    z = torch.rand((n_c, self.noise_dim)).to(dev, non_blocking=True)
-                else:
-                    z = ops.uniform((n_c, self.noise_dim), Fz.next_seed(), dev)
-                x = ops.gather_cat(emb_rows, idx_c, self.embed_dim, z, self.noise_dim, self.embed_dim + self.noise_dim)
+                do_mmd = c in self.seen and not has_unseen
+                sampled_only = do_mmd and use_real and self.fused_adam
+                z_cpu = torch.rand((n_c, self.noise_dim)) if self.noise == "cpu" else None
+                ridx_cpu = torch.randint(low=0, high=n_c, size=(self.bsg,)) if do_mmd else None
+                if sampled_only:
+                    ring = st["ring"][st["ring_pos"] % 512]
+                    st["ring_pos"] += 1
+                    ring.copy_(ridx_cpu)
+                    st["ridx"].copy_(ring, non_blocking=True)
+                    torch.index_select(idx_c, 0, st["ridx"], out=st["pix_local"])
+                    torch.add(st["pix_local"], i * npix, out=st["pix_global"])
+                    if z_cpu is not None:
+                        st["z"].copy_(z_cpu[ridx_cpu])
+                    self._run_sampled_update(training)
+                    mmd_losses[slot:slot + 1].copy_(st["loss"])
+                    mmd_slots.append((slot, len(classes)))
+                    slot += 1
+                    continue
+                # full-class generator call (image with an unseen class, or caller-supplied optimizer)
+                z = z_cpu.to(dev) if z_cpu is not None else ops.uniform((n_c, self.noise_dim), Fz.next_seed(), dev)
+                x = ops.gather_cat(st["emb"], idx_c, self.embed_dim, z, self.noise_dim, self.embed_dim + self.noise_dim)
                 fake_c, h, hd, seed = self._generator_forward(x, training)
-                if c in self.seen and not has_unseen:
-                    ridx = torch.randint(low=0, high=n_c, size=(self.bsg,)).to(dev, non_blocking=True)
+                if do_mmd:
+                    ridx = ridx_cpu.to(dev)
                     s = self.bsg
                     gen_s = ops.gather_rows(fake_c, ridx)
                     real_s = ops.gather_rows(real_rows[i], idx_c[ridx])
@@ -141,14 +282,13 @@ class GMMNStep:
                     gmat = torch.empty((2 * s, 2 * s), dtype=torch.float32, device=dev)
                     tile = torch.empty(2 * t * t, dtype=torch.float64, device=dev)
                     loss = mmd_losses[slot:slot + 1]
-                    check(lib().zs3_mmd_fwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), sig, I(len(self.sigma)), P(gmat),
-                                            P(tile), P(loss), stream()), "zs3_mmd_fwd")
+                    check(lib().zs3_mmd_fwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), self._sig, I(len(self.sigma)),
+                                            P(gmat), P(tile), P(loss), stream()), "zs3_mmd_fwd")
                     dgen = torch.empty_like(gen_s)
-                    check(lib().zs3_mmd_bwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(loss), P(one), P(dgen),
-                                            I(d), stream()), "zs3_mmd_bwd")
-                    self._generator_backward_rows(x, h, hd, seed, ridx, dgen)
-                    self.optimizer_generator.step()
-                    mmd_slots.append((slot, i, len(classes)))
+                    check(lib().zs3_mmd_bwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(loss), P(st["one"]),
+                                            P(dgen), I(d), stream()), "zs3_mmd_bwd")
+                    self._eager_update_rows(x, h, hd, seed, ridx, dgen)
+                    mmd_slots.append((slot, len(classes)))
                     slot += 1
                 if not use_real:
                     ops.scatter_rows(fake_c, idx_c, fake_rows[i])
@@ -159,9 +299,7 @@ class GMMNStep:
         closs.backward()
         self.optimizer.step()
         vals = torch.cat((mmd_losses, closs.detach().reshape(1))).cpu()   # the single read-back of the step
-        g_batch = 0.0
-        for sl, i, nuniq in mmd_slots:
-            g_batch += float(vals[sl]) / nuniq
+        g_batch = sum(float(vals[sl]) / nuniq for sl, nuniq in mmd_slots)
         return g_batch, float(vals[-1]), out
 
 

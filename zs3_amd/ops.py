@@ -314,19 +314,24 @@ def bilinear_bwd(dout, in_hw, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------- misc
-def dropout(x, p, seed, out=None, row_idx=None):
+def dropout(x, p, seed, out=None, row_idx=None, seed_dev=None):
     m, c, ld = _rows(x)
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     check(lib().zs3_dropout(P(x), I(ld), P(out), I(_rows(out)[2]), ctypes.c_long(m), I(c), F(p),
-                            ctypes.c_ulonglong(seed), P(row_idx), stream()), "zs3_dropout")
+                            ctypes.c_ulonglong(seed), P(row_idx), P(seed_dev), stream()), "zs3_dropout")
     return out
 
 
-def uniform(shape, seed, device):
-    out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(lib().zs3_uniform(P(out), ctypes.c_long(out.numel()), ctypes.c_ulonglong(seed), stream()), "zs3_uniform")
+def uniform(shape, seed, device, out=None, seed_dev=None):
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(lib().zs3_uniform(P(out), ctypes.c_long(out.numel()), ctypes.c_ulonglong(seed), P(seed_dev), stream()), "zs3_uniform")
     return out
+
+
+def counter_add(counter, v=1):
+    check(lib().zs3_counter_add(P(counter), ctypes.c_long(v), stream()), "zs3_counter_add")
 
 
 def nearest_rows(src_chw, size, ld=None):

@@ -64,7 +64,8 @@ class Adam(torch.optim.Adam):
                 g = p.grad if p.grad.stride() == p.stride() else p.grad.contiguous()
                 check(lib().zs3_adam_step(P(p), P(g), P(state["exp_avg"]), P(state["exp_avg_sq"]), ctypes.c_long(p.numel()),
                                           F(group["lr"]), F(b1), F(b2), F(group["eps"]), F(group["weight_decay"]),
-                                          I(int(state["step"])), stream()), "zs3_adam_step")
+                                          I(int(state["step"])), P(getattr(self, "_step_dev", None)), stream()),
+                      "zs3_adam_step")
                 touched.append(p)
         Fz.invalidate_planes(*touched)
         return loss
