@@ -17,6 +17,7 @@
 // Replaces convolution_backward(weight) for every nn.Conv2d / nn.Linear on the hot path (see conv_igemm.hip).
 #include "common.h"
 #include "zs3hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -254,14 +255,22 @@ int pick_splitk(int M, int tiles) {
   int maxs = chunks / 16;                 // at least 16 K-steps (512 pixels) per split
   if (maxs < 1) maxs = 1;
   int s = want < maxs ? want : maxs;
-  if (s > 32) s = 32;
+  if (s > 256) s = 256;
   return s;
 }
 
 }  // namespace
 
+// 128-wide tiles whenever there are more than 64 channels (measured: a half-empty 128 tile still beats 64-wide tiles)
+static int pick_tile_dim(int c) { return c > 64 ? 128 : 64; }
+static int tile_override() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ZS3_WGRAD_TILE"); v = e ? atoi(e) : 0; }
+  return v;
+}
 extern "C" int zs3_conv_wgrad_plan(int M, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
-  int bc = co > 64 ? 128 : 64, bd = ci > 64 ? 128 : 64;
+  int bc = pick_tile_dim(co), bd = pick_tile_dim(ci);
+  if (tile_override() == 64) { bc = 64; bd = 64; }
   int tiles = ((co + bc - 1) / bc) * ((ci + bd - 1) / bd) * taps;
   int s = pick_splitk(M, tiles);
   *splitk_out = s;
@@ -292,7 +301,8 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
   a.slab = (long)co_write * a.ldw;
   a.dw = splitk > 1 ? workspace : dw;
   hipStream_t st = (hipStream_t)stream;
-  int bc = co_write > 64 ? 128 : 64, bd = ci_write > 64 ? 128 : 64;
+  int bc = pick_tile_dim(co_write), bd = pick_tile_dim(ci_write);
+  if (tile_override() == 64) { bc = 64; bd = 64; }
   int rc;
   if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(a, taps, splitk, prec, st);
   else if (bc == 128) rc = launch_wgrad<128, 64>(a, taps, splitk, prec, st);
