@@ -15,6 +15,28 @@ from ._lib import require_gpu
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
+# ---------------------------------------------------------------------------------- side stream for weight gradients
+# A layer's wgrad only feeds the optimizer, while its dgrad feeds the next layer of the backward chain.  Many layers
+# of this network launch fewer workgroups than the 256 CUs can hold, so the wgrad kernels run on a second HIP stream
+# next to the dgrad / BatchNorm chain; the main stream joins it once, at the end of backward.
+WGRAD_SIDE_STREAM = True
+_side = {}
+_join_armed = [False]
+
+
+def wgrad_stream(device):
+    key = device.index
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def join_wgrad_stream():
+    """Make the current stream wait for every wgrad launched on the side stream (called at the end of backward)."""
+    _join_armed[0] = False
+    for st in _side.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
 # ---------------------------------------------------------------------------------- weight-plane cache
 _planes = {}
 
@@ -201,8 +223,21 @@ class _ConvBnAct(torch.autograd.Function):
         elif dskip is not None and ctx.needs_input_grad[0]:
             dx = dskip
         if need_w:
-            if geom is None:
+            side = wgrad_stream(dy.device) if (WGRAD_SIDE_STREAM and geom is None and not torch.cuda.is_current_stream_capturing()) else None
+            if side is not None:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)          # dy (and x) are ready on the main stream
+                dy.record_stream(side)          # keep their memory from being recycled while the side stream reads it
+                x.record_stream(side)
+                with torch.cuda.stream(side):
+                    dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec)
+                dw.record_stream(main)
+                if not _join_armed[0]:
+                    _join_armed[0] = True
+                    torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+            elif geom is None:
                 dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec)
+            if geom is None:
                 dw = dw.permute(0, 3, 1, 2)  # logical OIHW, channels_last memory like the parameter
                 if weight.dim() == 2:
                     dw = dw.reshape(weight.shape)

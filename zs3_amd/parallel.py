@@ -55,6 +55,10 @@ class GradSync:
         bi, off = self.where[p]
         if p in self._ready[bi]:
             return
+        if p.is_cuda:
+            from . import functional as Fz
+            if Fz._side:  # weight gradients are produced on the wgrad side stream: order the copy behind it
+                Fz.join_wgrad_stream()
         self.flat[bi][off:off + p.numel()].copy_(_as_flat(p.grad, p))
         self._ready[bi].add(p)
         if len(self._ready[bi]) == len(self.buckets[bi]):
