@@ -46,6 +46,19 @@ class GradSync:
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     # ---- hooks
+    def _comm_stream(self, p):
+        """Stream on which bucket copies and all-reduce launches are issued: the wgrad side stream when it is in use
+        (weight gradients are produced there, so no extra wait is needed and the main stream is never blocked),
+        otherwise the current stream."""
+        if not p.is_cuda:
+            return None
+        from . import functional as Fz
+        if Fz.WGRAD_SIDE_STREAM:
+            side = Fz.wgrad_stream(p.device)
+            side.wait_stream(torch.cuda.current_stream(p.device))   # gradients produced on the main stream (BN, bias)
+            return side
+        return None
+
     def _hook(self, p):
         if self.world == 1:
             return
@@ -55,14 +68,13 @@ class GradSync:
         bi, off = self.where[p]
         if p in self._ready[bi]:
             return
-        if p.is_cuda:
-            from . import functional as Fz
-            if Fz._side:  # weight gradients are produced on the wgrad side stream: order the copy behind it
-                Fz.join_wgrad_stream()
-        self.flat[bi][off:off + p.numel()].copy_(_as_flat(p.grad, p))
-        self._ready[bi].add(p)
-        if len(self._ready[bi]) == len(self.buckets[bi]):
-            self._launch(bi)
+        st = self._comm_stream(p)
+        ctx = torch.cuda.stream(st) if st is not None else _null()
+        with ctx:
+            self.flat[bi][off:off + p.numel()].copy_(_as_flat(p.grad, p))
+            self._ready[bi].add(p)
+            if len(self._ready[bi]) == len(self.buckets[bi]):
+                self._launch(bi)
 
     def _launch(self, bi):
         self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -73,17 +85,21 @@ class GradSync:
         every rank issues the same collectives), wait, and scatter the reduced values back into .grad."""
         if self.world == 1:
             return
-        for bi, bucket in enumerate(self.buckets):
-            if self._works[bi] is None and self._ready[bi]:
-                for p in bucket:
-                    if p not in self._ready[bi]:
-                        _, off = self.where[p]
-                        self.flat[bi][off:off + p.numel()].zero_()
-                self._launch(bi)
+        anyp = self.params[0]
+        st = self._comm_stream(anyp)
+        ctx = torch.cuda.stream(st) if st is not None else _null()
+        with ctx:
+            for bi, bucket in enumerate(self.buckets):
+                if self._works[bi] is None and self._ready[bi]:
+                    for p in bucket:
+                        if p not in self._ready[bi]:
+                            _, off = self.where[p]
+                            self.flat[bi][off:off + p.numel()].zero_()
+                    self._launch(bi)
         for bi, bucket in enumerate(self.buckets):
             if self._works[bi] is None:
                 continue
-            self._works[bi].wait()
+            self._works[bi].wait()   # the *current* (main) stream waits for the collective
             if self.average:
                 self.flat[bi].div_(self.world)
             for p in bucket:
@@ -99,6 +115,14 @@ class GradSync:
     def remove(self):
         for h in self._handles:
             h.remove()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def _as_flat(t, like):
