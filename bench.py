@@ -174,9 +174,10 @@ def main():
         tag = max(agg, key=lambda k: agg[k][2])
         n, fl, sec = agg[tag]
         ach = fl / sec / 1e12
+        traffic, traffic_src = pmc_traffic(tag)
         result["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TF,
-            "traffic": None, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
             "note": "achieved = algorithmic 2*M*N*K flops of the launches / HIP-event time; each product costs 3 bf16 MFMAs "
                     "(bf16x3), so MFMA-issue utilisation is 3x this fraction",
             "all_conv_igemm": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms_per_step": 1e3 * v[2] / args.steps}
@@ -188,6 +189,24 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r1_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the
+    gfx950 note of MI355X_MICROARCH.md).  PMC collection cannot run inside the timed process, hence the file."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    import re
+    m = re.match(r"conv_igemm(_ws)?<(\d+),(\d+),(\d)(?:,pipe(\d))?>", tag)
+    if not m:
+        return None, None
+    name = f"conv_igemm_ws_kernel<{m.group(4)}>" if m.group(1) else f"conv_igemm_kernel<{m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>"
+    k = json.load(open(path))["kernels"].get(name)
+    if not k:
+        return None, None
+    return k["read_bytes_per_launch"] + k["write_bytes_per_launch"], "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
 
 def cpu_baseline(args):
