@@ -1,0 +1,154 @@
+"""Full-size (BASELINE config: B=16, 513x513) checks through size-independent properties -- no oracle needed:
+adjoint identities tie forward, data-gradient and weight-gradient kernels together at the real layer shapes,
+determinism / idempotence of the whole forward, linearity of the conv kernels, CE partition-of-unity."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def dot(a, b):
+    return (a.double() * b.double()).sum().item()
+
+
+FULL_SHAPES = [  # N, H, Cin, Cout, k, stride, dil   (layer shapes of DeepLabv3+ at 513x513, B=16)
+    (16, 129, 304, 256, 3, 1, 1), (16, 33, 2048, 256, 3, 1, 18), (16, 129, 64, 256, 1, 1, 1), (16, 129, 128, 128, 3, 2, 1),
+    (16, 33, 1024, 256, 1, 1, 1), (16, 33, 512, 512, 3, 1, 4), (16, 129, 256, 21, 1, 1, 1), (16, 65, 256, 256, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("shape", FULL_SHAPES)
+def test_adjoint_identities_at_full_size(dev, shape):
+    """<dy, conv(x; w)> == <dgrad(dy; w), x> == <wgrad(dy, x), w>  (all three kernels, every tile variant the
+    heuristics pick at this size), to bf16x3 accuracy."""
+    from zs3_amd import ops
+    from zs3_amd.functional import _pad_channels
+    n, h, ci, co, k, s, d = shape
+    g = torch.Generator(device=dev).manual_seed(h * ci + co)
+    x = torch.randn(n, h, h, ci, device=dev, generator=g)
+    w = torch.randn(co, ci, k, k, device=dev, generator=g) / (ci * k * k) ** 0.5
+    pad = d * (k // 2)
+    wp = ops.prep_weight(w)
+    y, st = ops.conv2d_fwd(x, wp, s, pad, d, want_stats=True)
+    dy = _pad_channels(torch.randn(y.shape, device=dev, generator=g), 8)
+    dx = ops.conv2d_dgrad(dy, wp, (h, h), s, pad, d)
+    dw = ops.conv2d_wgrad(dy, x, co, ci, k, k, s, pad, pad, d)          # [co, k, k, ci]
+    a = dot(dy, y)
+    b = dot(dx, x)
+    c = dot(dw, w.permute(0, 2, 3, 1))
+    scale = (dy.double().norm() * y.double().norm()).item()
+    assert abs(a - b) <= 2e-5 * scale, (a, b)
+    assert abs(a - c) <= 2e-5 * scale, (a, c)
+    # BN partial sums of the epilogue == column sums of the stored output
+    ssum = st[:, 0].double().sum(0)
+    ref = y.double().sum((0, 1, 2))
+    assert ((ssum - ref).abs().max() / y.double().abs().sum((0, 1, 2)).max()).item() < 1e-6
+    # linearity in x (same weights): conv(x + x2) = conv(x) + conv(x2)
+    x2 = torch.randn(n, h, h, ci, device=dev, generator=g)
+    y12, _ = ops.conv2d_fwd(x + x2, wp, s, pad, d)
+    y2, _ = ops.conv2d_fwd(x2, wp, s, pad, d)
+    assert ((y12 - y - y2).abs().max() / y12.abs().max()).item() < 1e-4
+    # determinism: same launch twice is bit-identical
+    y_again, _ = ops.conv2d_fwd(x, wp, s, pad, d)
+    assert torch.equal(y, y_again)
+    assert torch.equal(dw, ops.conv2d_wgrad(dy, x, co, ci, k, k, s, pad, pad, d))
+
+
+def test_full_size_forward_is_deterministic_and_consistent(dev):
+    """B=16, 513x513 (BASELINE configs[1] shape): eval forward twice -> identical logits/argmax; the split forwards
+    compose to the full forward; BN(train) statistics equal the statistics of what BN saw."""
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.synthetic import make_batch
+    torch.manual_seed(1)
+    m = DeepLab(num_classes=21, pretrained=False, sync_bn=False).to(dev).eval()
+    b = make_batch(16, 513, seed=3, device=dev)
+    with torch.no_grad():
+        o1 = m(b["image"])
+        o2 = m(b["image"])
+        feat = m.forward_before_class_prediction(b["image"])
+        o3 = m.forward_class_prediction(feat, (513, 513))
+    assert o1.shape == (16, 21, 513, 513) and feat.shape == (16, 256, 129, 129)
+    assert torch.equal(o1, o2) and torch.equal(o1.argmax(1), o2.argmax(1))
+    assert torch.equal(o1, o3)
+    assert torch.isfinite(o1).all()
+    # CE: the gradient of every valid pixel sums to zero over classes (softmax - onehot), ignored pixels get none
+    lg = o1.detach().clone().requires_grad_(True)
+    loss = SegmentationLosses(cuda=True).build_loss("ce")(lg, b["label"])
+    loss.backward()
+    gsum = lg.grad.sum(1)
+    assert gsum.abs().max().item() < 1e-9
+    ign = b["label"] == 255
+    assert ign.any() and lg.grad.permute(0, 2, 3, 1)[ign].abs().max().item() == 0.0
+    # one full-size training step runs, is finite, and changes the weights
+    m.train()
+    from zs3_amd.optim import SGD
+    groups = [{"params": m.get_1x_lr_params(), "lr": 1e-3}, {"params": m.get_10x_lr_params(), "lr": 1e-2}]
+    opt = SGD(groups, momentum=0.9, weight_decay=5e-4)
+    w0 = m.decoder.last_conv[0].weight.detach().clone()
+    rm0 = m.backbone.layer3[5].bn2.running_mean.clone()
+    out = m(b["image"])
+    loss = SegmentationLosses(cuda=True).build_loss("ce")(out, b["label"])
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters())
+    assert not torch.equal(w0, m.decoder.last_conv[0].weight) and not torch.equal(rm0, m.backbone.layer3[5].bn2.running_mean)
+    assert int(m.backbone.bn1.num_batches_tracked) == 1
+
+
+def test_gmmn_step_device_noise_full_path(dev):
+    """hipGraph-captured generator update with device RNG: losses finite, generator and pred_conv move, backbone does
+    not, and two identically seeded runs give identical results (the captured update is deterministic)."""
+    from zs3_amd import functional as Fz
+    from zs3_amd.gmmn_trainer import GMMNStep
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.modeling.gmmn import GMMNnetwork
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.synthetic import make_batch
+    seen = [c for c in range(21) if c not in (10, 14)]
+
+    def run():
+        torch.manual_seed(1)
+        Fz.manual_seed(77)
+        m = DeepLab(num_classes=21, pretrained=False, sync_bn=False)
+        for name, mod in m.named_modules():
+            if name.endswith("bn3"):
+                mod.weight.data.fill_(0.1)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0            # model dropout off; the generator's dropout (p=0.5) stays on
+        gen = GMMNnetwork(300, 300, 256, 256)
+        m, gen = m.to(dev).train(), gen.to(dev).train()
+        groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+        opt, opt_g = SGD(groups, momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4)
+        w = torch.ones(21, device=dev)
+        w[[10, 14]] = 100.0
+        step = GMMNStep(m, gen, opt, opt_g, SegmentationLosses(weight=w, cuda=True).build_loss("ce"), seen=seen,
+                        unseen=[10, 14], noise="device")
+        out = []
+        for it in range(2):
+            b = make_batch(8, 129, seed=50 + it, with_label_emb=True, device=dev)
+            torch.manual_seed(5 + it)   # CPU stream of the sample indices
+            out.append(step(b["image"], b["label"], b["label_emb"])[:2])
+        return out, [p.detach().clone() for p in gen.parameters()], m.decoder.pred_conv.weight.detach().clone(), \
+            m.backbone.conv1.weight.detach().clone(), int(opt_g.state[next(gen.parameters())]["step"])
+
+    o1, g1, p1, s1, steps1 = run()
+    o2, g2, p2, s2, steps2 = run()
+    assert all(map(lambda v: v == v and abs(v) < 1e4, [x for pair in o1 for x in pair]))
+    assert o1 == o2 and steps1 == steps2 and steps1 > 10
+    for a, b_ in zip(g1, g2):
+        assert torch.equal(a, b_)
+    assert torch.equal(p1, p2) and torch.equal(s1, s2)
+    torch.manual_seed(1)
+    ref_gen = GMMNnetwork(300, 300, 256, 256)
+    assert not torch.equal(g1[0].cpu(), next(ref_gen.parameters()).detach())   # the generator was trained
