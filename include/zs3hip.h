@@ -135,6 +135,10 @@ int zs3_index_add_rows(const float* src, int lds, const long* idx, float* out, i
 /* torch.optim.SGD (train_pascal.py:55-60) and torch.optim.Adam (train_pascal_GMMN.py:65-67) update rules */
 int zs3_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, int nesterov,
                  int first, void* stream);
+/* One launch for a whole parameter set: table = int64[E][6] {p, g, momentum_buf, n, lr | wd<<32 (float bits), first},
+ * blockmap = int32[nblocks][2] {entry, chunk}; every block updates zs3_sgd_chunk() consecutive elements. */
+int zs3_sgd_chunk(void);
+int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov, void* stream);
 /* step_dev (optional): device int64 holding the number of steps taken so far; overrides `step` (= step_dev[0] + 1) */
 int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   float wd, int step, const void* step_dev, void* stream);

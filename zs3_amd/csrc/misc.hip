@@ -103,6 +103,31 @@ __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float l
   }
 }
 
+// multi-tensor SGD: one launch for the whole parameter set.  table[e] = {p, g, buf, n, lr|wd (two packed floats), first};
+// blockmap[b] = {entry, chunk}: block b updates elements [chunk*CHUNK, (chunk+1)*CHUNK) of entry e.
+#define ZS3_SGD_CHUNK 16384
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const long* __restrict__ table, const int* __restrict__ blockmap,
+                                                       float momentum, int nesterov) {
+  const int e = blockmap[2 * blockIdx.x], chunk = blockmap[2 * blockIdx.x + 1];
+  const long* t = table + 6L * e;
+  float* p = reinterpret_cast<float*>(t[0]);
+  const float* g = reinterpret_cast<const float*>(t[1]);
+  float* buf = reinterpret_cast<float*>(t[2]);
+  const long n = t[3];
+  const float lr = __uint_as_float((unsigned)(t[4] & 0xFFFFFFFFL)), wd = __uint_as_float((unsigned)(t[4] >> 32));
+  const int first = (int)t[5];
+  const long lo = (long)chunk * ZS3_SGD_CHUNK, hi = min(n, lo + ZS3_SGD_CHUNK);
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    float d = g[i] + wd * p[i];
+    if (momentum != 0.f) {
+      float b = first ? d : momentum * buf[i] + d;
+      buf[i] = b;
+      d = nesterov ? d + momentum * b : b;
+    }
+    p[i] -= lr * d;
+  }
+}
+
 // torch.optim.Adam (no amsgrad, eps outside sqrt/bias-correction as in torch): step_size = lr / bc1,
 // denom = sqrt(v)/sqrt(bc2) + eps
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
@@ -185,6 +210,15 @@ extern "C" int zs3_sgd_step(float* p, const float* g, float* buf, long n, float 
   if (n <= 0) return 0;
   hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, lr, momentum, wd,
                      nesterov, first);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_sgd_chunk(void) { return ZS3_SGD_CHUNK; }
+extern "C" int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov,
+                             void* stream) {
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)table,
+                     (const int*)blockmap, momentum, nesterov);
   return ZS3_LAUNCH_CHECK();
 }
 

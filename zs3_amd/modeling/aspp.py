@@ -60,15 +60,48 @@ class ASPP(nn.Module):
         self._init_weight()
         to_channels_last_(self)
 
+    # The five branches are independent and, at output stride 16, each of them launches fewer workgroups than the
+    # chip has CUs (33x33 maps): they run on three HIP streams and write into disjoint channel slices of one buffer.
+    # autograd replays each node's backward on the stream of its forward, so the backward overlaps the same way.
+    _streams = {}
+
+    def _branch_streams(self, device):
+        key = device.index
+        if key not in ASPP._streams:
+            ASPP._streams[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return ASPP._streams[key]
+
     def forward_nhwc(self, x):
         n, h, w, _ = x.shape
         cat = torch.empty((n, h, w, 1280), dtype=torch.float32, device=x.device)
-        parts = [br.forward_nhwc(x, out=cat[..., 256 * i:256 * (i + 1)])
-                 for i, br in enumerate((self.aspp1, self.aspp2, self.aspp3, self.aspp4))]
-        pooled = Fz.global_avg_pool(x)                                         # [N,1,1,2048]
         bn = self.global_avg_pool[2] if isinstance(self.global_avg_pool[2], nn.BatchNorm2d) else None
-        pooled = self.global_avg_pool[1].forward_nhwc(pooled, bn, act=Fz.ACT_RELU)  # [N,1,1,256]
-        parts.append(Fz.broadcast_to(pooled, (h, w), out=cat[..., 1024:1280]))
+
+        def branch(i):
+            br = (self.aspp1, self.aspp2, self.aspp3, self.aspp4)[i]
+            return br.forward_nhwc(x, out=cat[..., 256 * i:256 * (i + 1)])
+
+        def pooled():
+            p = self.global_avg_pool[1].forward_nhwc(Fz.global_avg_pool(x), bn, act=Fz.ACT_RELU)   # [N,1,1,256]
+            return Fz.broadcast_to(p, (h, w), out=cat[..., 1024:1280])
+
+        concurrent = x.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if not concurrent:
+            parts = [branch(0), branch(1), branch(2), branch(3), pooled()]
+        else:
+            main = torch.cuda.current_stream()
+            s1, s2 = self._branch_streams(x.device)
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            parts = [None] * 5
+            parts[1] = branch(1)
+            parts[0] = branch(0)
+            with torch.cuda.stream(s1):
+                parts[2] = branch(2)
+            with torch.cuda.stream(s2):
+                parts[3] = branch(3)
+                parts[4] = pooled()
+            main.wait_stream(s1)
+            main.wait_stream(s2)
         y = self.conv1.forward_nhwc(Fz.cat_slices(cat, parts), self.bn1, act=Fz.ACT_RELU)
         return self.dropout.forward_nhwc(y)
 

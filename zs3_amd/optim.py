@@ -9,34 +9,51 @@ from ._lib import F, I, P, check, lib, stream
 
 
 class SGD(torch.optim.SGD):
-    """torch.optim.SGD semantics (momentum, dampening=0, weight_decay, nesterov); one fused kernel per parameter."""
+    """torch.optim.SGD semantics (momentum, dampening=0, weight_decay, nesterov), state-dict compatible
+    (`momentum_buffer`).  All parameters of all groups that share momentum/nesterov are updated by ONE multi-tensor
+    launch: a small table of {param, grad, buffer, n, lr, wd} records goes to the device each step (gradient tensors
+    are new objects every step), 16 K elements per workgroup."""
 
     @torch.no_grad()
     def step(self, closure=None):
+        import struct
         loss = closure() if closure is not None else None
-        touched = []
+        chunk = lib().zs3_sgd_chunk()
+        by_cfg = {}
+        touched, keep = [], []
         for group in self.param_groups:
             if group.get("dampening", 0) != 0 or group.get("maximize", False):
                 raise NotImplementedError("zs3_amd.optim.SGD supports dampening=0, maximize=False")
             lr, mom, wd, nest = group["lr"], group["momentum"], group["weight_decay"], group["nesterov"]
+            packed = struct.unpack("<q", struct.pack("<ff", lr, wd))[0]
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 g = p.grad
-                dense_p = p.data if p.data.is_contiguous() else None
                 # parameters are dense in *some* permutation (channels_last conv weights): the update is elementwise,
-                # so it only needs p, grad and the buffer to share strides
+                # so p, grad and the buffer only need to share strides
                 if g.stride() != p.stride():
                     g = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(g)
+                    keep.append(g)
                 state = self.state[p]
                 first = 0
-                if mom != 0 and "momentum_buffer" not in state or (mom != 0 and state["momentum_buffer"] is None):
+                if mom != 0 and state.get("momentum_buffer") is None:
                     state["momentum_buffer"] = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
                     first = 1
                 buf = state.get("momentum_buffer") if mom != 0 else None
-                check(lib().zs3_sgd_step(P(p), P(g), P(buf), ctypes.c_long(p.numel()), F(lr), F(mom), F(wd), I(int(nest)),
-                                         I(first), stream()), "zs3_sgd_step")
+                rec = by_cfg.setdefault((p.device, float(mom), bool(nest)), [])
+                rec.append((p.data_ptr(), g.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel(), packed, first))
                 touched.append(p)
+        for (dev, mom, nest), recs in by_cfg.items():
+            table = torch.tensor(recs, dtype=torch.int64).pin_memory()
+            bmap = []
+            for e, r in enumerate(recs):
+                bmap.extend((e, c) for c in range((r[3] + chunk - 1) // chunk))
+            blockmap = torch.tensor(bmap, dtype=torch.int32).pin_memory()
+            table_d, map_d = table.to(dev, non_blocking=True), blockmap.to(dev, non_blocking=True)
+            check(lib().zs3_sgd_multi(P(table_d), P(map_d), I(len(bmap)), F(mom), I(int(nest)), stream()), "zs3_sgd_multi")
+            keep.extend((table, blockmap, table_d, map_d))
+        self._keepalive = keep   # pinned staging buffers must outlive the asynchronous copies
         Fz.invalidate_planes(*touched)
         return loss
 
