@@ -45,13 +45,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_ci = (p.ci_write + BD - 1) / BD, tiles_co = (p.co_write + BC - 1) / BC;
-  int b = blockIdx.x;
+  // 1-D grid, XCD-aware: every XCD (private L2) gets a contiguous range of (split, tile) pairs, so the tiles
+  // that reduce over the same pixel chunk -- and therefore read the same dy / x rows -- share one L2
+  const int ntiles = tiles_ci * tiles_co * p.KH * p.KW;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = b / ntiles;
+  b -= split * ntiles;
   const int tci = b % tiles_ci; b /= tiles_ci;
   const int tco = b % tiles_co; b /= tiles_co;
   const int tap = b;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int co0 = tco * BC, ci0 = tci * BD;
-  const int m_begin = blockIdx.y * p.chunk;
+  const int m_begin = split * p.chunk;
   const int m_end = min(p.M, m_begin + p.chunk);
 
   // staging coordinates: A (dy) -- BC/4 threads per pixel, B (x) -- BD/4 threads per pixel
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
   }
 
-  float* out = p.dw + (size_t)blockIdx.y * p.slab;
+  float* out = p.dw + (size_t)split * p.slab;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -240,7 +245,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 template <int BC, int BD>
 int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, hipStream_t st) {
   int tiles = ((a.co_write + BC - 1) / BC) * ((a.ci_write + BD - 1) / BD) * taps;
-  dim3 grid(tiles, splitk), block(256);
+  dim3 grid(tiles * splitk), block(256);
   if (prec == 1)
     hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 1>), grid, block, 0, st, a);
   else
