@@ -116,7 +116,7 @@ def test_gmmn_step_device_noise_full_path(dev):
     from zs3_amd.utils.synthetic import make_batch
     seen = [c for c in range(21) if c not in (10, 14)]
 
-    def run():
+    def run(use_table=False):
         torch.manual_seed(1)
         Fz.manual_seed(77)
         m = DeepLab(num_classes=21, pretrained=False, sync_bn=False)
@@ -138,12 +138,17 @@ def test_gmmn_step_device_noise_full_path(dev):
         for it in range(2):
             b = make_batch(8, 129, seed=50 + it, with_label_emb=True, device=dev)
             torch.manual_seed(5 + it)   # CPU stream of the sample indices
-            out.append(step(b["image"], b["label"], b["label_emb"])[:2])
+            if use_table:
+                out.append(step(b["image"], b["label"], table=b["table"])[:2])
+            else:
+                out.append(step(b["image"], b["label"], b["label_emb"])[:2])
         return out, [p.detach().clone() for p in gen.parameters()], m.decoder.pred_conv.weight.detach().clone(), \
             m.backbone.conv1.weight.detach().clone(), int(opt_g.state[next(gen.parameters())]["step"])
 
     o1, g1, p1, s1, steps1 = run()
     o2, g2, p2, s2, steps2 = run()
+    o3, g3, p3, s3, steps3 = run(use_table=True)   # on-device table lookup == the dataloader's label_emb, bit for bit
+    assert o3 == o1 and torch.equal(p3, p1) and all(torch.equal(a, b_) for a, b_ in zip(g3, g1))
     assert all(map(lambda v: v == v and abs(v) < 1e4, [x for pair in o1 for x in pair]))
     assert o1 == o2 and steps1 == steps2 and steps1 > 10
     for a, b_ in zip(g1, g2):

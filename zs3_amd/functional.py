@@ -201,9 +201,14 @@ class _ConvBnAct(torch.autograd.Function):
                 dz = dA
             if dres is not None:
                 dres = dz
-            dy = _pad_channels(dz, 8) if (need_x or need_w) else dz
-            if ctx.has_bias and ctx.needs_input_grad[4]:
-                dbias = ops.colstats(dz)[:, 0].sum(0) if vec_ok else dz.reshape(-1, cout).sum(0)
+            want_bias = ctx.has_bias and ctx.needs_input_grad[4]
+            dy = _pad_channels(dz, 8) if (need_x or need_w or (want_bias and not vec_ok)) else dz
+            if want_bias:
+                if vec_ok:
+                    dbias = ops.colstats(dz)[:, 0].sum(0)
+                else:  # odd channel count (21 classes): reduce the zero-padded 8-aligned copy with the HIP kernel
+                    full = dy.as_strided(dy.shape[:-1] + (ops._rows(dy)[2],), dy.stride(), dy.storage_offset())
+                    dbias = ops.colstats(full)[:, 0].sum(0)[:cout]
         dx = dw = None
         if need_x:
             if geom is None:

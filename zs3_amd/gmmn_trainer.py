@@ -207,8 +207,14 @@ class GMMNStep:
         self._resplit()
 
     # ------------------------------------------------------------------ one iteration
-    def __call__(self, image, target, embedding):
-        require_gpu(image, target, embedding)
+    def __call__(self, image, target, embedding=None, table=None):
+        """embedding: the reference's `label_emb` [B, embed_dim, H, W] (zs3/dataloaders/datasets/base.py:45-51), or
+        table: the [num_classes, embed_dim] class-embedding table itself -- then the per-pixel embedding rows are looked
+        up on the device at feature resolution (embed(nearest(label)) == nearest(embed(label)) exactly),
+        which avoids materialising and shipping 316 MB per 513x513 sample."""
+        if (embedding is None) == (table is None):
+            raise ValueError("pass exactly one of `embedding` (label_emb) or `table`")
+        require_gpu(image, target, embedding, table)
         model, dev = self.model, image.device
         b = image.shape[0]
         with torch.no_grad():
@@ -229,6 +235,9 @@ class GMMNStep:
         hist = torch.zeros((b, 256), dtype=torch.int64, device=dev).scatter_add_(1, tgt_l, torch.ones_like(tgt_l))
         order = torch.argsort(tgt_l, dim=1, stable=True)                                          # pixels grouped by class
         hist_h = hist.cpu().tolist()
+        if table is not None:
+            table_f = table.contiguous().float()
+            tgt_cls = torch.where(tgt_l == 255, torch.zeros_like(tgt_l), tgt_l).contiguous()
         training = self.generator.training
         n_mmd = int(sum(1 for i in range(b) for c in range(255) if hist_h[i][c] > 0))
         mmd_losses = torch.zeros(max(n_mmd, 1), dtype=torch.float32, device=dev)
@@ -237,9 +246,13 @@ class GMMNStep:
             classes = [c for c in range(256) if hist_h[i][c] > 0]
             has_unseen = any(c in self.unseen for c in classes)
             use_real = self.real_seen_features and not has_unseen
-            check(lib().zs3_nearest_rows(P(embedding[i].contiguous()), I(self.embed_dim), I(embedding.shape[2]),
-                                         I(embedding.shape[3]), I(fh), I(fw), P(st["emb"]), I(self.embed_dim), stream()),
-                  "zs3_nearest_rows")
+            if embedding is not None:
+                check(lib().zs3_nearest_rows(P(embedding[i].contiguous()), I(self.embed_dim), I(embedding.shape[2]),
+                                             I(embedding.shape[3]), I(fh), I(fw), P(st["emb"]), I(self.embed_dim), stream()),
+                      "zs3_nearest_rows")
+            else:  # label 255 -> class 0 like the dataloader (base.py:47-48); those rows are never used
+                check(lib().zs3_gather_rows(P(table_f), I(self.embed_dim), P(tgt_cls[i]), P(st["emb"]), I(self.embed_dim),
+                                            ctypes.c_long(npix), I(self.embed_dim), stream()), "zs3_gather_rows")
             if use_real:
                 fake_rows[i].copy_(real_rows[i])
             else:
