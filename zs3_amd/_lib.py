@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libzs3hip.so")
+LIB_PATH = os.environ.get("ZS3_LIB") or os.path.join(_HERE, "lib", "libzs3hip.so")   # ZS3_LIB: A/B builds
 _lib = None
 
 
