@@ -58,7 +58,13 @@ def _worker(rank, world, port, q):
         # SyncBN statistics: global sums / count from per-rank chunk partials
         part = torch.arange(2 * 2 * 4, dtype=torch.float32).reshape(2, 2, 4) * (rank + 1)
         tot, cnt = combine_bn_partials(part, 10 * (rank + 1))
-        assert cnt == 30.0 and torch.equal(tot, (torch.arange(16.).reshape(2, 2, 4).sum(0, keepdim=True)) * 3)
+        # -> fp32 hi/lo "chunks" of the fp64 global sums + a 1-element fp64 count tensor
+        assert cnt.dtype == torch.float64 and cnt.item() == 30.0 and tot.shape == (2, 2, 4)
+        assert torch.equal(tot.double().sum(0), (torch.arange(16.).reshape(2, 2, 4).sum(0).double()) * 3)
+        big = torch.full((3, 2, 4), 1e8 / 3 + rank, dtype=torch.float32)     # sums that fp32 cannot hold exactly
+        tot, _ = combine_bn_partials(big, 1)
+        other = torch.full((3, 2, 4), 1e8 / 3 + (1 - rank), dtype=torch.float32)
+        assert torch.equal(tot.double().sum(0), big.double().sum(0) + other.double().sum(0))
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

@@ -1,0 +1,82 @@
+"""Single-GPU exercise of the multi-GPU plumbing on real RCCL: a one-rank NCCL process group runs the bucketed gradient
+all-reduce from the wgrad side stream, the globally normalised CE and the SyncBN statistics path.  With one rank every
+collective is the identity, so the step must reproduce the plain single-process step (up to fp64 re-association in the SyncBN sums)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def one_rank_group(dev):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    yield True
+    dist.destroy_process_group()
+
+
+def _step(dev, ddp):
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.optim import SGD
+    from zs3_amd.parallel import GradSync, broadcast_parameters, enable_sync_bn
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.synthetic import make_batch
+    torch.manual_seed(1)
+    m = DeepLab(num_classes=21, pretrained=False, sync_bn=True)
+    for name, mod in m.named_modules():
+        if name.endswith("bn3"):
+            mod.weight.data.fill_(0.1)
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m = m.to(dev).train()
+    sync = None
+    import zs3_amd.parallel as par
+    par.FORCE_COLLECTIVES = ddp
+    if ddp:
+        broadcast_parameters(m)
+        assert enable_sync_bn(m) == 113
+        sync = GradSync(list(m.parameters()), bucket_mb=16.0, force=True)
+        assert len(sync.buckets) > 4
+    groups = [{"params": m.get_1x_lr_params(), "lr": 1e-3}, {"params": m.get_10x_lr_params(), "lr": 1e-2}]
+    opt = SGD(groups, momentum=0.9, weight_decay=5e-4)
+    crit = SegmentationLosses(cuda=True, group=True if ddp else None).build_loss("ce")
+    b = make_batch(4, 97, seed=3, device=dev)
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        loss = crit(m(b["image"]), b["label"])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    if sync is not None:
+        assert sync.bytes_reduced == 2 * 4 * sum(p.numel() for p in m.parameters())
+        sync.remove()
+    par.FORCE_COLLECTIVES = False
+    return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_one_rank_rccl_step_equals_plain_step(dev, one_rank_group):
+    l0, s0 = _step(dev, ddp=False)
+    l1, s1 = _step(dev, ddp=True)
+    # one rank: every collective is the identity; the SyncBN path only re-associates fp64 sums
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-6, (l0, l1)
+    for k in s0:
+        if s0[k].dtype.is_floating_point:
+            err = (s0[k] - s1[k]).abs().max().item()
+            assert err <= 1e-6 + 1e-5 * s0[k].abs().max().item(), (k, err)

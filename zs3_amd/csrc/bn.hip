@@ -116,7 +116,7 @@ __device__ __forceinline__ void combine_partials(const float* partial, int chunk
 }
 
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* partial, int chunks, int C, double count,
-                                                             const float* gamma, const float* beta, float eps,
+                                                             const double* count_dev, const float* gamma, const float* beta, float eps,
                                                              float momentum, float* running_mean, float* running_var,
                                                              float* mean_out, float* invstd_out, float* scale_out,
                                                              float* shift_out) {
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* parti
   if (c >= C) return;
   double s, q;
   combine_partials(partial, chunks, C, c, s, q);
+  if (count_dev) count = *count_dev;  // cross-rank sample count produced on the device by the SyncBN all-reduce
   if ((threadIdx.x & 63) == 0) {
     double mean = s / count;
     double var = q / count - mean * mean;
@@ -157,12 +158,13 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int chunks, int C, double count,
-                                                             float* dgamma, float* dbeta, float* c1, float* c2,
+                                                             const double* count_dev, float* dgamma, float* dbeta, float* c1, float* c2,
                                                              int use_batch_stats) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   double s, q;
   combine_partials(partial, chunks, C, c, s, q);
+  if (count_dev) count = *count_dev;
   if ((threadIdx.x & 63) == 0) {
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
@@ -335,12 +337,13 @@ extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, in
   return ZS3_LAUNCH_CHECK();
 }
 
-extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const float* gamma,
+extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
+                                   const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_out, float* invstd_out, float* scale_out,
                                    float* shift_out, void* stream) {
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
-                     count, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
+                     count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
                      shift_out);
   return ZS3_LAUNCH_CHECK();
 }
@@ -353,10 +356,11 @@ extern "C" int zs3_bn_eval_affine(const float* gamma, const float* beta, const f
   return ZS3_LAUNCH_CHECK();
 }
 
-extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, float* dgamma, float* dbeta,
+extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
+                                   float* dgamma, float* dbeta,
                                    float* c1, float* c2, int use_batch_stats, void* stream) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
-                     count, dgamma, dbeta, c1, c2, use_batch_stats);
+                     count, count_dev, dgamma, dbeta, c1, c2, use_batch_stats);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -195,10 +195,19 @@ def colstats(x):
     return part
 
 
+def _count_args(count):
+    """(host count, device count pointer): `count` is a python number or a 1-element fp64 device tensor."""
+    if torch.is_tensor(count):
+        assert count.dtype == torch.float64 and count.numel() == 1 and count.is_cuda
+        return ctypes.c_double(0.0), P(count)
+    return ctypes.c_double(count), P(None)
+
+
 def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var):
     c = partial.shape[2]
+    chost, cdev = _count_args(count)
     out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # mean, invstd, scale, shift
-    check(lib().zs3_bn_fwd_finalize(P(partial), I(partial.shape[0]), I(c), ctypes.c_double(count), P(gamma), P(beta),
+    check(lib().zs3_bn_fwd_finalize(P(partial), I(partial.shape[0]), I(c), chost, cdev, P(gamma), P(beta),
                                     F(eps), F(momentum), P(running_mean), P(running_var), P(out[0]), P(out[1]),
                                     P(out[2]), P(out[3]), stream()), "zs3_bn_fwd_finalize")
     return out
@@ -242,7 +251,8 @@ def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None):
 def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True):
     c = partial.shape[2]
     out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # dgamma, dbeta, c1, c2
-    check(lib().zs3_bn_bwd_finalize(P(partial), I(partial.shape[0]), I(c), ctypes.c_double(count), P(out[0]), P(out[1]),
+    chost, cdev = _count_args(count)
+    check(lib().zs3_bn_bwd_finalize(P(partial), I(partial.shape[0]), I(c), chost, cdev, P(out[0]), P(out[1]),
                                     P(out[2]), P(out[3]), I(int(use_batch_stats)), stream()), "zs3_bn_bwd_finalize")
     return out
 

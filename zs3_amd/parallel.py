@@ -13,10 +13,15 @@ import torch
 import torch.distributed as dist
 
 
+# single-GPU plumbing tests set this to run the SyncBN reduction path with one rank
+FORCE_COLLECTIVES = False
+
+
 class GradSync:
-    def __init__(self, params, process_group=None, bucket_mb=64.0, average=False):
+    def __init__(self, params, process_group=None, bucket_mb=64.0, average=False, force=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = force   # run the full hook / bucket / all-reduce path even with one rank (single-GPU plumbing test)
         self.average = average
         self.params = [p for p in params if p.requires_grad]
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -60,7 +65,7 @@ class GradSync:
         return None
 
     def _hook(self, p):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if not self._armed:
             self._armed = True
@@ -83,7 +88,7 @@ class GradSync:
     def finish(self):
         """End of backward: flush incomplete buckets (parameters that received no gradient contribute zeros, so
         every rank issues the same collectives), wait, and scatter the reduced values back into .grad."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         anyp = self.params[0]
         st = self._comm_stream(anyp)
@@ -149,15 +154,22 @@ def broadcast_parameters(module, src=0, group=None):
 
 def combine_bn_partials(partial, count, group=None):
     """SyncBN statistics (batchnorm.py:60-67,101-122 of the vendored module: sum / sum-of-squares reduced
-    over replicas): collapse the per-chunk partial sums [chunks,2,C] to one row, all-reduce it together with
-    the sample count.  Returns ([1,2,C] global sums, global count)."""
-    tot = partial.sum(0, keepdim=True)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return tot, count
-    cnt = torch.tensor([float(count)], dtype=torch.float64, device=partial.device)
-    dist.all_reduce(tot, group=group)
-    dist.all_reduce(cnt, group=group)
-    return tot, float(cnt.item())
+    over replicas).  The per-chunk partial sums [chunks,2,C] are collapsed in fp64, the local sample count is
+    appended, and ONE fp64 all-reduce carries both; nothing visits the host.  Returns (partial', count') for
+    zs3_bn_*_finalize: partial' is the fp64 totals as an fp32 hi/lo pair of "chunks" [2,2,C] (the finalize
+    kernel re-adds them in fp64), count' a 1-element fp64 device tensor."""
+    if not FORCE_COLLECTIVES and (not dist.is_initialized() or dist.get_world_size(group) == 1):
+        return partial, count
+    c = partial.shape[2]
+    buf = torch.empty(2 * c + 1, dtype=torch.float64, device=partial.device)
+    torch.sum(partial.double(), dim=0, out=buf[:2 * c].view(2, c))
+    buf[2 * c] = float(count)
+    if dist.is_initialized():
+        dist.all_reduce(buf, group=group)
+    tot = buf[:2 * c].view(2, c)
+    hi = tot.float()
+    lo = (tot - hi.double()).float()
+    return torch.stack((hi, lo), 0), buf[2 * c:]
 
 
 def enable_sync_bn(module, group=None):
