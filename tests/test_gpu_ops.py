@@ -55,6 +55,43 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 5e-5
 
 
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 21, 31])
+def test_conv_every_tile_config(dev, cfg):
+    """every kernel variant behind zs3_conv_igemm (register-staged tiles, wave-specialised, LDS-DMA) on ragged shapes:
+    M tails, channel tails (304 -> 320, 21 -> 24), stride 2, dilation, fused epilogue and BN partial sums"""
+    from zs3_amd import ops
+    from zs3_amd.functional import _pad_channels
+    for (n, h, w, ci, co, k, s, d) in [(2, 33, 31, 256, 256, 3, 1, 1), (1, 35, 33, 304, 256, 3, 1, 1),
+                                       (2, 33, 33, 128, 128, 3, 2, 1), (1, 17, 17, 2048, 256, 3, 1, 6),
+                                       (2, 20, 20, 256, 21, 1, 1, 1), (3, 17, 19, 64, 256, 1, 1, 1)]:
+        g = torch.Generator().manual_seed(cfg * 131 + h + ci)
+        x = torch.randn(n, ci, h, w, generator=g)
+        wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+        pad = d * (k // 2)
+        xr = x.double().requires_grad_(True)
+        ref = F.conv2d(xr, wt.double(), stride=s, padding=pad, dilation=d)
+        dy = torch.randn(ref.shape, generator=g)
+        ref.backward(dy.double())
+        xg = x.to(dev).permute(0, 2, 3, 1).contiguous()
+        wp = ops.prep_weight(wt.to(dev))
+        y, st = ops.conv2d_fwd(xg, wp, s, pad, d, want_stats=True, tile_cfg=cfg)
+        assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5, (cfg, ci, co)
+        ssum = st[:, 0].double().sum(0).cpu()
+        qsum = st[:, 1].double().sum(0).cpu()
+        refd = ref.detach()
+        assert ((ssum - refd.sum((0, 2, 3))).abs().max() / refd.abs().sum((0, 2, 3)).max()).item() < 1e-5
+        assert ((qsum - refd.square().sum((0, 2, 3))).abs().max() / refd.square().sum((0, 2, 3)).max()).item() < 1e-5
+        sc, sh = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+        res = torch.randn(ref.shape, generator=g)
+        z, _ = ops.conv2d_fwd(xg, wp, s, pad, d, scale=sc.to(dev), shift=sh.to(dev), act=1, tile_cfg=cfg,
+                              res=res.to(dev).permute(0, 2, 3, 1).contiguous())
+        zref = torch.relu(refd * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double())
+        assert rel(z.permute(0, 3, 1, 2), zref) < 5e-5, (cfg, ci, co)
+        dyg = _pad_channels(dy.to(dev).permute(0, 2, 3, 1).contiguous(), 8)
+        dx = ops.conv2d_dgrad(dyg, wp, (h, w), s, pad, d, tile_cfg=cfg)
+        assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 5e-5, (cfg, ci, co)
+
+
 @pytest.mark.parametrize("shape,res,relu,train", [((2, 17, 19, 64), True, True, True), ((3, 9, 9, 48), False, True, True),
                                                   ((2, 5, 5, 2048), True, True, True), ((4, 1, 1, 256), False, True, True),
                                                   ((2, 17, 19, 64), True, True, False), ((2, 8, 8, 1280), False, False, True)])

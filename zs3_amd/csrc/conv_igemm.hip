@@ -653,6 +653,405 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the wave-specialised 256x128x32 kernel (tile_cfg 31).
+//
+// Producers (waves 4-7) never touch the data: every tile row is fetched with global_load_lds_dwordx4, which
+// moves 64 lanes x 16 B straight from L2/HBM into LDS (wave-uniform LDS base + lane*16; the *global* address is
+// per lane).  The A tile therefore sits in LDS as raw fp32 (256 rows x 128 B) and the B tile as the packed
+// bf16 {hi,lo} lines of zs3_prep_weight (128 rows x 128 B); with no staging registers the prefetch depth is the
+// LDS ring: three 48 KB stages, tiles k+1 and k+2 in flight while tile k is multiplied, one s_barrier per K
+// step, and the producers only wait on a counted vmcnt (never 0 inside the loop).
+// Rows are 128 B apart, so the 16-byte chunks of row r are stored XOR-swizzled (chunk c at slot
+// c ^ ((r>>1)&7)): the producer applies it to the lane's global source address, the consumer to its read
+// address, and the ds_read_b128 fragment reads of 16 different rows hit 16 different bank quads.
+// Consumers (waves 0-3, one 64x128 wave tile each, so every A value is converted exactly once) read 8 fp32 of
+// their row, split them into bf16 hi/lo in registers (2 VALU per MFMA, hidden under the 32-cycle MFMAs) and
+// issue the three bf16 MFMAs per product.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int PREC>
+__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
+  constexpr int BM = 256, BN = 128, TM = 2, TN = 4, NST = 3;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int ntn = (p.ncols + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / ntn, nt = bid - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int KT = p.KH * p.KW * (p.cin_pad / 32);
+  const int wm = wave & 3;
+
+  f32x16 acc[TM][TN];
+
+  if (producer) {
+    const int pw = wave - 4;
+    const int lrow = lane >> 3, slot = lane & 7;
+    constexpr int RA = 8, RB = 4;   // 8-row groups of A / B fetched per producer wave and K step
+    // group g of A holds tile rows 8g..8g+7 (g = 8 pw + i); the swizzle of row r is (r>>1)&7 = ((i&1)<<2) | (lane>>4)
+    const int chunk_even = slot ^ (lane >> 4), chunk_odd = slot ^ (4 | (lane >> 4));
+    const float* xrow[RA];
+    int bh[RA], bw[RA];
+    bool rvalid[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int m = m0 + 64 * pw + 8 * i + lrow;
+      rvalid[i] = m < p.M;
+      int mm = rvalid[i] ? m : 0;
+      int hw = p.Ho * p.Wo;
+      int n = mm / hw, rem = mm - n * hw;
+      int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+      xrow[i] = p.x + (size_t)n * p.H * p.W * p.ldx + ((i & 1) ? chunk_odd : chunk_even) * 4;
+      if (p.dgrad) {
+        bh[i] = oh + p.pad_h;
+        bw[i] = ow + p.pad_w;
+      } else {
+        bh[i] = oh * p.stride - p.pad_h;
+        bw[i] = ow * p.stride - p.pad_w;
+      }
+    }
+    const unsigned short* wrow[RB];
+    int wstep[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      int col = n0 + 32 * pw + 8 * j + lrow;
+      bool ok = col < p.ncols;
+      wrow[j] = ok ? p.w_pk + (size_t)col * (2 * p.ldw) + ((j & 1) ? chunk_odd : chunk_even) * 8
+                   : reinterpret_cast<const unsigned short*>(p.zero);
+      wstep[j] = ok ? 1 : 0;
+    }
+    int kh = 0, kw = 0, c0 = 0, kofs = 0;
+    const float* abase[RA];
+    int astep[RA];
+    auto issue_tile = [&](int stage) {
+      if (c0 == 0) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          int hi, wi;
+          bool ok = rvalid[i];
+          if (p.dgrad) {
+            const int th = bh[i] - kh * p.dil, tw = bw[i] - kw * p.dil;
+            const int mask = (1 << p.stride_log2) - 1;
+            hi = th >> p.stride_log2;
+            wi = tw >> p.stride_log2;
+            ok = ok && ((th | tw) >= 0) && (((th | tw) & mask) == 0);
+          } else {
+            hi = bh[i] + kh * p.dil;
+            wi = bw[i] + kw * p.dil;
+            ok = ok && ((hi | wi) >= 0);
+          }
+          ok = ok && hi < p.H && wi < p.W;
+          abase[i] = ok ? xrow[i] + (hi * p.W + wi) * p.ldx : p.zero;
+          astep[i] = ok ? 1 : 0;
+        }
+      }
+      unsigned char* sA = dsm + stage * STAGE_BYTES + pw * (8 * 1024);
+      unsigned char* sB = dsm + stage * STAGE_BYTES + A_BYTES + pw * (4 * 1024);
+      if (p.cin_valid == p.cin_pad) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase[i] + c0 * astep[i]), (lds_void_t*)(sA + i * 1024), 16, 0, 0);
+      } else {   // ragged last channel chunk of a tap: lanes past cin_valid fetch the zero page
+        const int rem = p.cin_valid - c0;
+        const bool ok_even = chunk_even * 4 < rem, ok_odd = chunk_odd * 4 < rem;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const float* src = ((i & 1) ? ok_odd : ok_even) ? abase[i] + c0 * astep[i] : p.zero;
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sA + i * 1024), 16, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wrow[j] + 2 * kofs * wstep[j]), (lds_void_t*)(sB + j * 1024), 16, 0,
+                                         0);
+      kofs += 32;
+      c0 += 32;
+      if (c0 == p.cin_pad) {
+        c0 = 0;
+        if (++kw == p.KW) {
+          kw = 0;
+          ++kh;
+        }
+      }
+    };
+    issue_tile(0);
+    if (KT > 1) {
+      issue_tile(1);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // tile 0 has landed
+    int st2 = 2;                   // ring slot of tile kt + 2
+#ifdef ZS3_CONV_TIMING
+    long t_issue = 0, t_wait = 0, t_bar = 0;
+#define ZS3_T(v) { long t_ = __builtin_readcyclecounter(); v += t_ - t_last; t_last = t_; }
+    long t_last = __builtin_readcyclecounter();
+#else
+#define ZS3_T(v)
+#endif
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + 2 < KT) {
+        issue_tile(st2);
+        st2 = st2 == NST - 1 ? 0 : st2 + 1;
+        ZS3_T(t_issue)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // tile kt+1 has landed, tile kt+2 stays in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      ZS3_T(t_wait)
+      __builtin_amdgcn_s_barrier();
+      ZS3_T(t_bar)
+    }
+#ifdef ZS3_CONV_TIMING
+    if (p.act == 99 && blockIdx.x == 0 && lane == 0) {
+      long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + wave * 3;
+      o[0] = t_issue; o[1] = t_wait; o[2] = t_bar;
+    }
+#endif
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, sw = (lr >> 1) & 7, jh = lane >> 5;
+    int offA0[2], offA1[2], offBh[2], offBl[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int j4 = jh + 2 * kk;              // which 8-wide K group of the 32-chunk this lane's fragment holds
+      offA0[kk] = ((2 * j4) ^ sw) * 16;        // fp32 chunks 2*j4, 2*j4+1
+      offA1[kk] = ((2 * j4 + 1) ^ sw) * 16;
+      offBh[kk] = (j4 ^ sw) * 16;              // bf16 hi chunk j4, lo chunk 4 + j4
+      offBl[kk] = ((4 + j4) ^ sw) * 16;
+    }
+    const int rowA = (wm * 64 + lr) * 128, rowB = A_BYTES + lr * 128;
+    // One K step = 4 sub-steps (kk, i) of 12 MFMAs each (3 bf16 products x 4 column tiles; the three updates of one
+    // accumulator are 4 MFMAs apart).  The slots between the MFMAs of sub-step s carry the LDS reads of the next raw
+    // fp32 fragment / the next B fragments and the hi/lo split for sub-step s+1 (3 VALU per slot), so the conversion
+    // work sits in the shadow of the 32-cycle MFMAs.  The K-step barrier sits before sub-step 3, which works from
+    // registers only and meanwhile prefetches sub-step 0 of the next tile from the next ring slot.  hipcc's own
+    // schedule hoists all LDS reads and conversions to the top and issues the 48 MFMAs as one clump (no overlap),
+    // so every slot is pinned with sched_barrier(0).
+    bf16x8 b_hi[2][TN], b_lo[2][TN];
+    u32x4 uh[2], ul[2];
+    f32x4 r0, r1;
+    float ha = 0.f, hb = 0.f;
+    const unsigned char* Ab;
+    const unsigned char* Bb;
+    auto set_stage = [&](int stage) {
+      Ab = dsm + stage * STAGE_BYTES + rowA;
+      Bb = dsm + stage * STAGE_BYTES + rowB;
+    };
+    auto read_a = [&](int kk, int i) {
+      r0 = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offA0[kk]);
+      r1 = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offA1[kk]);
+    };
+    auto read_b = [&](int kk, int j) {
+      b_hi[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBh[kk]);
+      if (PREC == 3) b_lo[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBl[kk]);
+    };
+    auto split_half = [&](int buf, int hp) {   // hp = 2*q + phase: values 2q, 2q+1 of the 8-wide fragment
+      const int q = hp >> 1;
+      const float a = q == 0 ? r0[0] : q == 1 ? r0[2] : q == 2 ? r1[0] : r1[2];
+      const float b = q == 0 ? r0[1] : q == 1 ? r0[3] : q == 2 ? r1[1] : r1[3];
+      if ((hp & 1) == 0) {
+        const unsigned h = cvt_pk_bf16(a, b);
+        uh[buf][q] = h;
+        ha = __uint_as_float(h << 16);
+        hb = __uint_as_float(h & 0xFFFF0000u);
+      } else {
+        ul[buf][q] = PREC == 3 ? cvt_pk_bf16(a - ha, b - hb) : 0u;
+      }
+    };
+    // sub-step s4 of the tile in the current ring slot; fillers prepare sub-step s4+1 (s4 == 3: sub-step 0 of the
+    // tile in the slot set_stage() was last pointed at)
+    auto substep = [&](int s4) {
+      const int kk = s4 >> 1, i = s4 & 1, buf = s4 & 1;
+      const int nkk = ((s4 + 1) & 3) >> 1, ni = (s4 + 1) & 1;
+      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, uh[buf]);
+      const bf16x8 a_lo = __builtin_bit_cast(bf16x8, ul[buf]);
+      if (PREC == 3) {
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          const int t = g >> 2, j = g & 3;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? a_lo : a_hi, t == 1 ? b_lo[kk][j] : b_hi[kk][j],
+                                                              acc[i][j], 0, 0, 0);
+          if (g == 0) read_a(nkk, ni);
+          if ((s4 == 0 || s4 == 3) && g >= 1 && g <= 4) read_b(s4 == 0 ? 1 : 0, g - 1);   // B of the next kk
+          if (g >= 4) split_half(buf ^ 1, g - 4);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[kk][j], acc[i][j], 0, 0, 0);
+          if (j == 0) read_a(nkk, ni);
+          if (s4 == 0 || s4 == 3) read_b(s4 == 0 ? 1 : 0, j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int hp = 0; hp < 8; ++hp) split_half(buf ^ 1, hp);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    __builtin_amdgcn_s_barrier();  // tile 0 has landed
+    asm volatile("" ::: "memory");
+    int st = 0;
+    set_stage(0);
+    read_a(0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) read_b(0, j);
+#pragma unroll
+    for (int hp = 0; hp < 8; ++hp) split_half(0, hp);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef ZS3_CONV_TIMING
+    long t_work = 0, t_bar = 0;
+    long t_last = __builtin_readcyclecounter();
+#endif
+    for (int kt = 0; kt < KT; ++kt) {
+      substep(0);
+      substep(1);
+      substep(2);
+      st = st == NST - 1 ? 0 : st + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ZS3_T(t_work)
+      __builtin_amdgcn_s_barrier();  // tile kt+1 has landed; nobody reads tile kt from LDS any more
+      asm volatile("" ::: "memory");
+      ZS3_T(t_bar)
+      set_stage(st);
+      substep(3);                    // after the last tile this prefetches stale (unused) data
+    }
+#ifdef ZS3_CONV_TIMING
+    if (p.act == 99 && blockIdx.x == 0 && lane == 0) {
+      long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + wave * 3;
+      o[0] = t_work; o[1] = 0; o[2] = t_bar;
+    }
+#endif
+  }
+
+  // ---- epilogue (consumers hold the accumulators; every DMA has landed and been consumed)
+  if (p.stat_partial) {
+    float* red = reinterpret_cast<float*>(dsm);
+    if (!producer) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r];
+            s += v;
+            q2 = fmaf(v, v, q2);
+          }
+        s += __shfl_xor(s, 32, 64);
+        q2 += __shfl_xor(q2, 32, 64);
+        if (lane < 32) {
+          red[(wm * 2 + 0) * BN + j * 32 + lane] = s;
+          red[(wm * 2 + 1) * BN + j * 32 + lane] = q2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      int col = n0 + tid;
+      if (col < p.ncols) {
+        p.stat_partial[((size_t)mt * 2 + 0) * p.ncols + col] =
+            (red[tid] + red[2 * BN + tid]) + (red[4 * BN + tid] + red[6 * BN + tid]);
+        p.stat_partial[((size_t)mt * 2 + 1) * p.ncols + col] =
+            (red[BN + tid] + red[3 * BN + tid]) + (red[5 * BN + tid] + red[7 * BN + tid]);
+      }
+    }
+  }
+  constexpr int LDC = BN + 4;
+  static_assert((BM / 2) * LDC * 4 <= NST * STAGE_BYTES, "half output tile must fit in the operand LDS");
+  float* ctile = reinterpret_cast<float*>(dsm);
+  const bool affine = (p.scale != nullptr) || (p.shift != nullptr);
+  constexpr int C4 = BN / 4, RPP = 512 / C4;
+  const int c4 = tid % C4, r0 = tid / C4;
+  const int col = n0 + c4 * 4;
+  const bool vec = ((p.ldy & 3) == 0) && ((p.ncols & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (col + e < p.ncols) {
+      if (p.scale) sc[e] = p.scale[col + e];
+      if (p.shift) sh[e] = p.shift[col + e];
+    }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (!producer && (wm >> 1) == half) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (wm & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ctile[row * LDC + j * 32 + (lane & 31)] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    for (int rr = r0; rr < BM / 2; rr += RPP) {
+      const int row = m0 + half * (BM / 2) + rr;
+      if (row >= p.M || col >= p.ncols) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * LDC + c4 * 4);
+      if (affine) v = v * sc + sh;
+      float* dst = p.y + (size_t)row * p.ldy + col;
+      if (vec) {
+        if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
+        }
+        if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < p.ncols) {
+            float t = v[e];
+            if (p.res) t += p.res[(size_t)row * p.ldr + col + e];
+            if (p.act == 1) t = fmaxf(t, 0.f);
+            else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
+            if (p.accumulate) t += dst[e];
+            dst[e] = t;
+          }
+      }
+    }
+  }
+}
+
+template <int PREC>
+int launch_dma_prec(const ConvArgs& a, hipStream_t st) {
+  constexpr int LDS_BYTES = 3 * (256 + 128) * 128;   // 144 KB of the CU's 160 KB
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<PREC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return -4;
+    configured = true;
+  }
+  int mt = (a.M + 255) / 256, nt = (a.ncols + 127) / 128;
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<PREC>), dim3(mt * nt), dim3(512), LDS_BYTES, st, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
+  return prec == 1 ? launch_dma_prec<1>(a, st) : launch_dma_prec<3>(a, st);
+}
+
 int launch_ws(const ConvArgs& a, int prec, hipStream_t st) {
   int mt = (a.M + 255) / 256, nt = (a.ncols + 127) / 128;
   dim3 grid(mt * nt), block(512);
@@ -684,7 +1083,7 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
     if (blocks < 512) bm = 64;
   } else {
     int t = tile_cfg % 10;
-    bm = tile_cfg == 21 ? 256 : ((t == 3 || t == 4) ? 64 : 128);
+    bm = (tile_cfg == 21 || tile_cfg == 31) ? 256 : ((t == 3 || t == 4) ? 64 : 128);
   }
   return (M + bm - 1) / bm;
 }
@@ -727,6 +1126,7 @@ extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const 
     case 13: return launch_cfg<64, 128, 2>(a, prec, st);
     case 14: return launch_cfg<64, 64, 2>(a, prec, st);
     case 21: return launch_ws(a, prec, st);
+    case 31: return launch_dma(a, prec, st);
   }
   return -3;
 }

@@ -16,14 +16,16 @@ PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event
 
 
 def pick_tile(m, ncols, k=0):
-    """Block-tile choice for the implicit-GEMM kernel (1: 128x128, 2: 128x64, 3: 64x128, 4: 64x64)."""
-    # measured on MI355X over the 28 layer shapes of the network (tools/probe/conv_bench.py): the 128x128 tile wins when
-    # the launch has >= ~1000 of them (>= 2 resident per CU for several rounds), otherwise the 64x64 tile (4 blocks
-    # per CU, 16 waves) hides latency better.  +10 = two-deep register prefetch (2-3 % faster everywhere).
+    """Tile / kernel choice for the implicit-GEMM conv (zs3_conv_igemm tile_cfg): 1x = register-staged 4-wave kernel
+    (11: 128x128, 14: 64x64 block tile), 31 = wave-specialised 256x128 kernel fed by LDS-DMA."""
+    # measured on MI355X over the 28 layer shapes of the network, forward and dgrad (tools/probe/conv_bench.py).
+    # The LDS-DMA kernel wins wherever there is enough K per tile to amortise its 3-stage ring (K >= 512) and at least
+    # two 128-wide column tiles (or a 3x3-sized K); short-K / narrow layers keep the small-tile kernels: 128x128 when
+    # the launch has >= ~1000 tiles (>= 2 resident per CU for several rounds), else 64x64 (4 blocks per CU).
     if ncols <= 64:
         return 14
-    if k >= 1152 and m >= 8192:
-        return 21   # wave-specialised 256x128 tile: wins on the K-heavy layers (3x3 and 2048-channel convs)
+    if m >= 8192 and k >= 512 and (ncols >= 256 or k >= 1152):
+        return 31
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
 
 
