@@ -199,10 +199,10 @@ def pmc_traffic(tag):
     if not os.path.exists(path):
         return None, None
     import re
-    m = re.match(r"conv_igemm(_ws)?<(\d+),(\d+),(\d)(?:,pipe(\d))?>", tag)
+    m = re.match(r"conv_igemm(_ws|_dma)?<(\d+),(\d+),(\d)(?:,pipe(\d))?>", tag)
     if not m:
         return None, None
-    name = f"conv_igemm_ws_kernel<{m.group(4)}>" if m.group(1) else f"conv_igemm_kernel<{m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>"
+    name = f"conv_igemm{m.group(1)}_kernel<{m.group(4)}>" if m.group(1) else f"conv_igemm_kernel<{m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>"
     k = json.load(open(path))["kernels"].get(name)
     if not k:
         return None, None

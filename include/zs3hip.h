@@ -48,10 +48,11 @@ int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
 /* ---- weight gradient ------------------------------------------------------------------------- */
 /* dw[co][kh][kw][ci] = sum_m dy[m][co] * x[gather(m,kh,kw)][ci]  (channels_last weight layout).
  * dy: [M][lddy] with co_read (multiple of 4) readable channels of which co_write rows are produced;
- * x likewise (ci_read / ci_write).  Split-K over pixels: call zs3_conv_wgrad_plan for the workspace
- * size (floats), pass NULL when it returns 0.  Replaces convolution_backward(weight) of the same
+ * x likewise (ci_read / ci_write).  Split-K over pixels: call zs3_conv_wgrad_plan (same M = N*Ho*Wo, Wo, channel
+ * counts and tap count as the launch; it also fixes the kernel choice) for the workspace size (floats), pass NULL
+ * when it returns 0.  Replaces convolution_backward(weight) of the same
  * call sites as zs3_conv_igemm. */
-int zs3_conv_wgrad_plan(int M, int co, int ci, int taps, int* splitk_out, long* workspace_floats);
+int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats);
 int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int Ho, int Wo,
                    int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read, int co_write, int ci_read,
                    int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream);

@@ -35,7 +35,7 @@ def test_host_side_planners_need_no_gpu(libpath):
     assert lib.zs3_conv_igemm_mtiles(266256, 256, 1) == (266256 + 127) // 128
     assert lib.zs3_conv_igemm_mtiles(100, 256, 4) == 2
     sk, ws = ctypes.c_int(0), ctypes.c_long(0)
-    assert lib.zs3_conv_wgrad_plan(266256, 256, 256, 9, ctypes.byref(sk), ctypes.byref(ws)) == 0
+    assert lib.zs3_conv_wgrad_plan(266256, 129, 256, 256, 9, ctypes.byref(sk), ctypes.byref(ws)) == 0
     assert sk.value >= 1 and (ws.value == 0 or ws.value == sk.value * 256 * 9 * 256)
     ch, rpb = ctypes.c_int(0), ctypes.c_int(0)
     lib.zs3_colstats_plan(1000, 64, ctypes.byref(ch), ctypes.byref(rpb))

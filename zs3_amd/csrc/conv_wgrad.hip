@@ -234,6 +234,224 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant for layers with >= 256 channels on both sides (kernel 2 of zs3_conv_wgrad).
+//
+// Block = 256(co) x 256(ci) outputs of one filter tap and one pixel chunk; 8 waves (2 per SIMD) with 128(co) x
+// 64(ci) wave tiles.  Per K step (16 pixels) the block needs 16 dy rows and 16 gathered x rows: one
+// global_load_lds_dwordx4 per pixel row (64 lanes x 16 B = the 256 fp32 channels of that pixel) moves them straight
+// into a 4-slot LDS ring (32 KB per slot), three tiles ahead of the multiply, waiting only on a counted vmcnt;
+// each wave issues 2 + 2 rows.  LDS therefore holds raw fp32 [pixel][channel]; the transpose the MFMA wants (8
+// consecutive pixels of one channel per lane) is done with ds_read_b32 (lanes = consecutive channels:
+// conflict-free) and the bf16 hi/lo split happens in registers.  24 MFMAs per K step and wave; the LDS reads,
+// conversion VALU ops and DMA issues that prepare the following fragments / tiles are pinned into the slots between
+// them (6 VALU per MFMA -- more than one wave can hide, which is what the second wave on the SIMD is for).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int PREC>
+__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradArgs p) {
+  constexpr int BC = 256, BD = 256, KPIX = 16;
+  constexpr int PART = KPIX * 1024, STAGE_BYTES = 2 * PART;   // dy rows then x rows, 1 KB (256 fp32) per pixel
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_ci = (p.ci_write + BD - 1) / BD, tiles_co = (p.co_write + BC - 1) / BC;
+  const int ntiles = tiles_ci * tiles_co * p.KH * p.KW;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = b / ntiles;
+  b -= split * ntiles;
+  const int tci = b % tiles_ci; b /= tiles_ci;
+  const int tco = b % tiles_co; b /= tiles_co;
+  const int tap = b;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int co0 = tco * BC, ci0 = tci * BD;
+  const int m_begin = split * p.chunk;
+  const int m_end = min(p.M, m_begin + p.chunk);
+  const int KT = (m_end - m_begin + KPIX - 1) / KPIX;
+
+  // ---- loader state: this wave fetches rows 2 wave, 2 wave + 1 of both parts of every tile
+  const bool a_cok = co0 + lane * 4 < p.co_read;   // this lane's 4 channels exist
+  const bool b_cok = ci0 + lane * 4 < p.ci_read;
+  const int tap_h = kh * p.dil - p.pad_h, tap_w = kw * p.dil - p.pad_w;
+  int pm[2], pn[2], poh[2], pow_[2];   // wave-uniform pixel slots, advanced by 16 pixels per tile without divisions
+  {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int m = m_begin + 2 * wave + r;
+      pm[r] = m;
+      int mm = m < p.M ? m : 0;
+      pn[r] = mm / hw;
+      int rem = mm - pn[r] * hw;
+      poh[r] = rem / p.Wo;
+      pow_[r] = rem - poh[r] * p.Wo;
+    }
+  }
+  // branch-free (the K loop must stay one basic block for the pinned schedule): wave-uniform row bases, per-lane
+  // select against the zero page, and single-wrap carries (the launcher guarantees Wo >= KPIX)
+  const unsigned long zaddr = (unsigned long)p.zero;
+  const unsigned lane16 = lane * 16;
+  const long lane_a = a_cok ? -1L : 0L, lane_b = b_cok ? -1L : 0L;
+  auto issue_row = [&](int slot, int r) {   // masks instead of conditions: hipcc turns wave-uniform conditions into branches
+    unsigned char* sA = dsm + slot * STAGE_BYTES + wave * 2048 + r * 1024;
+    const int in = (pm[r] - m_end) >> 31;   // all ones while the pixel is inside this split's chunk
+    const unsigned long ga = (unsigned long)(p.dy + (size_t)pm[r] * p.lddy + co0) + lane16;
+    const unsigned long pa = zaddr + ((ga - zaddr) & (unsigned long)((long)in & lane_a));
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)pa, (lds_void_t*)sA, 16, 0, 0);
+    const int hi = poh[r] * p.stride + tap_h, wi = pow_[r] * p.stride + tap_w;
+    const int rok = in & ~((hi | wi) >> 31) & ((hi - p.H) >> 31) & ((wi - p.W) >> 31);
+    const int hic = hi & rok, wic = wi & rok;
+    const unsigned long gb = (unsigned long)(p.x + (((size_t)pn[r] * p.H + hic) * p.W + wic) * p.ldx + ci0) + lane16;
+    const unsigned long pb = zaddr + ((gb - zaddr) & (unsigned long)((long)rok & lane_b));
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)pb, (lds_void_t*)(sA + PART), 16, 0, 0);
+    pm[r] += KPIX;
+    pow_[r] += KPIX;
+    const int cw = (p.Wo - 1 - pow_[r]) >> 31;   // all ones when the column wrapped (Wo >= KPIX: at most once)
+    pow_[r] -= p.Wo & cw;
+    poh[r] -= cw;
+    const int ch = (p.Ho - 1 - poh[r]) >> 31;
+    poh[r] -= p.Ho & ch;
+    pn[r] -= ch;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wco = wave >> 2, wci = wave & 3;
+  const int c = lane & 31, h = lane >> 5;
+  // byte offset of this lane's first value inside a slot: pixel row 8h, channel (wave base + c)
+  const int offA = (8 * h) * 1024 + (128 * wco + c) * 4;
+  const int offB = PART + (8 * h) * 1024 + (64 * wci + c) * 4;
+  u32x4 a_hi[2], a_lo[2], b_hi[2][2], b_lo[2][2];
+  float raw1[8], raw2[8];
+  float t_ha = 0.f, t_hb = 0.f;
+  auto read_frag = [&](float (&raw)[8], const unsigned char* base) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) raw[e] = *reinterpret_cast<const float*>(base + e * 1024);
+  };
+  auto split_half = [&](const float (&raw)[8], u32x4& hi, u32x4& lo, int hp) {   // hp = 2*q + phase
+    const int q = hp >> 1;
+    if ((hp & 1) == 0) {
+      const unsigned hw = cvt_pk_bf16(raw[2 * q], raw[2 * q + 1]);
+      hi[q] = hw;
+      t_ha = __uint_as_float(hw << 16);
+      t_hb = __uint_as_float(hw & 0xFFFF0000u);
+    } else {
+      lo[q] = PREC == 3 ? cvt_pk_bf16(raw[2 * q] - t_ha, raw[2 * q + 1] - t_hb) : 0u;
+    }
+  };
+
+  // tiles 0..2 in flight (4 loads per tile and wave); tiles 0 and 1 must have landed before the first K step
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) issue_row(t, r);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {   // prologue: A fragment 0 and the two B fragments of tile 0
+    read_frag(raw1, dsm + offA);
+#pragma unroll
+    for (int hp = 0; hp < 8; ++hp) split_half(raw1, a_hi[0], a_lo[0], hp);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      read_frag(raw2, dsm + offB + j * 128);
+#pragma unroll
+      for (int hp = 0; hp < 8; ++hp) split_half(raw2, b_hi[0][j], b_lo[0][j], hp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // kstep: 4 groups of 6 MFMAs (A fragment i against the 2 B fragments of the current tile).  The slots in between
+  // read and split A fragment i+1 (i == 3: fragment 0 of the next tile) and half of a B fragment of the next tile
+  // (groups 0,1: fragment 0; groups 2,3: fragment 1), and issue this wave's rows of the tile three steps ahead.
+  auto kstep = [&](const unsigned char* cur, const unsigned char* nxt, int bcur, int slot3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int abuf = i & 1, bj = i >> 1, bhalf = i & 1;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, a_hi[abuf]);
+      const bf16x8 al = __builtin_bit_cast(bf16x8, a_lo[abuf]);
+#pragma unroll
+      for (int g = (PREC == 3 ? 0 : 4); g < 6; ++g) {
+        const int t = g >> 1, j = g & 1;
+        const bf16x8 bb = __builtin_bit_cast(bf16x8, t == 1 ? b_lo[bcur][j] : b_hi[bcur][j]);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? al : ah, bb, acc[i][j], 0, 0, 0);
+        const int f = PREC == 3 ? g : g - 4;   // filler slot index (PREC 1 has only two MFMAs per group)
+        if (f == 0) {
+          read_frag(raw1, (i < 3 ? cur + (i + 1) * 128 : nxt) + offA);
+          if (bhalf == 0) read_frag(raw2, nxt + offB + bj * 128);
+          if (i < 2) issue_row(slot3, i);   // past the last tile these are zero-page loads into a free slot
+        }
+        if (PREC == 3) {
+          if (g >= 2) {   // A pairs 0..3 in slots 2..5
+            split_half(raw1, a_hi[abuf ^ 1], a_lo[abuf ^ 1], 2 * (g - 2));
+            split_half(raw1, a_hi[abuf ^ 1], a_lo[abuf ^ 1], 2 * (g - 2) + 1);
+          }
+          if (g >= 4) {   // two of the four B pairs per group, in slots 4,5
+            const int q = 2 * bhalf + (g - 4);
+            split_half(raw2, b_hi[bcur ^ 1][bj], b_lo[bcur ^ 1][bj], 2 * q);
+            split_half(raw2, b_hi[bcur ^ 1][bj], b_lo[bcur ^ 1][bj], 2 * q + 1);
+          }
+        } else if (f == 1) {
+#pragma unroll
+          for (int hp = 0; hp < 8; ++hp) split_half(raw1, a_hi[abuf ^ 1], a_lo[abuf ^ 1], hp);
+#pragma unroll
+          for (int q = 2 * bhalf; q < 2 * bhalf + 2; ++q) {
+            split_half(raw2, b_hi[bcur ^ 1][bj], b_lo[bcur ^ 1][bj], 2 * q);
+            split_half(raw2, b_hi[bcur ^ 1][bj], b_lo[bcur ^ 1][bj], 2 * q + 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // tile kt+2 must have landed before anybody starts step kt+1 (which reads it); tile kt+3 may stay in flight
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  int st = 0;
+  for (int kt = 0; kt < KT; kt += 2) {   // two K steps per trip: the B double-buffer index stays a compile-time constant
+    const int st1 = (st + 1) & 3, st2 = (st + 2) & 3, st3 = (st + 3) & 3;
+    kstep(dsm + st * STAGE_BYTES, dsm + st1 * STAGE_BYTES, 0, st3);
+    if (kt + 1 < KT) kstep(dsm + st1 * STAGE_BYTES, dsm + st2 * STAGE_BYTES, 1, st);
+    st = st2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (masked) row loads must land before the LDS is released
+
+  float* out = p.dw + (size_t)split * p.slab;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + wci * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.co_write && ci < p.ci_write) out[(size_t)co * p.ldw + (size_t)tap * p.cin_w + ci] = acc[i][j][r];
+      }
+    }
+}
+
+template <int PREC>
+int launch_wgrad_dma_prec(const WgradArgs& a, int taps, int splitk, hipStream_t st) {
+  constexpr int LDS_BYTES = 4 * 2 * 16 * 1024;   // 128 KB ring
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_dma_kernel<PREC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+      return -4;
+    configured = true;
+  }
+  int tiles = ((a.co_write + 255) / 256) * ((a.ci_write + 255) / 256) * taps;
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<PREC>), dim3(tiles * splitk), dim3(512), LDS_BYTES, st, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int splitk, long slab) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -268,16 +486,57 @@ int pick_splitk(int M, int tiles) {
 
 // 128-wide tiles whenever there are more than 64 channels (measured: a half-empty 128 tile still beats 64-wide tiles)
 static int pick_tile_dim(int c) { return c > 64 ? 128 : 64; }
+static int env_int(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
 static int tile_override() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("ZS3_WGRAD_TILE"); v = e ? atoi(e) : 0; }
+  if (v < 0) v = env_int("ZS3_WGRAD_TILE");
   return v;
 }
-extern "C" int zs3_conv_wgrad_plan(int M, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
-  int bc = pick_tile_dim(co), bd = pick_tile_dim(ci);
-  if (tile_override() == 64) { bc = 64; bd = 64; }
-  int tiles = ((co + bc - 1) / bc) * ((ci + bd - 1) / bd) * taps;
-  int s = pick_splitk(M, tiles);
+// kernel 2 (LDS-DMA, 256x256 tiles) when both channel counts fill 256-wide tiles; ZS3_WGRAD_KERNEL=1|2 forces one (debug)
+static bool use_dma_kernel(int co, int ci, int wo = 1 << 30) {
+  static int v = -1;
+  if (v < 0) v = env_int("ZS3_WGRAD_KERNEL");
+  if (v == 1) return false;
+  if (v == 2) return true;
+  return co >= 256 && ci >= 256 && co % 256 == 0 && ci % 256 == 0 && wo >= 16;
+}
+static int pick_splitk_dma(int M, int tiles, long out_elems) {
+  // One 512-thread block per CU, 256 CUs.  Cost model in units of one K step (16 pixels, ~1.5 us): rounds x (K steps
+  // per block + ~12 for prologue and the 256 KB tile store) + the [Cout][K] slab each split writes and the reduction
+  // reads back (~4 TB/s).  A 257th block costs a whole extra round, so the block count matters more than the split.
+  int maxs = M / 256;   // at least 16 K-steps (256 pixels) per split
+  if (maxs < 1) maxs = 1;
+  if (maxs > 128) maxs = 128;
+  static int forced = -1;
+  if (forced < 0) forced = env_int("ZS3_WGRAD_SPLIT");   // debug knob
+  if (forced > 0) return forced < maxs ? forced : maxs;
+  const double slab_units = (double)out_elems * 4.0 * 2.0 / 4e12 / 1.5e-6;
+  const long ksteps = (M + 15) / 16;
+  int best = 1;
+  double best_t = 1e30;
+  for (int s = 1; s <= maxs; ++s) {
+    const long n = (long)tiles * s;
+    const double t = (double)((n + 255) / 256) * ((double)((ksteps + s - 1) / s) + 12.0) + (s > 1 ? s * slab_units : 0.0);
+    if (t < best_t) {
+      best_t = t;
+      best = s;
+    }
+  }
+  return best;
+}
+extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
+  int s;
+  if (use_dma_kernel(co, ci, Wo)) {
+    s = pick_splitk_dma(M, ((co + 255) / 256) * ((ci + 255) / 256) * taps, (long)co * ci * taps);
+  } else {
+    int bc = pick_tile_dim(co), bd = pick_tile_dim(ci);
+    if (tile_override() == 64) { bc = 64; bd = 64; }
+    int tiles = ((co + bc - 1) / bc) * ((ci + bd - 1) / bd) * taps;
+    s = pick_splitk(M, tiles);
+  }
   *splitk_out = s;
   *workspace_floats = s > 1 ? (long)s * co * taps * ci : 0;
   return 0;
@@ -299,7 +558,8 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
   const int taps = KH * KW;
   int splitk;
   long ws;
-  zs3_conv_wgrad_plan(a.M, co_write, ci_write, taps, &splitk, &ws);
+  zs3_conv_wgrad_plan(a.M, Wo, co_write, ci_write, taps, &splitk, &ws);
+  const bool dma = use_dma_kernel(co_write, ci_write, Wo);
   if (splitk > 1 && workspace == nullptr) return -3;
   int chunks = (a.M + 31) / 32;
   a.chunk = ((chunks + splitk - 1) / splitk) * 32;
@@ -309,7 +569,9 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
   int bc = pick_tile_dim(co_write), bd = pick_tile_dim(ci_write);
   if (tile_override() == 64) { bc = 64; bd = 64; }
   int rc;
-  if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(a, taps, splitk, prec, st);
+  if (dma)
+    rc = prec == 1 ? launch_wgrad_dma_prec<1>(a, taps, splitk, st) : launch_wgrad_dma_prec<3>(a, taps, splitk, st);
+  else if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(a, taps, splitk, prec, st);
   else if (bc == 128) rc = launch_wgrad<128, 64>(a, taps, splitk, prec, st);
   else if (bd == 128) rc = launch_wgrad<64, 128>(a, taps, splitk, prec, st);
   else rc = launch_wgrad<64, 64>(a, taps, splitk, prec, st);

@@ -133,7 +133,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
                                I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), stream()), "zs3_conv_igemm")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append(("conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
+        PROFILE.append(("conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1))
     return out, stat
 
@@ -169,7 +169,7 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
     ci_read = ci_read or min(_round_up(cin, 4), ldx)
     dw = torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
     splitk, ws = ctypes.c_int(0), ctypes.c_long(0)
-    lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
+    lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
     work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
     check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
                                I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
