@@ -495,13 +495,17 @@ static int tile_override() {
   if (v < 0) v = env_int("ZS3_WGRAD_TILE");
   return v;
 }
-// kernel 2 (LDS-DMA, 256x256 tiles) when both channel counts fill 256-wide tiles; ZS3_WGRAD_KERNEL=1|2 forces one (debug)
-static bool use_dma_kernel(int co, int ci, int wo = 1 << 30) {
+// kernel 2 (LDS-DMA, 256x256 tiles) takes the leading multiple-of-256 input channels when Cout fills 256-wide tiles;
+// a remainder of <= 128 input channels (the 304-channel decoder concat) goes to kernel 1 in a second launch over the
+// same split-K slabs.  Returns the number of input channels given to kernel 2.  ZS3_WGRAD_KERNEL=1|2 forces one (debug).
+static int dma_width(int co, int ci, int wo) {
   static int v = -1;
   if (v < 0) v = env_int("ZS3_WGRAD_KERNEL");
-  if (v == 1) return false;
-  if (v == 2) return true;
-  return co >= 256 && ci >= 256 && co % 256 == 0 && ci % 256 == 0 && wo >= 16;
+  if (v == 1) return 0;
+  if (v == 2) return ci;
+  if (co < 256 || co % 256 || ci < 256 || wo < 16) return 0;
+  const int rem = ci % 256;
+  return rem <= 128 ? ci - rem : 0;
 }
 static int pick_splitk_dma(int M, int tiles, long out_elems) {
   // One 512-thread block per CU, 256 CUs.  Cost model in units of one K step (16 pixels, ~1.5 us): rounds x (K steps
@@ -529,8 +533,9 @@ static int pick_splitk_dma(int M, int tiles, long out_elems) {
 }
 extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
   int s;
-  if (use_dma_kernel(co, ci, Wo)) {
-    s = pick_splitk_dma(M, ((co + 255) / 256) * ((ci + 255) / 256) * taps, (long)co * ci * taps);
+  const int wd = dma_width(co, ci, Wo);
+  if (wd > 0) {
+    s = pick_splitk_dma(M, ((co + 255) / 256) * ((wd + 255) / 256) * taps, (long)co * ci * taps);
   } else {
     int bc = pick_tile_dim(co), bd = pick_tile_dim(ci);
     if (tile_override() == 64) { bc = 64; bd = 64; }
@@ -559,22 +564,34 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
   int splitk;
   long ws;
   zs3_conv_wgrad_plan(a.M, Wo, co_write, ci_write, taps, &splitk, &ws);
-  const bool dma = use_dma_kernel(co_write, ci_write, Wo);
+  const int wd = dma_width(co_write, ci_write, Wo);
   if (splitk > 1 && workspace == nullptr) return -3;
   int chunks = (a.M + 31) / 32;
   a.chunk = ((chunks + splitk - 1) / splitk) * 32;
   a.slab = (long)co_write * a.ldw;
   a.dw = splitk > 1 ? workspace : dw;
   hipStream_t st = (hipStream_t)stream;
-  int bc = pick_tile_dim(co_write), bd = pick_tile_dim(ci_write);
-  if (tile_override() == 64) { bc = 64; bd = 64; }
-  int rc;
-  if (dma)
-    rc = prec == 1 ? launch_wgrad_dma_prec<1>(a, taps, splitk, st) : launch_wgrad_dma_prec<3>(a, taps, splitk, st);
-  else if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(a, taps, splitk, prec, st);
-  else if (bc == 128) rc = launch_wgrad<128, 64>(a, taps, splitk, prec, st);
-  else if (bd == 128) rc = launch_wgrad<64, 128>(a, taps, splitk, prec, st);
-  else rc = launch_wgrad<64, 64>(a, taps, splitk, prec, st);
+  int rc = 0;
+  if (wd > 0) {   // leading wd input channels: LDS-DMA kernel
+    WgradArgs d = a;
+    d.ci_write = wd;
+    d.ci_read = ci_read < wd ? ci_read : wd;
+    rc = prec == 1 ? launch_wgrad_dma_prec<1>(d, taps, splitk, st) : launch_wgrad_dma_prec<3>(d, taps, splitk, st);
+    if (rc) return rc;
+  }
+  if (wd < ci_write) {   // remaining (or all) input channels: register-staged kernel, same slabs and pixel chunks
+    WgradArgs r = a;
+    r.x = a.x + wd;
+    r.dw = a.dw + wd;
+    r.ci_write = ci_write - wd;
+    r.ci_read = ci_read - wd;
+    int bc = pick_tile_dim(r.co_write), bd = pick_tile_dim(r.ci_write);
+    if (tile_override() == 64) { bc = 64; bd = 64; }
+    if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(r, taps, splitk, prec, st);
+    else if (bc == 128) rc = launch_wgrad<128, 64>(r, taps, splitk, prec, st);
+    else if (bd == 128) rc = launch_wgrad<64, 128>(r, taps, splitk, prec, st);
+    else rc = launch_wgrad<64, 64>(r, taps, splitk, prec, st);
+  }
   if (rc) return rc;
   if (splitk > 1) {
     long n = a.slab;
