@@ -510,14 +510,14 @@ static int dma_width(int co, int ci, int wo) {
 static int pick_splitk_dma(int M, int tiles, long out_elems) {
   // One 512-thread block per CU, 256 CUs.  Cost model in units of one K step (16 pixels, ~1.5 us): rounds x (K steps
   // per block + ~12 for prologue and the 256 KB tile store) + the [Cout][K] slab each split writes and the reduction
-  // reads back (~4 TB/s).  A 257th block costs a whole extra round, so the block count matters more than the split.
+  // reads back (priced at ~1 TB/s: in the training step this kernel shares HBM with the BN / dgrad stream; measured).  A 257th block costs a whole extra round, so the block count matters more than the split.
   int maxs = M / 256;   // at least 16 K-steps (256 pixels) per split
   if (maxs < 1) maxs = 1;
   if (maxs > 128) maxs = 128;
   static int forced = -1;
   if (forced < 0) forced = env_int("ZS3_WGRAD_SPLIT");   // debug knob
   if (forced > 0) return forced < maxs ? forced : maxs;
-  const double slab_units = (double)out_elems * 4.0 * 2.0 / 4e12 / 1.5e-6;
+  const double slab_units = (double)out_elems * 4.0 * 2.0 / 1e12 / 1.5e-6;
   const long ksteps = (M + 15) / 16;
   int best = 1;
   double best_t = 1e30;
