@@ -66,11 +66,13 @@ int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, void* st
 int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
                      const float* invstd, const float* mask_scale, const float* mask_shift, int M, int C, float* partial,
                      void* stream);
-/* count_dev (nullable): device-resident sample count that overrides `count` (cross-rank SyncBN: the count is
+/* num_batches_tracked (nullable): BatchNorm's int64 step counter, incremented by the kernel.
+   count_dev (nullable): device-resident sample count that overrides `count` (cross-rank SyncBN: the count is
    all-reduced together with the sums and never visits the host) */
 int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
-                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
-                        float* invstd_out, float* scale_out, float* shift_out, void* stream);
+                        const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
+                        long* num_batches_tracked, void* stream);
 int zs3_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, int C, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                        void* stream);

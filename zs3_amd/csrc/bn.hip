@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* parti
                                                              const double* count_dev, const float* gamma, const float* beta, float eps,
                                                              float momentum, float* running_mean, float* running_var,
                                                              float* mean_out, float* invstd_out, float* scale_out,
-                                                             float* shift_out) {
+                                                             float* shift_out, long* num_batches_tracked) {
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   double s, q;
@@ -341,10 +342,10 @@ extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, doub
                                    const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_out, float* invstd_out, float* scale_out,
-                                   float* shift_out, void* stream) {
+                                   float* shift_out, long* num_batches_tracked, void* stream) {
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
                      count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
-                     shift_out);
+                     shift_out, num_batches_tracked);
   return ZS3_LAUNCH_CHECK();
 }
 

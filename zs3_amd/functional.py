@@ -133,7 +133,7 @@ class _ConvBnAct(torch.autograd.Function):
                 from .parallel import combine_bn_partials
                 part, count = combine_bn_partials(part, count, None if bn["sync"] is True else bn["sync"])
             st = ops.bn_fwd_finalize(part, count, gamma, beta, bn["eps"], bn["momentum"], bn["running_mean"],
-                                     bn["running_var"])
+                                     bn["running_var"], bn.get("nbt"))
             a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak)
         elif bn is not None:
             st = ops.bn_eval_affine(gamma, beta, bn["running_mean"], bn["running_var"], bn["eps"])
@@ -269,11 +269,14 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
         gamma, beta = bn.weight, bn.bias
         use_batch = bn.training or bn.running_mean is None
         mom = bn.momentum
+        nbt = None
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-            if mom is None:
+            if mom is None:   # cumulative moving average needs the count on the host
+                bn.num_batches_tracked.add_(1)
                 mom = 1.0 / float(bn.num_batches_tracked)
-        cfg["bn"] = {"training": use_batch, "eps": bn.eps, "momentum": mom if mom is not None else 0.0,
+            else:
+                nbt = bn.num_batches_tracked   # incremented by the finalize kernel
+        cfg["bn"] = {"training": use_batch, "nbt": nbt, "eps": bn.eps, "momentum": mom if mom is not None else 0.0,
                      "sync": getattr(bn, "_zs3_sync_group", None),
                      "running_mean": bn.running_mean if (bn.training and bn.track_running_stats) or not use_batch else None,
                      "running_var": bn.running_var if (bn.training and bn.track_running_stats) or not use_batch else None}
@@ -292,7 +295,7 @@ class _BnAct(torch.autograd.Function):
             if m <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
             st = ops.bn_fwd_finalize(ops.colstats(y), m, gamma, beta, cfg["eps"], cfg["momentum"], cfg["running_mean"],
-                                     cfg["running_var"])
+                                     cfg["running_var"], cfg.get("nbt"))
         else:
             st = ops.bn_eval_affine(gamma, beta, cfg["running_mean"], cfg["running_var"], cfg["eps"])
         a = ops.affine_act(y, st[2], st[3], act=cfg["act"], out=cfg.get("out"))
@@ -316,12 +319,15 @@ class _BnAct(torch.autograd.Function):
 def bn_act(y, bn, act=ACT_NONE, out=None):
     use_batch = bn.training or bn.running_mean is None
     mom = bn.momentum
+    nbt = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
         if mom is None:
+            bn.num_batches_tracked.add_(1)
             mom = 1.0 / float(bn.num_batches_tracked)
+        else:
+            nbt = bn.num_batches_tracked
     track = bn.training and bn.track_running_stats
-    cfg = {"training": use_batch, "eps": bn.eps, "momentum": mom if mom is not None else 0.0, "act": act, "out": out,
+    cfg = {"training": use_batch, "nbt": nbt, "eps": bn.eps, "momentum": mom if mom is not None else 0.0, "act": act, "out": out,
            "running_mean": bn.running_mean if track or not use_batch else None,
            "running_var": bn.running_var if track or not use_batch else None}
     return _BnAct.apply(y, bn.weight, bn.bias, cfg)

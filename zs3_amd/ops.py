@@ -205,13 +205,13 @@ def _count_args(count):
     return ctypes.c_double(count), P(None)
 
 
-def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var):
+def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None):
     c = partial.shape[2]
     chost, cdev = _count_args(count)
     out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # mean, invstd, scale, shift
     check(lib().zs3_bn_fwd_finalize(P(partial), I(partial.shape[0]), I(c), chost, cdev, P(gamma), P(beta),
                                     F(eps), F(momentum), P(running_mean), P(running_var), P(out[0]), P(out[1]),
-                                    P(out[2]), P(out[3]), stream()), "zs3_bn_fwd_finalize")
+                                    P(out[2]), P(out[3]), P(num_batches_tracked), stream()), "zs3_bn_fwd_finalize")
     return out
 
 
@@ -251,12 +251,17 @@ def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None):
 
 
 def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True):
+    """-> (dgamma, dbeta, c1, c2).  dgamma / dbeta own their storage so that autograd can adopt them as .grad
+    without a copy."""
     c = partial.shape[2]
-    out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # dgamma, dbeta, c1, c2
+    dev = partial.device
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    cc = torch.empty((2, c), dtype=torch.float32, device=dev)
     chost, cdev = _count_args(count)
-    check(lib().zs3_bn_bwd_finalize(P(partial), I(partial.shape[0]), I(c), chost, cdev, P(out[0]), P(out[1]),
-                                    P(out[2]), P(out[3]), I(int(use_batch_stats)), stream()), "zs3_bn_bwd_finalize")
-    return out
+    check(lib().zs3_bn_bwd_finalize(P(partial), I(partial.shape[0]), I(c), chost, cdev, P(dgamma), P(dbeta),
+                                    P(cc[0]), P(cc[1]), I(int(use_batch_stats)), stream()), "zs3_bn_bwd_finalize")
+    return dgamma, dbeta, cc[0], cc[1]
 
 
 def bn_act_bwd(dA, a_out, y, mean, invstd, gamma, c1, c2, dy=None, dres=None, dres_accumulate=False, act=1, leak=0.2,

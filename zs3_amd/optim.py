@@ -8,6 +8,12 @@ from . import functional as Fz
 from ._lib import F, I, P, check, lib, stream
 
 
+def _same_layout(a, b):
+    """Same element order in memory: strides agree on every dimension of extent > 1 (the strides of extent-1 dimensions,
+    e.g. of a [Cout, Cin, 1, 1] weight, are arbitrary and differ between channels_last and contiguous tensors)."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 class SGD(torch.optim.SGD):
     """torch.optim.SGD semantics (momentum, dampening=0, weight_decay, nesterov), state-dict compatible
     (`momentum_buffer`).  All parameters of all groups that share momentum/nesterov are updated by ONE multi-tensor
@@ -32,7 +38,7 @@ class SGD(torch.optim.SGD):
                 g = p.grad
                 # parameters are dense in *some* permutation (channels_last conv weights): the update is elementwise,
                 # so p, grad and the buffer only need to share strides
-                if g.stride() != p.stride():
+                if not _same_layout(g, p):
                     g = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(g)
                     keep.append(g)
                 state = self.state[p]
@@ -78,7 +84,7 @@ class Adam(torch.optim.Adam):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                g = p.grad if p.grad.stride() == p.stride() else p.grad.contiguous()
+                g = p.grad if _same_layout(p.grad, p) else p.grad.contiguous()
                 check(lib().zs3_adam_step(P(p), P(g), P(state["exp_avg"]), P(state["exp_avg_sq"]), ctypes.c_long(p.numel()),
                                           F(group["lr"]), F(b1), F(b2), F(group["eps"]), F(group["weight_decay"]),
                                           I(int(state["step"])), P(getattr(self, "_step_dev", None)), stream()),
