@@ -728,8 +728,8 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
     int kh = 0, kw = 0, c0 = 0, kofs = 0;
     const float* abase[RA];
     int astep[RA];
-    auto issue_tile = [&](int stage) {
-      if (c0 == 0) {
+    auto tap_addresses = [&]() {   // per-row gather base of the current filter tap (called when a tap starts)
+      {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
           int hi, wi;
@@ -750,8 +750,36 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
           astep[i] = ok ? 1 : 0;
         }
       }
+    };
+    auto advance = [&]() {
+      kofs += 32;
+      c0 += 32;
+      if (c0 == p.cin_pad) {
+        c0 = 0;
+        if (++kw == p.KW) {
+          kw = 0;
+          ++kh;
+        }
+      }
+    };
+    // (A register-staged producer -- global_load_dwordx4 + ds_write_b128 of the same bytes -- was measured against this
+    // LDS-DMA form: 2700 vs 2100 producer cycles per K step; both sit on the ~35 B/clk/CU the L2 delivers.)
+    auto issue_tile = [&](int stage) {
+      if (c0 == 0) tap_addresses();
       unsigned char* sA = dsm + stage * STAGE_BYTES + pw * (8 * 1024);
       unsigned char* sB = dsm + stage * STAGE_BYTES + A_BYTES + pw * (4 * 1024);
+#ifdef ZS3_DMA_ZEROSRC   // probe: every lane re-reads the (L1-resident) zero page -> separates issue cost from L2 bandwidth
+      if (true) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.zero + (lane & 63) * 4), (lds_void_t*)(sA + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.zero + (lane & 63) * 4), (lds_void_t*)(sB + j * 1024), 16, 0, 0);
+        advance();
+        return;
+      }
+#endif
       if (p.cin_valid == p.cin_pad) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
@@ -769,15 +797,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       for (int j = 0; j < RB; ++j)
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(wrow[j] + 2 * kofs * wstep[j]), (lds_void_t*)(sB + j * 1024), 16, 0,
                                          0);
-      kofs += 32;
-      c0 += 32;
-      if (c0 == p.cin_pad) {
-        c0 = 0;
-        if (++kw == p.KW) {
-          kw = 0;
-          ++kh;
-        }
-      }
+      advance();
     };
     issue_tile(0);
     if (KT > 1) {
@@ -883,9 +903,14 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
           const int t = g >> 2, j = g & 3;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? a_lo : a_hi, t == 1 ? b_lo[kk][j] : b_hi[kk][j],
                                                               acc[i][j], 0, 0, 0);
-          if (g == 0) read_a(nkk, ni);
-          if ((s4 == 0 || s4 == 3) && g >= 1 && g <= 4) read_b(s4 == 0 ? 1 : 0, g - 1);   // B of the next kk
-          if (g >= 4) split_half(buf ^ 1, g - 4);
+#ifndef ZS3_DMA_ABLATE
+#define ZS3_DMA_ABLATE 0
+#endif
+          if (!(ZS3_DMA_ABLATE & 2)) {
+            if (g == 0) read_a(nkk, ni);
+            if ((s4 == 0 || s4 == 3) && g >= 1 && g <= 4) read_b(s4 == 0 ? 1 : 0, g - 1);   // B of the next kk
+          }
+          if (!(ZS3_DMA_ABLATE & 1) && g >= 4) split_half(buf ^ 1, g - 4);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
