@@ -27,6 +27,7 @@ struct ColArgs {
   const float* invstd;
   const float* mscale;  // MODE1, optional: ReLU mask recomputed as y*mscale + mshift > 0 (no residual) instead of reading `a`
   const float* mshift;
+  const unsigned char* mbits;  // MODE1, optional: ReLU mask as one byte per 4 channels (bit k = channel 4q+k was positive)
   float* partial;
   int M, C, ldx, lda, ldy, rows_per_block;
 };
@@ -63,7 +64,11 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
           q += v * v;
         } else {
           f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + (size_t)r * p.ldy + cq * 4);
-          if (p.a) {
+          if (p.mbits) {
+            const unsigned mb = p.mbits[(size_t)r * c4n + cq];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (mb >> k) & 1u ? v[k] : 0.f;
+          } else if (p.a) {
             f32x4 av = *reinterpret_cast<const f32x4*>(p.a + (size_t)r * p.lda + cq * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = av[k] > 0.f ? v[k] : 0.f;
@@ -181,6 +186,7 @@ struct AffArgs {
   const float* shift;
   const float* res;
   float* out;
+  unsigned char* mask;   // optional: sign of the pre-activation value, one byte per 4 channels (read back by the BN backward)
   long M;
   int C, ldx, ldr, ldo, div, act, accumulate;
   float alpha, leak;
@@ -197,6 +203,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const AffArgs p) {
     if (p.shift) v = v + *reinterpret_cast<const f32x4*>(p.shift + cq);
     v = v * p.alpha;
     if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + cq);
+    if (p.mask) p.mask[i] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
     if (p.act == 1) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -221,6 +228,7 @@ struct BnBwdArgs {
   const float* c2;
   const float* mscale;
   const float* mshift;
+  const unsigned char* mbits;
   float* dy;
   float* dres;
   long M;
@@ -236,7 +244,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
     f32x4 dz = *reinterpret_cast<const f32x4*>(p.dA + m * p.ldd + cq);
     f32x4 yv = {0.f, 0.f, 0.f, 0.f};
     if (p.y) yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
-    if (p.a) {
+    if (p.mbits) {
+      const unsigned mb = p.mbits[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dz[k] = (mb >> k) & 1u ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
+    } else if (p.a) {
       f32x4 av = *reinterpret_cast<const f32x4*>(p.a + m * p.lda + cq);
 #pragma unroll
       for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
@@ -326,11 +338,12 @@ extern "C" int zs3_colstats(const float* x, int ldx, int M, int C, float* partia
 
 extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
                                 const float* mean, const float* invstd, const float* mask_scale,
-                                const float* mask_shift, int M, int C, float* partial, void* stream) {
+                                const float* mask_shift, const unsigned char* mask_bits, int M, int C, float* partial,
+                                void* stream) {
   if (C % 4 || ldd % 4 || ldy % 4 || (a_out && lda % 4)) return -1;
   ColArgs a{};
   a.x = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.partial = partial;
-  a.mscale = mask_scale; a.mshift = mask_shift;
+  a.mscale = mask_scale; a.mshift = mask_shift; a.mbits = mask_bits;
   a.M = M; a.C = C; a.ldx = ldd; a.lda = lda; a.ldy = ldy;
   int chunks;
   zs3_colstats_plan(M, C, &chunks, &a.rows_per_block);
@@ -367,11 +380,11 @@ extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, doub
 
 extern "C" int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shift, float alpha,
                               const float* res, int ldr, float* out, int ldo, long M, int C, int div, int act,
-                              float leak, int accumulate, void* stream) {
+                              float leak, int accumulate, unsigned char* mask_out, void* stream) {
   if (C % 4 || ldx % 4 || ldo % 4 || (res && ldr % 4)) return -1;
   if (M <= 0) return 0;
   AffArgs a;
-  a.x = x; a.scale = scale; a.shift = shift; a.res = res; a.out = out; a.M = M; a.C = C; a.ldx = ldx; a.ldr = ldr;
+  a.x = x; a.scale = scale; a.shift = shift; a.res = res; a.out = out; a.mask = mask_out; a.M = M; a.C = C; a.ldx = ldx; a.ldr = ldr;
   a.ldo = ldo; a.div = div; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.leak = leak;
   hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
@@ -379,14 +392,14 @@ extern "C" int zs3_affine_act(const float* x, int ldx, const float* scale, const
 
 extern "C" int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
                               const float* mean, const float* invstd, const float* gamma, const float* c1,
-                              const float* c2, const float* mask_scale, const float* mask_shift, float* dy, int ldo,
-                              float* dres, int ldr, int dres_accumulate, long M, int C, int act, float leak,
-                              void* stream) {
+                              const float* c2, const float* mask_scale, const float* mask_shift,
+                              const unsigned char* mask_bits, float* dy, int ldo, float* dres, int ldr,
+                              int dres_accumulate, long M, int C, int act, float leak, void* stream) {
   if (C % 4 || ldd % 4 || (dy && ldo % 4) || (a_out && lda % 4) || (dres && ldr % 4)) return -1;
   if (M <= 0) return 0;
   BnBwdArgs a;
   a.dA = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.c1 = c1; a.c2 = c2;
-  a.mscale = mask_scale; a.mshift = mask_shift;
+  a.mscale = mask_scale; a.mshift = mask_shift; a.mbits = mask_bits;
   a.dy = dy; a.dres = dres; a.M = M; a.C = C; a.ldd = ldd; a.lda = lda; a.ldy = ldy; a.ldo = ldo; a.ldr = ldr;
   a.dres_accumulate = dres_accumulate; a.act = act; a.leak = leak;
   hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);

@@ -5,6 +5,7 @@ contiguous).  Each Function is one *fused layer* (conv + BatchNorm + residual + 
 training step is ~150 autograd nodes instead of ~700 ATen ops.  Nothing here falls back to torch
 compute: tensors must live on the GPU and libzs3hip.so must be present.
 """
+import os
 import random
 import weakref
 
@@ -101,6 +102,15 @@ def _dense_rows(t):
         return t.contiguous()
 
 
+def _mask_bits_for(y, act, residual, need_grad):
+    """Residual layers: the ReLU mask cannot be recomputed from y alone, and re-reading the output `a` twice in the backward
+    pass costs 8 bytes per element; affine_act writes the sign bits (1/16 of that) instead."""
+    if not need_grad or act == ACT_NONE or residual is None:
+        return None
+    m, c, _ = ops._rows(y)
+    return torch.empty(m * (c // 4), dtype=torch.uint8, device=y.device)
+
+
 # ---------------------------------------------------------------------------------- conv + BN + act
 class _ConvBnAct(torch.autograd.Function):
     """y = conv(x, w) ; a = act(bn(y) + bias + residual).  One node for the whole fused layer.
@@ -120,7 +130,7 @@ class _ConvBnAct(torch.autograd.Function):
         out = cfg.get("out")
         leak = cfg.get("leak", 0.2)
         prec = cfg.get("prec")
-        y = a = st = None
+        y = a = st = mbits = None
         conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, **k)) if geom is None else (
             lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, **geom, **k))
         if bn is not None and bn["training"]:
@@ -134,12 +144,14 @@ class _ConvBnAct(torch.autograd.Function):
                 part, count = combine_bn_partials(part, count, None if bn["sync"] is True else bn["sync"])
             st = ops.bn_fwd_finalize(part, count, gamma, beta, bn["eps"], bn["momentum"], bn["running_mean"],
                                      bn["running_var"], bn.get("nbt"))
-            a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak)
+            mbits = _mask_bits_for(y, act, residual, need_grad)
+            a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits)
         elif bn is not None:
             st = ops.bn_eval_affine(gamma, beta, bn["running_mean"], bn["running_var"], bn["eps"])
             if need_grad:
                 y, _ = conv()
-                a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak)
+                mbits = _mask_bits_for(y, act, residual, need_grad)
+                a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits)
             else:
                 a, _ = conv(scale=st[2], shift=st[3], res=residual, act=act, leak=leak, out=out)
         else:
@@ -152,8 +164,8 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.x_shape = tuple(x.shape)
         # ReLU mask in backward: recomputed from y (y*scale + shift > 0) when there is no residual, so `a` is not re-read
         ctx.mask_from_y = bool(bn is not None and y is not None and act == ACT_RELU and residual is None)
-        keep_a = act != ACT_NONE and not ctx.mask_from_y
-        ctx.save_for_backward(x, weight, gamma, y, a if keep_a else None, st)
+        keep_a = act != ACT_NONE and not ctx.mask_from_y and mbits is None
+        ctx.save_for_backward(x, weight, gamma, y, a if keep_a else None, st, mbits)
         ctx.pass_through = bool(cfg.get("pass_through"))
         if ctx.pass_through:
             return a, x.view(x.shape)   # the block input again, as the skip connection: its gradient comes back to us
@@ -161,7 +173,7 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dA, dskip=None):
-        x, weight, gamma, y, a, st = ctx.saved_tensors
+        x, weight, gamma, y, a, st, mbits = ctx.saved_tensors
         cfg = ctx.cfg
         msc, msh = (st[2], st[3]) if ctx.mask_from_y else (None, None)
         stride, pad, dil, act = cfg["stride"], cfg["pad"], cfg["dil"], cfg["act"]
@@ -174,7 +186,7 @@ class _ConvBnAct(torch.autograd.Function):
             dres = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
         m = dA.shape[0] * dA.shape[1] * dA.shape[2] if dA.dim() == 4 else dA.shape[0]
         if ctx.has_bn:
-            part = ops.bn_bwd_stats(dA, a, y, st[0], st[1], msc, msh)
+            part = ops.bn_bwd_stats(dA, a, y, st[0], st[1], msc, msh, mbits)
             sync = (cfg.get("bn") or {}).get("sync") if ctx.bn_training else None
             if sync is not None:
                 from .parallel import combine_bn_partials
@@ -187,7 +199,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dgamma, dbeta = fin[0], fin[1]
                 c1, c2 = (fin[2], fin[3]) if ctx.bn_training else (None, None)
             dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, dres=dres, act=act, leak=leak, mask_scale=msc,
-                                mask_shift=msh)
+                                mask_shift=msh, mask_bits=mbits)
         else:
             cout = dA.shape[-1]
             vec_ok = cout % 4 == 0 and ops._rows(dA)[2] % 4 == 0
