@@ -44,6 +44,17 @@ int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scal
                    int ncols, int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec,
                    int tile_cfg, const void* zero_page, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
+/* zs3_conv_igemm (no affine / activation) whose epilogue also produces the BatchNorm-backward sums of the layer
+ * the output gradient belongs to: bn_partial[mtiles][2][ncols] = (sum dz, sum dz*xhat) per row tile, with
+ * dz = stored value (after `res` / accumulate) * ReLU mask and xhat = (bn_y - bn_mean) * bn_invstd.  Mask: mask_bits
+ * ([M][ncols/4] sign bytes of zs3_affine_act), else bn_y*mask_scale + mask_shift > 0, else none.  Saves the separate
+ * zs3_bn_bwd_stats pass (one full read of the gradient) at resnet.py:33-53 / aspp.py / decoder.py backward. */
+int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const float* res, int N, int H, int W, int Ho,
+                           int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w,
+                           int dil, int ncols, int ldy, int ldr, int accumulate, int dgrad, int prec, int tile_cfg,
+                           const void* zero_page, const float* bn_y, int bn_ldy, const float* bn_mean,
+                           const float* bn_invstd, const float* mask_scale, const float* mask_shift,
+                           const unsigned char* mask_bits, float* bn_partial, void* stream);
 
 /* ---- weight gradient ------------------------------------------------------------------------- */
 /* dw[co][kh][kw][ci] = sum_m dy[m][co] * x[gather(m,kh,kw)][ci]  (channels_last weight layout).

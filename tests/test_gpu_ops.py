@@ -92,6 +92,40 @@ def test_conv_every_tile_config(dev, cfg):
         assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 5e-5, (cfg, ci, co)
 
 
+@pytest.mark.parametrize("cfg", [11, 14, 21, 31])
+@pytest.mark.parametrize("mask", ["none", "from_y", "bits"])
+def test_dgrad_epilogue_bn_backward_sums(dev, cfg, mask):
+    """zs3_conv_igemm_bnstats: the dgrad epilogue's (sum dz, sum dz*xhat) equal the separate zs3_bn_bwd_stats pass over the
+    gradient it stored -- with and without accumulation onto a skip gradient, for every mask source"""
+    from zs3_amd import ops
+    n, h, w, ci, co, k = 2, 33, 31, 128, 256, 3
+    g = torch.Generator().manual_seed(cfg + len(mask))
+    wt = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(dev)
+    wp = ops.prep_weight(wt)
+    dy = torch.randn(n, h, w, co, generator=g).to(dev)
+    y_prev = torch.randn(n, h, w, ci, generator=g).to(dev)            # pre-BN output of the producing layer
+    mean, istd = torch.randn(ci, generator=g).to(dev) * 0.1, (torch.rand(ci, generator=g) + 0.5).to(dev)
+    msc = msh = bits = a_prev = None
+    if mask == "from_y":
+        msc, msh = (torch.rand(ci, generator=g) + 0.5).to(dev), (torch.randn(ci, generator=g) * 0.3).to(dev)
+    elif mask == "bits":
+        bits = torch.empty(n * h * w * ci // 4, dtype=torch.uint8, device=dev)
+        a_prev = ops.affine_act(y_prev, res=torch.randn(n, h, w, ci, generator=g).to(dev), act=1, mask_out=bits)
+    for accumulate in (False, True):
+        skip = torch.randn(n, h, w, ci, generator=g).to(dev) if accumulate else None
+        want_dx = ops.conv2d_dgrad(dy, wp, (h, w), 1, 1, 1, tile_cfg=cfg, out=skip.clone() if accumulate else None,
+                                   accumulate=accumulate)
+        dx, part = ops.conv2d_dgrad(dy, wp, (h, w), 1, 1, 1, tile_cfg=cfg, out=skip.clone() if accumulate else None,
+                                    accumulate=accumulate, bn_bwd=(y_prev, mean, istd, msc, msh, bits))
+        assert torch.equal(dx, want_dx)
+        ref = ops.bn_bwd_stats(dx, None, y_prev, mean, istd, msc, msh, bits)
+        got, want = part.double().sum(0), ref.double().sum(0)
+        assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5, (cfg, mask, accumulate)
+        if bits is not None:   # the sign bytes agree with the activation they were derived from
+            ref_a = ops.bn_bwd_stats(dx, a_prev, y_prev, mean, istd)
+            assert torch.equal(ref_a, ref)
+
+
 @pytest.mark.parametrize("shape,res,relu,train", [((2, 17, 19, 64), True, True, True), ((3, 9, 9, 48), False, True, True),
                                                   ((2, 5, 5, 2048), True, True, True), ((4, 1, 1, 256), False, True, True),
                                                   ((2, 17, 19, 64), True, True, False), ((2, 8, 8, 1280), False, False, True)])

@@ -40,7 +40,107 @@ struct ConvArgs {
   int ncols, ldw, ldy, ldr, M;
   int act, accumulate, dgrad, stride_log2;
   float leak;
+  // optional BatchNorm-backward statistics of the layer whose output gradient this launch produces (dgrad epilogue):
+  // bs_partial[mtile][2][ncols] = (sum dz, sum dz*xhat) with dz = stored value * ReLU mask, xhat = (bs_y - mean) * istd
+  const float* bs_y;
+  const float* bs_mean;
+  const float* bs_istd;
+  const float* bs_msc;            // mask = bs_y * msc + msh > 0 (no residual) ...
+  const float* bs_msh;
+  const unsigned char* bs_mbits;  // ... or sign bits [M][ncols/4] (residual layers)
+  float* bs_partial;
+  int bs_ldy;
 };
+
+// Rows [0, nrows) of an LDS-staged output tile -> global memory as dwordx4 per lane, with the fused epilogue (affine,
+// residual, activation, accumulate).  `c4`/`r0` = this thread's column quad / first row, RPP = rows per pass.  When
+// p.bs_partial is set the thread also accumulates the BN-backward sums of its 4 columns over the rows it stores.
+template <int RPP>
+__device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* ctile, int ldc, int row_base, int nrows,
+                                                int col, int c4, int r0, f32x4 sc, f32x4 sh, bool affine, bool vec,
+                                                f32x4& bs_s, f32x4& bs_q) {
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
+  const bool bstat = p.bs_partial != nullptr && vec && col < p.ncols;
+  if (bstat) {
+    mu = *reinterpret_cast<const f32x4*>(p.bs_mean + col);
+    is = *reinterpret_cast<const f32x4*>(p.bs_istd + col);
+    if (p.bs_msc) {
+      msc = *reinterpret_cast<const f32x4*>(p.bs_msc + col);
+      msh = *reinterpret_cast<const f32x4*>(p.bs_msh + col);
+    }
+  }
+  for (int rr = r0; rr < nrows; rr += RPP) {
+    const int row = row_base + rr;
+    if (row >= p.M || col >= p.ncols) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
+    if (affine) v = v * sc + sh;
+    float* dst = p.y + (size_t)row * p.ldy + col;
+    if (vec) {
+      if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
+      }
+      if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = v;
+      if (bstat) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(p.bs_y + (size_t)row * p.bs_ldy + col);
+        f32x4 dz = v;
+        if (p.bs_mbits) {
+          const unsigned mb = p.bs_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[e] = (mb >> e) & 1u ? dz[e] : 0.f;
+        } else if (p.bs_msc) {
+          const f32x4 av = yv * msc + msh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[e] = av[e] > 0.f ? dz[e] : 0.f;
+        }
+        bs_s += dz;
+        bs_q += dz * ((yv - mu) * is);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < p.ncols) {
+          float t = v[e];
+          if (p.res) t += p.res[(size_t)row * p.ldr + col + e];
+          if (p.act == 1) t = fmaxf(t, 0.f);
+          else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
+          if (p.accumulate) t += dst[e];
+          dst[e] = t;
+        }
+    }
+  }
+}
+
+// Block reduction of the per-thread BN-backward sums (fixed order: deterministic) and store of this row tile's partials.
+// Thread (r0, c4) holds the sums of columns 4*c4..4*c4+3 over its rows; `red` needs 2 * RPP * BN floats of LDS.
+template <int BN, int RPP, int NT>
+__device__ __forceinline__ void finish_bwd_stats(const ConvArgs& p, float* red, int tid, int c4, int r0, int mt, int n0,
+                                                 f32x4 bs_s, f32x4 bs_q) {
+  __syncthreads();   // the output tile in LDS is no longer read
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[r0 * BN + c4 * 4 + e] = bs_s[e];
+    red[(RPP + r0) * BN + c4 * 4 + e] = bs_q[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < BN; c += NT) {
+    const int col = n0 + c;
+    if (col < p.ncols) {
+      float ts = 0.f, tq = 0.f;
+      for (int g = 0; g < RPP; ++g) {
+        ts += red[g * BN + c];
+        tq += red[(RPP + g) * BN + c];
+      }
+      p.bs_partial[((size_t)mt * 2 + 0) * p.ncols + col] = ts;
+      p.bs_partial[((size_t)mt * 2 + 1) * p.ncols + col] = tq;
+    }
+  }
+}
 
 template <int BM, int BN, int PREC, int PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
@@ -326,36 +426,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         if (p.scale) sc[e] = p.scale[col + e];
         if (p.shift) sh[e] = p.shift[col + e];
       }
-    for (int rr = r0; rr < BM; rr += RPP) {
-      const int row = m0 + rr;
-      if (row >= p.M || col >= p.ncols) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * LDC + c4 * 4);
-      if (affine) v = v * sc + sh;
-      float* dst = p.y + (size_t)row * p.ldy + col;
-      if (vec) {
-        if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
-        if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
-        }
-        if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (col + e < p.ncols) {
-            float t = v[e];
-            if (p.res) t += p.res[(size_t)row * p.ldr + col + e];
-            if (p.act == 1) t = fmaxf(t, 0.f);
-            else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
-            if (p.accumulate) t += dst[e];
-            dst[e] = t;
-          }
-      }
-    }
+    f32x4 bs_s = {0.f, 0.f, 0.f, 0.f}, bs_q = {0.f, 0.f, 0.f, 0.f};
+    store_tile_rows<RPP>(p, ctile, LDC, m0, BM, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
+    if (p.bs_partial) finish_bwd_stats<BN, RPP, 256>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
   }
 }
 
@@ -605,6 +678,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvArgs p) {
       if (p.scale) sc[e] = p.scale[col + e];
       if (p.shift) sh[e] = p.shift[col + e];
     }
+  f32x4 bs_s = {0.f, 0.f, 0.f, 0.f}, bs_q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -620,37 +694,9 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvArgs p) {
           }
     }
     __syncthreads();
-    for (int rr = r0; rr < BM / 2; rr += RPP) {
-      const int row = m0 + half * (BM / 2) + rr;
-      if (row >= p.M || col >= p.ncols) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * LDC + c4 * 4);
-      if (affine) v = v * sc + sh;
-      float* dst = p.y + (size_t)row * p.ldy + col;
-      if (vec) {
-        if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
-        if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
-        }
-        if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (col + e < p.ncols) {
-            float t = v[e];
-            if (p.res) t += p.res[(size_t)row * p.ldr + col + e];
-            if (p.act == 1) t = fmaxf(t, 0.f);
-            else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
-            if (p.accumulate) t += dst[e];
-            dst[e] = t;
-          }
-      }
-    }
+    store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
   }
+  if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1010,6 +1056,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       if (p.scale) sc[e] = p.scale[col + e];
       if (p.shift) sh[e] = p.shift[col + e];
     }
+  f32x4 bs_s = {0.f, 0.f, 0.f, 0.f}, bs_q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -1025,37 +1072,9 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
           }
     }
     __syncthreads();
-    for (int rr = r0; rr < BM / 2; rr += RPP) {
-      const int row = m0 + half * (BM / 2) + rr;
-      if (row >= p.M || col >= p.ncols) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * LDC + c4 * 4);
-      if (affine) v = v * sc + sh;
-      float* dst = p.y + (size_t)row * p.ldy + col;
-      if (vec) {
-        if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
-        if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
-        }
-        if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (col + e < p.ncols) {
-            float t = v[e];
-            if (p.res) t += p.res[(size_t)row * p.ldr + col + e];
-            if (p.act == 1) t = fmaxf(t, 0.f);
-            else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
-            if (p.accumulate) t += dst[e];
-            dst[e] = t;
-          }
-      }
-    }
+    store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
   }
+  if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
 }
 
 template <int PREC>
@@ -1113,14 +1132,18 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
   return (M + bm - 1) / bm;
 }
 
-extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scale,
-                              const float* shift, const float* res, float* stat_partial, int N, int H, int W,
-                              int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
-                              int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int act, float leak,
-                              int accumulate, int dgrad, int prec, int tile_cfg, const void* zero_page, void* stream) {
+static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const float* scale, const float* shift,
+                           const float* res, float* stat_partial, int N, int H, int W, int Ho, int Wo, int cin_pad,
+                           int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int ncols,
+                           int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec, int tile_cfg,
+                           const void* zero_page, void* stream, const float* bs_y, int bs_ldy, const float* bs_mean,
+                           const float* bs_istd, const float* bs_msc, const float* bs_msh,
+                           const unsigned char* bs_mbits, float* bs_partial) {
   if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 1 && prec != 3)) return -1;
   if (stride < 1 || (stride & (stride - 1)) != 0 || zero_page == nullptr) return -1;
   if (((uintptr_t)x & 15) || ((uintptr_t)w_pk & 15) || ((uintptr_t)zero_page & 15)) return -2;
+  if (bs_partial && (!bs_y || !bs_mean || !bs_istd || (bs_ldy & 3) || (ncols & 3) || (ldy & 3) || (res && (ldr & 3))))
+    return -6;   // the fused BN-backward sums need the vectorised store path
   ConvArgs a;
   a.x = x; a.w_pk = (const unsigned short*)w_pk; a.y = y;
   a.scale = scale; a.shift = shift; a.res = res; a.stat_partial = stat_partial;
@@ -1130,6 +1153,8 @@ extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const 
   a.ncols = ncols; a.ldw = KH * KW * cin_pad; a.ldy = ldy; a.ldr = ldr; a.M = N * Ho * Wo;
   a.act = act; a.accumulate = accumulate; a.dgrad = dgrad; a.leak = leak;
   a.zero = (const float*)zero_page;
+  a.bs_y = bs_y; a.bs_ldy = bs_ldy; a.bs_mean = bs_mean; a.bs_istd = bs_istd; a.bs_msc = bs_msc; a.bs_msh = bs_msh;
+  a.bs_mbits = bs_mbits; a.bs_partial = bs_partial;
   a.stride_log2 = 0;
   while ((1 << a.stride_log2) < stride) ++a.stride_log2;
   if (a.M <= 0 || ncols <= 0) return 0;
@@ -1154,4 +1179,27 @@ extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const 
     case 31: return launch_dma(a, prec, st);
   }
   return -3;
+}
+
+extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scale,
+                              const float* shift, const float* res, float* stat_partial, int N, int H, int W,
+                              int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
+                              int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int act, float leak,
+                              int accumulate, int dgrad, int prec, int tile_cfg, const void* zero_page, void* stream) {
+  return conv_igemm_impl(x, w_pk, y, scale, shift, res, stat_partial, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
+                         stride, pad_h, pad_w, dil, ncols, ldy, ldr, act, leak, accumulate, dgrad, prec, tile_cfg,
+                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const float* res, int N, int H, int W,
+                                      int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
+                                      int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int accumulate,
+                                      int dgrad, int prec, int tile_cfg, const void* zero_page, const float* bn_y,
+                                      int bn_ldy, const float* bn_mean, const float* bn_invstd,
+                                      const float* mask_scale, const float* mask_shift,
+                                      const unsigned char* mask_bits, float* bn_partial, void* stream) {
+  if (!bn_partial) return -1;
+  return conv_igemm_impl(x, w_pk, y, nullptr, nullptr, res, nullptr, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
+                         stride, pad_h, pad_w, dil, ncols, ldy, ldr, 0, 0.f, accumulate, dgrad, prec, tile_cfg, zero_page,
+                         stream, bn_y, bn_ldy, bn_mean, bn_invstd, mask_scale, mask_shift, mask_bits, bn_partial);
 }

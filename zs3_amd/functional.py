@@ -21,6 +21,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # of this network launch fewer workgroups than the 256 CUs can hold, so the wgrad kernels run on a second HIP stream
 # next to the dgrad / BatchNorm chain; the main stream joins it once, at the end of backward.
 WGRAD_SIDE_STREAM = True
+FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
 _side = {}
 _join_armed = [False]
 
@@ -102,6 +103,19 @@ def _dense_rows(t):
         return t.contiguous()
 
 
+class BnLink:
+    """Hand-off between a fused conv+BN(+ReLU) layer and the *only* consumer of its output.  The consumer's dgrad epilogue
+    already holds the finished gradient dA of this layer in registers, so it also produces this layer's BN-backward sums
+    (sum dz, sum dz*xhat; zs3_conv_igemm_bnstats) and the separate statistics pass over dA is skipped.  The model code
+    promises the sole-consumer property (`input_has_one_consumer=True`); the producer double-checks that the gradient it
+    receives is the very buffer the sums were computed for."""
+    __slots__ = ("y", "mean", "istd", "msc", "msh", "mbits", "partial", "for_ptr")
+
+    def __init__(self):
+        self.y = self.mean = self.istd = self.msc = self.msh = self.mbits = self.partial = None
+        self.for_ptr = 0
+
+
 def _mask_bits_for(y, act, residual, need_grad):
     """Residual layers: the ReLU mask cannot be recomputed from y alone, and re-reading the output `a` twice in the backward
     pass costs 8 bytes per element; affine_act writes the sign bits (1/16 of that) instead."""
@@ -167,6 +181,13 @@ class _ConvBnAct(torch.autograd.Function):
         keep_a = act != ACT_NONE and not ctx.mask_from_y and mbits is None
         ctx.save_for_backward(x, weight, gamma, y, a if keep_a else None, st, mbits)
         ctx.pass_through = bool(cfg.get("pass_through"))
+        link = cfg.get("out_link")
+        if link is not None and ctx.bn_training and need_grad and act in (ACT_NONE, ACT_RELU) and bn.get("sync") is None:
+            link.y, link.mean, link.istd, link.mbits = y, st[0], st[1], mbits
+            if ctx.mask_from_y:
+                link.msc, link.msh = st[2], st[3]
+        else:
+            cfg["out_link"] = None
         if ctx.pass_through:
             return a, x.view(x.shape)   # the block input again, as the skip connection: its gradient comes back to us
         return a
@@ -186,7 +207,14 @@ class _ConvBnAct(torch.autograd.Function):
             dres = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
         m = dA.shape[0] * dA.shape[1] * dA.shape[2] if dA.dim() == 4 else dA.shape[0]
         if ctx.has_bn:
-            part = ops.bn_bwd_stats(dA, a, y, st[0], st[1], msc, msh, mbits)
+            link = cfg.get("out_link")
+            if link is not None and link.partial is not None and link.for_ptr == dA.data_ptr() and \
+                    ops._rows(dA)[2] == dA.shape[-1]:
+                part = link.partial      # summed by the consumer's dgrad epilogue
+            else:
+                part = ops.bn_bwd_stats(dA, a, y, st[0], st[1], msc, msh, mbits)
+            if link is not None:
+                link.partial = link.y = link.mbits = None
             sync = (cfg.get("bn") or {}).get("sync") if ctx.bn_training else None
             if sync is not None:
                 from .parallel import combine_bn_partials
@@ -227,8 +255,17 @@ class _ConvBnAct(torch.autograd.Function):
                 fuse = (dskip is not None and tuple(dskip.shape) == ctx.x_shape and dskip.is_contiguous()
                         and dskip.shape[-1] == wp.cin)
                 # identity blocks: the skip gradient is accumulated by the dgrad epilogue instead of a separate add kernel
-                dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec,
-                                      out=dskip if fuse else None, accumulate=fuse)
+                in_link = cfg.get("in_link")
+                if in_link is not None and in_link.y is not None and (dskip is None or fuse) and \
+                        wp.cin == ctx.x_shape[-1] and wp.cin % 4 == 0:
+                    dx, part_in = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec,
+                                                   out=dskip if fuse else None, accumulate=fuse,
+                                                   bn_bwd=(in_link.y, in_link.mean, in_link.istd, in_link.msc,
+                                                           in_link.msh, in_link.mbits))
+                    in_link.partial, in_link.for_ptr = part_in, dx.data_ptr()
+                else:
+                    dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec,
+                                          out=dskip if fuse else None, accumulate=fuse)
                 if dskip is not None and not fuse:
                     dx = dx + dskip
                 if dx.shape[-1] != ctx.x_shape[-1]:  # x carried pad channels
@@ -270,10 +307,14 @@ def _act_grad(a, act, leak):
 
 
 def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
-                leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False):
-    """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None."""
+                leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False):
+    """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None.
+    input_has_one_consumer: promise that `x` feeds nothing but this layer (and, with pass_through, the skip tensor this
+    layer hands back), which lets this layer's dgrad produce the BN-backward sums of the layer that made `x` (BnLink)."""
     cfg = {"stride": stride, "pad": pad, "dil": dil, "act": act, "out": out, "leak": leak, "prec": prec, "geom": geom,
            "wgrad": wgrad, "pass_through": pass_through,
+           "in_link": getattr(x, "_zs3_bn_link", None) if (input_has_one_consumer and FUSE_BN_BWD_STATS) else None,
+           "out_link": BnLink() if (bn is not None and out is None and FUSE_BN_BWD_STATS) else None,
            "need_grad": torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
                                                         (x, weight, bias, residual, getattr(bn, "weight", None)))}
     gamma = beta = None
@@ -292,7 +333,10 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
                      "sync": getattr(bn, "_zs3_sync_group", None),
                      "running_mean": bn.running_mean if (bn.training and bn.track_running_stats) or not use_batch else None,
                      "running_var": bn.running_var if (bn.training and bn.track_running_stats) or not use_batch else None}
-    return _ConvBnAct.apply(x, weight, gamma, beta, bias, residual, cfg)
+    res = _ConvBnAct.apply(x, weight, gamma, beta, bias, residual, cfg)
+    if cfg.get("out_link") is not None:
+        (res[0] if pass_through else res)._zs3_bn_link = cfg["out_link"]
+    return res
 
 
 # ---------------------------------------------------------------------------------- standalone BN (+act)

@@ -35,12 +35,14 @@ class Bottleneck(nn.Module):
         if self.downsample is None:
             # identity block: conv1's node also hands the input through as the skip tensor, so that the skip gradient
             # comes back to it and is accumulated inside its dgrad epilogue (no separate add kernel in backward)
-            y, skip = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU, pass_through=True)
+            # ... and, being the only consumer of x, its dgrad also sums the previous block's bn3 backward statistics
+            y, skip = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU, pass_through=True, input_has_one_consumer=True)
         else:
             y = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU)
             skip = self.downsample[0].forward_nhwc(x, self.downsample[1])
-        y = self.conv2.forward_nhwc(y, self.bn2, act=Fz.ACT_RELU)
-        return self.conv3.forward_nhwc(y, self.bn3, residual=skip, act=Fz.ACT_RELU)  # bn3 + add + relu in one pass
+        y = self.conv2.forward_nhwc(y, self.bn2, act=Fz.ACT_RELU, input_has_one_consumer=True)
+        return self.conv3.forward_nhwc(y, self.bn3, residual=skip, act=Fz.ACT_RELU,   # bn3 + add + relu in one pass
+                                       input_has_one_consumer=True)
 
     def forward(self, x):
         return ops.nchw(self.forward_nhwc(ops.nhwc(x)))

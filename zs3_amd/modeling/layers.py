@@ -19,9 +19,11 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
         return self
 
-    def forward_nhwc(self, x, bn=None, residual=None, act=Fz.ACT_NONE, out=None, pass_through=False):
+    def forward_nhwc(self, x, bn=None, residual=None, act=Fz.ACT_NONE, out=None, pass_through=False,
+                     input_has_one_consumer=False):
         return Fz.conv_bn_act(x, self.weight, bn=bn, bias=self.bias, residual=residual, stride=self.stride[0],
-                              pad=self.padding[0], dil=self.dilation[0], act=act, out=out, pass_through=pass_through)
+                              pad=self.padding[0], dil=self.dilation[0], act=act, out=out, pass_through=pass_through,
+                              input_has_one_consumer=input_has_one_consumer)
 
     def forward(self, x):  # logical NCHW in / out
         return ops.nchw(self.forward_nhwc(ops.nhwc(x)))

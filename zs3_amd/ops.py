@@ -107,8 +107,10 @@ def conv_out_size(h, k, stride, pad, dil):
 
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
                scale=None, shift=None, res=None, want_stats=False, act=0, leak=0.2, accumulate=False, dgrad=False,
-               prec=None, tile_cfg=0):
-    """Raw launcher.  x: NHWC [N,H,W,*]; returns (y [N,ho,wo,ncols] or `out`, stat_partial or None)."""
+               prec=None, tile_cfg=0, bn_bwd=None):
+    """Raw launcher.  x: NHWC [N,H,W,*]; returns (y [N,ho,wo,ncols] or `out`, stat_partial or None).
+    bn_bwd = (y, mean, invstd, mask_scale, mask_shift, mask_bits): also return the BatchNorm-backward partial sums
+    (sum dz, sum dz*xhat per row tile) of the layer the output gradient belongs to (zs3_conv_igemm_bnstats)."""
     require_gpu(x, w_pk, out, scale, shift, res)
     prec = prec or PREC_DEFAULT
     n, h, w_, _ = x.shape
@@ -121,16 +123,28 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
     stat = None
-    if want_stats:
+    if want_stats or bn_bwd is not None:
         mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
         stat = torch.empty((mt, 2, ncols), dtype=torch.float32, device=x.device)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().zs3_conv_igemm(P(x), P(w_pk), P(out), P(scale), P(shift), P(res), P(stat), I(n), I(h), I(w_),
-                               I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h),
-                               I(pad_w), I(dil), I(ncols), I(ldy), I(ldr), I(act), F(leak), I(int(accumulate)),
-                               I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), stream()), "zs3_conv_igemm")
+    if bn_bwd is not None:
+        assert scale is None and shift is None and act == 0 and not want_stats
+        by, bmean, bistd, bmsc, bmsh, bbits = bn_bwd
+        require_gpu(by, bmean, bistd, bmsc, bmsh, bbits)
+        check(lib().zs3_conv_igemm_bnstats(P(x), P(w_pk), P(out), P(res), I(n), I(h), I(w_), I(ho), I(wo), I(cin_pad),
+                                           I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h), I(pad_w), I(dil),
+                                           I(ncols), I(ldy), I(ldr), I(int(accumulate)), I(int(dgrad)), I(prec),
+                                           I(tile_cfg), P(zero_page(x.device)), P(by), I(_check_nhwc(by)), P(bmean),
+                                           P(bistd), P(bmsc), P(bmsh), P(bbits), P(stat), stream()),
+              "zs3_conv_igemm_bnstats")
+    else:
+        check(lib().zs3_conv_igemm(P(x), P(w_pk), P(out), P(scale), P(shift), P(res), P(stat), I(n), I(h), I(w_),
+                                   I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h),
+                                   I(pad_w), I(dil), I(ncols), I(ldy), I(ldr), I(act), F(leak), I(int(accumulate)),
+                                   I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), stream()),
+              "zs3_conv_igemm")
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
@@ -152,9 +166,9 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
     """dy: NHWC [N,Ho,Wo,C>=wp.cout] (channels beyond cout zero) -> dx [N,H,W,wp.cin]."""
     h, w_ = in_hw
     cin_valid = min(_round_up(wp.cout, 4), _check_nhwc(dy))
-    out, _ = conv_igemm(dy, wp.t_pk, ho=h, wo=w_, cin_pad=wp.cout_pad, cin_valid=cin_valid, kh=wp.kh,
-                        kw=wp.kw, stride=stride, pad_h=pad, pad_w=pad, dil=dil, ncols=wp.cin, dgrad=True, **kw)
-    return out
+    out, part = conv_igemm(dy, wp.t_pk, ho=h, wo=w_, cin_pad=wp.cout_pad, cin_valid=cin_valid, kh=wp.kh,
+                           kw=wp.kw, stride=stride, pad_h=pad, pad_w=pad, dil=dil, ncols=wp.cin, dgrad=True, **kw)
+    return (out, part) if kw.get("bn_bwd") is not None else out
 
 
 def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1, prec=None, ci_read=None):
