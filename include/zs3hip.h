@@ -22,6 +22,11 @@ extern "C" {
  * reference (cuDNN consumed fp32 weights directly). */
 int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
                     void* stream);
+/* the same for many weights in ONE launch (after an optimizer step): table[e] = {w, f_pk, t_pk, cout, taps, cin, cin_pad,
+ * cout_pad} as 8 int64 (device memory), blockmap[b] = {entry, chunk} as 2 int32, one block per zs3_prep_chunk()
+ * consecutive elements of an entry's (forward ++ transposed) element space. */
+int zs3_prep_chunk(void);
+int zs3_prep_weight_multi(const long* table, const int* blockmap, int nblocks, void* stream);
 /* NCHW 3-channel image -> [N][H][Wp][4] zero-padded NHWC4 (image at columns [left,left+W)).  Feeds
  * the 7x7/s2 stem (resnet.py:79) as a 7x1 conv over 32-float (8 pixel x 4 ch) windows. */
 int zs3_nchw3_to_nhwc4(const float* img, float* out, int N, int H, int W, int Wp, int left, void* stream);

@@ -64,6 +64,48 @@ def invalidate_planes(*params):
         _planes.pop(id(w), None)
 
 
+_refresh_tables = {}
+
+
+def refresh_planes(*params):
+    """After an optimizer step through raw pointers: recompute the cached planes of every parameter that has any, in ONE
+    launch (zs3_prep_weight_multi) into the existing plane buffers, instead of one zs3_prep_weight per layer at its next
+    forward.  Parameters whose memory is not the [Cout][KH][KW][Cin] storage the planes were built from are invalidated."""
+    todo = []
+    for w in params:
+        hit = _planes.get(id(w))
+        if hit is None:
+            continue
+        ver, wp, ref = hit
+        w4 = w if w.dim() == 4 else w[:, :, None, None]
+        if ref() is not w or ver[0] != w.data_ptr() or ver[2] != tuple(w.shape) or not ver[3] or \
+                not w4.permute(0, 2, 3, 1).is_contiguous():
+            _planes.pop(id(w), None)
+            continue
+        todo.append((w, wp, ref))
+    if not todo:
+        return
+    dev = todo[0][0].device
+    key = (dev.index,) + tuple((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr()) for w, wp, _ in todo)
+    tab = _refresh_tables.get(dev.index)
+    if tab is None or tab[0] != key:
+        chunk = ops.lib().zs3_prep_chunk()
+        recs, bmap = [], []
+        for e, (w, wp, _) in enumerate(todo):
+            taps = wp.kh * wp.kw
+            recs.append((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr(), wp.cout, taps, wp.cin, wp.cin_pad, wp.cout_pad))
+            total = wp.cout * taps * wp.cin_pad + wp.cin * taps * wp.cout_pad
+            bmap.extend((e, c) for c in range((total + chunk - 1) // chunk))
+        table = torch.tensor(recs, dtype=torch.int64).to(dev)
+        blockmap = torch.tensor(bmap, dtype=torch.int32).to(dev)
+        tab = (key, table, blockmap, len(bmap))
+        _refresh_tables[dev.index] = tab
+    ops.check(ops.lib().zs3_prep_weight_multi(ops.P(tab[1]), ops.P(tab[2]), ops.I(tab[3]), ops.stream()),
+              "zs3_prep_weight_multi")
+    for w, wp, ref in todo:
+        _planes[id(w)] = ((w.data_ptr(), w._version, tuple(w.shape), True), wp, ref)
+
+
 # ---------------------------------------------------------------------------------- RNG for dropout
 _rng = None
 

@@ -60,7 +60,7 @@ class SGD(torch.optim.SGD):
             check(lib().zs3_sgd_multi(P(table_d), P(map_d), I(len(bmap)), F(mom), I(int(nest)), stream()), "zs3_sgd_multi")
             keep.extend((table, blockmap, table_d, map_d))
         self._keepalive = keep   # pinned staging buffers must outlive the asynchronous copies
-        Fz.invalidate_planes(*touched)
+        Fz.refresh_planes(*touched)   # one launch re-splits every updated conv weight into its bf16 hi/lo planes
         return loss
 
 
