@@ -148,6 +148,23 @@ int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float
 int zs3_uniform(float* out, long n, unsigned long long seed, const void* seed_dev, void* stream);
 /* counter[0] += v (device int64 / uint64): advances the stream position / step count between graph replays */
 int zs3_counter_add(void* counter, long v, void* stream);
+/* ---- fused pieces of the GMMN generator update (train_pascal_GMMN.py:205-236, replayed per image and class) ---- */
+/* zs3_uniform + zs3_gather_cat in one launch: out[r] = [a[idx[r]][0:Ca] | U[0,1)^Cb | 0...] */
+int zs3_gather_cat_noise(const float* a, int lda, const long* idx, int Ca, int Cb, float* out, int ldo, long n,
+                         unsigned long long seed, const void* seed_dev, void* stream);
+/* out = dropout_backward(dy; p, seed, row_idx) * leaky_relu'(h; leak): Dropout + LeakyReLU backward of gmmn.py:19-22 */
+int zs3_dropout_act_bwd(const float* dy, int ldd, const float* h, int ldh, float* out, int ldo, long M, int C, float p,
+                        unsigned long long seed, const long* row_idx, const void* seed_dev, float leak, void* stream);
+/* out[c] = sum_m x[m][c] (rows in order): bias gradients of the generator's Linear layers */
+int zs3_colsum(const float* x, int ldx, int M, int C, float* out, void* stream);
+/* torch.optim.Adam for several tensors in one launch, device-resident step count; table[e] = {p, g, exp_avg, exp_avg_sq,
+ * n, f_pk, t_pk, cout, cin, cin_pad, cout_pad} (11 int64): entries with f_pk != 0 are Linear weights whose bf16 hi/lo
+ * operands (zs3_prep_weight layout, taps = 1) are rewritten in the same pass; blockmap[b] = {entry, chunk of
+ * zs3_adam_chunk() elements}. */
+int zs3_adam_chunk(void);
+int zs3_adam_multi(const long* table, const int* blockmap, int nblocks, float lr, float b1, float b2, float eps, float wd,
+                   const void* step_dev, void* stream);
+int zs3_counter_add2(void* c0, long v0, void* c1, long v1, void* stream);
 /* F.interpolate(mode="nearest") of one [C][H][W] image into pixel rows [ho*wo][ldo] (train_pascal_GMMN.py:175-195) */
 int zs3_nearest_rows(const float* src, int C, int H, int W, int ho, int wo, float* rows, int ldo, void* stream);
 /* out[r] = [a[idx[r]][0:Ca] | b[r][0:Cb] | 0...]: torch.cat((embd, noise), 1) of gmmn.py:44 fused with the class mask */

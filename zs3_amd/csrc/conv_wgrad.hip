@@ -498,12 +498,14 @@ static int tile_override() {
 // kernel 2 (LDS-DMA, 256x256 tiles) takes the leading multiple-of-256 input channels when Cout fills 256-wide tiles;
 // a remainder of <= 128 input channels (the 304-channel decoder concat) goes to kernel 1 in a second launch over the
 // same split-K slabs.  Returns the number of input channels given to kernel 2.  ZS3_WGRAD_KERNEL=1|2 forces one (debug).
-static int dma_width(int co, int ci, int wo) {
+static int dma_width(int co, int ci, int wo, int M) {
   static int v = -1;
   if (v < 0) v = env_int("ZS3_WGRAD_KERNEL");
   if (v == 1) return 0;
   if (v == 2) return ci;
-  if (co < 256 || co % 256 || ci < 256 || wo < 16) return 0;
+  // short reductions (the GMMN generator's per-class pixel sets) stay on kernel 1: the 256x256 blocks' prologue, tile store
+  // and the second launch for a ragged Cin cost more than they save there (measured: +7 ms per GMMN step)
+  if (co < 256 || co % 256 || ci < 256 || wo < 16 || M < 8192) return 0;
   const int rem = ci % 256;
   return rem <= 128 ? ci - rem : 0;
 }
@@ -533,7 +535,7 @@ static int pick_splitk_dma(int M, int tiles, long out_elems) {
 }
 extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
   int s;
-  const int wd = dma_width(co, ci, Wo);
+  const int wd = dma_width(co, ci, Wo, M);
   if (wd > 0) {
     s = pick_splitk_dma(M, ((co + 255) / 256) * ((wd + 255) / 256) * taps, (long)co * ci * taps);
   } else {
@@ -564,7 +566,7 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
   int splitk;
   long ws;
   zs3_conv_wgrad_plan(a.M, Wo, co_write, ci_write, taps, &splitk, &ws);
-  const int wd = dma_width(co_write, ci_write, Wo);
+  const int wd = dma_width(co_write, ci_write, Wo, a.M);
   if (splitk > 1 && workspace == nullptr) return -3;
   int chunks = (a.M + 31) / 32;
   a.chunk = ((chunks + splitk - 1) / splitk) * 32;

@@ -148,6 +148,112 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
   }
 }
 
+// ---- fused pieces of the GMMN generator update (one captured graph per (image, class): every launch counts) ----
+// out[r][0:Ca] = a[idx[r]][0:Ca]; out[r][Ca:Ca+Cb] = U[0,1) noise with the stream of uniform_kernel on a [n][Cb]
+// tensor (element r*Cb + c); out[r][Ca+Cb:ldo] = 0
+__global__ void gather_cat_noise_kernel(const float* a, int lda, const long* idx, int Ca, int Cb, float* out, int ldo,
+                                        long n, unsigned long long seed, const unsigned long long* seed_dev) {
+  if (seed_dev) seed += seed_dev[0];
+  const long total = n * ldo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / ldo;
+    const int c = (int)(i - r * ldo);
+    float v = 0.f;
+    if (c < Ca) v = a[(idx ? idx[r] : r) * lda + c];
+    else if (c < Ca + Cb) v = u01(seed, (unsigned long long)(r * Cb + (c - Ca)));
+    out[i] = v;
+  }
+}
+
+// out = dropout_backward(dy) * leaky_relu'(h): the two elementwise steps between the generator's second and first Linear
+__global__ void dropout_act_bwd_kernel(const float* dy, int ldd, const float* h, int ldh, float* out, int ldo, long M, int C,
+                                       float p, float inv_keep, unsigned long long seed, const long* row_idx,
+                                       const unsigned long long* seed_dev, float leak) {
+  if (seed_dev) seed += seed_dev[0];
+  const long total = M * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C;
+    const int c = (int)(i - m * C);
+    float v = dy[m * ldd + c];
+    if (p > 0.f) {
+      const unsigned long long e = row_idx ? (unsigned long long)(row_idx[m] * C + c) : (unsigned long long)i;
+      v = u01(seed, e) >= p ? v * inv_keep : 0.f;
+    }
+    out[m * ldo + c] = h[m * ldh + c] > 0.f ? v : v * leak;
+  }
+}
+
+// out[c] = sum_m x[m][c] for the few hundred rows of a bias gradient: 64 channels x 4 interleaved row groups per block,
+// the four partial sums combined in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, int M, int C, float* out) {
+  __shared__ float red[256];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int m = ty; m < M; m += 4) s += x[(long)m * ldx + c];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) out[c] = (red[tx] + red[64 + tx]) + (red[128 + tx] + red[192 + tx]);
+}
+
+// Adam for several tensors in one launch; tensors with plane pointers (Linear weights [cout][cin]) also get their bf16
+// hi/lo operands rewritten in place (forward rows = cout, transposed rows = cin; layout of zs3_prep_weight).
+// table[e] = {p, g, m, v, n, f_pk, t_pk, cout, cin, cin_pad, cout_pad}; blockmap[b] = {entry, chunk}.
+constexpr int ADAM_CHUNK = 1024;   // small chunks: the generator has 0.2 M parameters and the update is latency-bound
+__device__ __forceinline__ long packed_index_1tap(long row, long k, long ktot, int half) {
+  return ((row * (ktot >> 5) + (k >> 5)) * 2 + half) * 32 + (k & 31);
+}
+__global__ __launch_bounds__(256) void adam_multi_kernel(const long* __restrict__ table, const int* __restrict__ blockmap,
+                                                         float lr, float b1, float b2, float eps, float wd,
+                                                         const long* step_dev) {
+  const int e = blockmap[2 * blockIdx.x], chunk = blockmap[2 * blockIdx.x + 1];
+  const long* t = table + 11 * (long)e;
+  float* p = reinterpret_cast<float*>(t[0]);
+  const float* g = reinterpret_cast<const float*>(t[1]);
+  float* m = reinterpret_cast<float*>(t[2]);
+  float* v = reinterpret_cast<float*>(t[3]);
+  const long n = t[4];
+  unsigned short* f_pk = reinterpret_cast<unsigned short*>(t[5]);
+  unsigned short* t_pk = reinterpret_cast<unsigned short*>(t[6]);
+  const int cin = (int)t[8], cin_pad = (int)t[9], cout_pad = (int)t[10];
+  const double st = (double)(step_dev[0] + 1);
+  const float bc1 = (float)(1.0 - pow((double)b1, st));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+  const long i0 = (long)chunk * ADAM_CHUNK;
+  const long i1 = i0 + ADAM_CHUNK < n ? i0 + ADAM_CHUNK : n;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float gi = g[i] + wd * p[i];
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float w = p[i] - (lr / bc1) * (mi / denom);
+    p[i] = w;
+    if (f_pk) {
+      const long co = i / cin, ci = i - co * cin;
+      const unsigned short h = f32_to_bf16_rne(w);
+      const unsigned short l = f32_to_bf16_rne(w - bf16_bits_to_f32(h));
+      f_pk[packed_index_1tap(co, ci, cin_pad, 0)] = h;
+      f_pk[packed_index_1tap(co, ci, cin_pad, 1)] = l;
+      if (t_pk) {
+        t_pk[packed_index_1tap(ci, co, cout_pad, 0)] = h;
+        t_pk[packed_index_1tap(ci, co, cout_pad, 1)] = l;
+      }
+    }
+  }
+}
+
+__global__ void counter_add2_kernel(long* c0, long v0, long* c1, long v1) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    c0[0] += v0;
+    if (c1) c1[0] += v1;
+  }
+}
+
 }  // namespace
 
 extern "C" int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
@@ -236,5 +342,44 @@ __global__ void counter_add_kernel(long* c, long v) {
 }
 extern "C" int zs3_counter_add(void* counter, long v, void* stream) {
   hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long*)counter, v);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_gather_cat_noise(const float* a, int lda, const long* idx, int Ca, int Cb, float* out, int ldo, long n,
+                                    unsigned long long seed, const void* seed_dev, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gather_cat_noise_kernel, dim3(ew_blocks(n * ldo)), dim3(256), 0, (hipStream_t)stream, a, lda, idx, Ca,
+                     Cb, out, ldo, n, seed, (const unsigned long long*)seed_dev);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_dropout_act_bwd(const float* dy, int ldd, const float* h, int ldh, float* out, int ldo, long M, int C,
+                                   float p, unsigned long long seed, const long* row_idx, const void* seed_dev, float leak,
+                                   void* stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(dropout_act_bwd_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, dy, ldd, h, ldh,
+                     out, ldo, M, C, p, p > 0.f ? 1.f / (1.f - p) : 1.f, seed, row_idx,
+                     (const unsigned long long*)seed_dev, leak);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_colsum(const float* x, int ldx, int M, int C, float* out, void* stream) {
+  if (C <= 0) return 0;
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, M, C, out);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_adam_chunk(void) { return ADAM_CHUNK; }
+extern "C" int zs3_adam_multi(const long* table, const int* blockmap, int nblocks, float lr, float b1, float b2, float eps,
+                              float wd, const void* step_dev, void* stream) {
+  if (nblocks <= 0) return 0;
+  if (!step_dev) return -1;
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, table, blockmap, lr, b1, b2, eps,
+                     wd, (const long*)step_dev);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_counter_add2(void* c0, long v0, void* c1, long v1, void* stream) {
+  hipLaunchKernelGGL(counter_add2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long*)c0, v0, (long*)c1, v1);
   return ZS3_LAUNCH_CHECK();
 }

@@ -86,6 +86,8 @@ class GMMNStep:
             "seed_base": Fz.next_seed(), "shape": (b, npix),
         }
         self._st = st
+        for name, prm in (("dw1", lin1.weight), ("db1", lin1.bias), ("dw2", lin2.weight), ("db2", lin2.bias)):
+            st[name] = torch.zeros(prm.shape, **f32)
         if self.fused_adam:
             opt = self.optimizer_generator
             opt._step_dev = None
@@ -98,6 +100,24 @@ class GMMNStep:
                         state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             any_p = opt.param_groups[0]["params"][0]
             st["step_dev"].fill_(int(opt.state[any_p]["step"]))
+            # one-launch Adam (+ in-place re-split of the two Linear weights) when the four generator tensors form a
+            # single param group with plain contiguous storage
+            st["adam_multi"] = None
+            grads = {lin1.weight: st["dw1"], lin1.bias: st["db1"], lin2.weight: st["dw2"], lin2.bias: st["db2"]}
+            planes = {lin1.weight: st["wp1"], lin2.weight: st["wp2"]}
+            groups = [g for g in opt.param_groups if any(p in grads for p in g["params"])]
+            if len(groups) == 1 and all(p.is_contiguous() for p in grads):
+                chunk = lib().zs3_adam_chunk()
+                recs, bmap = [], []
+                for e, (p, g) in enumerate(grads.items()):
+                    state, wp = opt.state[p], planes.get(p)
+                    recs.append((p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                 p.numel(), wp.f_pk.data_ptr() if wp else 0, wp.t_pk.data_ptr() if wp else 0,
+                                 wp.cout if wp else 0, wp.cin if wp else 1, wp.cin_pad if wp else 32,
+                                 wp.cout_pad if wp else 32))
+                    bmap.extend((e, c) for c in range((p.numel() + chunk - 1) // chunk))
+                st["adam_multi"] = (torch.tensor(recs, dtype=torch.int64).to(dev),
+                                    torch.tensor(bmap, dtype=torch.int32).to(dev), len(bmap), groups[0])
 
     # ------------------------------------------------------------------ the fixed-shape sampled-row update
     def _sampled_update(self, training):
@@ -106,12 +126,16 @@ class GMMNStep:
         st = self._st
         lin1, lrelu, drop, lin2 = self._layers()
         s, d = self.bsg, self.feature_dim
-        if self.noise != "cpu":
-            ops.uniform(None, st["seed_base"], None, out=st["z"], seed_dev=st["seed_dev"])
-        x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, self.embed_dim + self.noise_dim)
+        width = self.embed_dim + self.noise_dim
+        if self.noise != "cpu":   # noise drawn inside the gather (same stream as zs3_uniform on a [S, noise_dim] tensor)
+            x = ops.gather_cat_noise(st["emb"], st["pix_local"], self.embed_dim, self.noise_dim, width, s, st["seed_base"],
+                                     seed_dev=st["seed_dev"])
+        else:
+            x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, width)
         h = _rows_gemm(x, st["wp1"], lin1.bias, Fz.ACT_LEAKY, lrelu.negative_slope)
         use_drop = training and drop.p > 0
-        hd = ops.dropout(h, drop.p, st["seed_base"] ^ 0x5DEECE66D, row_idx=st["ridx"], seed_dev=st["seed_dev"]) if use_drop else h
+        dseed = st["seed_base"] ^ 0x5DEECE66D
+        hd = ops.dropout(h, drop.p, dseed, row_idx=st["ridx"], seed_dev=st["seed_dev"]) if use_drop else h
         gen_s = _rows_gemm(hd, st["wp2"], lin2.bias)
         real_s = ops.gather_rows(st["real"], st["pix_global"])
         t = (2 * s + 31) // 32
@@ -122,21 +146,25 @@ class GMMNStep:
         dgen = torch.empty_like(gen_s)
         check(lib().zs3_mmd_bwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(st["loss"]), P(st["one"]), P(dgen), I(d),
                                 stream()), "zs3_mmd_bwd")
-        # generator backward on the sampled rows
+        # generator backward on the sampled rows, gradients into static buffers
         wp1, wp2 = st["wp1"], st["wp2"]
-        dw2 = ops.conv2d_wgrad(dgen.view(1, 1, s, -1), hd.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1)
-        db2 = ops.colstats(dgen)[:, 0].sum(0)
+        ops.conv2d_wgrad(dgen.view(1, 1, s, -1), hd.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1, out=st["dw2"])
+        ops.colsum(dgen, out=st["db2"])
         dhd = ops.conv2d_dgrad(dgen.view(1, 1, s, -1), wp2, (1, s)).view(s, -1)
-        if use_drop:
-            dhd = ops.dropout(dhd, drop.p, st["seed_base"] ^ 0x5DEECE66D, row_idx=st["ridx"], seed_dev=st["seed_dev"])
-        dpre = torch.empty_like(dhd)
-        ops.bn_act_bwd(dhd, h, None, None, None, None, None, None, dres=dpre, act=Fz.ACT_LEAKY, leak=lrelu.negative_slope,
-                       want_dy=False)
-        dw1 = ops.conv2d_wgrad(dpre.view(1, 1, s, -1), x.view(1, 1, s, -1), wp1.cout, wp1.cin, 1, 1)
-        db1 = ops.colstats(dpre)[:, 0].sum(0)
-        grads = {lin1.weight: dw1.view(lin1.weight.shape), lin1.bias: db1, lin2.weight: dw2.view(lin2.weight.shape),
-                 lin2.bias: db2}
+        dpre = ops.dropout_act_bwd(dhd, h, drop.p if use_drop else 0.0, dseed, lrelu.negative_slope, row_idx=st["ridx"],
+                                   seed_dev=st["seed_dev"])
+        ops.conv2d_wgrad(dpre.view(1, 1, s, -1), x.view(1, 1, s, -1), wp1.cout, wp1.cin, 1, 1, out=st["dw1"])
+        ops.colsum(dpre, out=st["db1"])
         opt = self.optimizer_generator
+        multi = st.get("adam_multi")
+        if multi is not None:
+            table, bmap, nblk, group = multi
+            b1, b2 = group["betas"]
+            check(lib().zs3_adam_multi(P(table), P(bmap), I(nblk), F(group["lr"]), F(b1), F(b2), F(group["eps"]),
+                                       F(group["weight_decay"]), P(st["step_dev"]), stream()), "zs3_adam_multi")
+            ops.counter_add2(st["step_dev"], 1, st["seed_dev"], 1 << 24)
+            return
+        grads = {lin1.weight: st["dw1"], lin1.bias: st["db1"], lin2.weight: st["dw2"], lin2.bias: st["db2"]}
         for group in opt.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -147,8 +175,7 @@ class GMMNStep:
                 check(lib().zs3_adam_step(P(p), P(g.contiguous()), P(state["exp_avg"]), P(state["exp_avg_sq"]),
                                           ctypes.c_long(p.numel()), F(group["lr"]), F(b1), F(b2), F(group["eps"]),
                                           F(group["weight_decay"]), I(0), P(st["step_dev"]), stream()), "zs3_adam_step")
-        ops.counter_add(st["step_dev"], 1)
-        ops.counter_add(st["seed_dev"], 1 << 24)
+        ops.counter_add2(st["step_dev"], 1, st["seed_dev"], 1 << 24)
         self._resplit()
 
     def _run_sampled_update(self, training):

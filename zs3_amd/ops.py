@@ -171,7 +171,7 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
     return (out, part) if kw.get("bn_bwd") is not None else out
 
 
-def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1, prec=None, ci_read=None):
+def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1, prec=None, ci_read=None, out=None):
     """dy: NHWC [N,Ho,Wo,>=cout]; x: NHWC [N,H,W,>=cin] -> dw [cout, kh, kw, cin] (channels_last weight storage)."""
     require_gpu(dy, x)
     prec = prec or PREC_DEFAULT
@@ -181,7 +181,8 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
     lddy, ldx = _check_nhwc(dy), _check_nhwc(x)
     co_read = min(_round_up(cout, 4), lddy)
     ci_read = ci_read or min(_round_up(cin, 4), ldx)
-    dw = torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
+    assert dw.is_contiguous() and dw.numel() == cout * kh * kw * cin
     splitk, ws = ctypes.c_int(0), ctypes.c_long(0)
     lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
     work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
@@ -364,6 +365,35 @@ def uniform(shape, seed, device, out=None, seed_dev=None):
 
 def counter_add(counter, v=1):
     check(lib().zs3_counter_add(P(counter), ctypes.c_long(v), stream()), "zs3_counter_add")
+
+
+def counter_add2(c0, v0, c1, v1):
+    check(lib().zs3_counter_add2(P(c0), ctypes.c_long(v0), P(c1), ctypes.c_long(v1), stream()), "zs3_counter_add2")
+
+
+def gather_cat_noise(a, idx, ca, cb, ldo, n, seed, seed_dev=None):
+    """[a[idx] | U[0,1)^cb | 0] rows: zs3_gather_cat on a zs3_uniform tensor without materialising the noise."""
+    out = torch.empty((n, ldo), dtype=torch.float32, device=a.device)
+    check(lib().zs3_gather_cat_noise(P(a), I(a.stride(0)), P(idx), I(ca), I(cb), P(out), I(ldo), ctypes.c_long(n),
+                                     ctypes.c_ulonglong(seed), P(seed_dev), stream()), "zs3_gather_cat_noise")
+    return out
+
+
+def dropout_act_bwd(dy, h, p, seed, leak, row_idx=None, seed_dev=None):
+    m, c, ldd = _rows(dy)
+    out = torch.empty((m, c), dtype=torch.float32, device=dy.device)
+    check(lib().zs3_dropout_act_bwd(P(dy), I(ldd), P(h), I(_rows(h)[2]), P(out), I(c), ctypes.c_long(m), I(c), F(p),
+                                    ctypes.c_ulonglong(seed), P(row_idx), P(seed_dev), F(leak), stream()),
+          "zs3_dropout_act_bwd")
+    return out
+
+
+def colsum(x, out=None):
+    m, c, ld = _rows(x)
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib().zs3_colsum(P(x), I(ld), I(m), I(c), P(out), stream()), "zs3_colsum")
+    return out
 
 
 def nearest_rows(src_chw, size, ld=None):
