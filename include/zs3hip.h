@@ -137,6 +137,12 @@ int zs3_mmd_fwd(const float* gen, int ldg, const float* real, int ldr, int N, in
                 float* G, double* tile_ws, float* loss, void* stream);
 int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G, const float* loss,
                 const float* gout, float* dgen, int ldo, void* stream);
+/* zs3_mmd_bwd that takes the loss from zs3_mmd_fwd's tile_ws (zs3_mmd_fwd may then be called with loss = NULL) */
+int zs3_mmd_bwd_ws(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
+                   const double* tile_ws, const float* gout, float* dgen, int ldo, void* stream);
+/* end of one generator update: loss_ring[slot_dev[0]++] = MMD loss from tile_ws; step_dev[0] += 1; seed_dev[0] += seed_inc */
+int zs3_gmmn_update_epilogue(const double* tile_ws, int N, float* loss_ring, void* slot_dev, int ring_len, void* step_dev,
+                             void* seed_dev, long seed_inc, void* stream);
 
 /* ---- GMMN step helpers and optimisers (misc.hip) ---------------------------------------------- */
 /* nn.Dropout (aspp.py:100, decoder.py:19,23, gmmn.py:20): y = keep ? x/(1-p) : 0 with a counter-based mask
@@ -165,6 +171,9 @@ int zs3_adam_chunk(void);
 int zs3_adam_multi(const long* table, const int* blockmap, int nblocks, float lr, float b1, float b2, float eps, float wd,
                    const void* step_dev, void* stream);
 int zs3_counter_add2(void* c0, long v0, void* c1, long v1, void* stream);
+/* pix_local[j] = order[ridx[j]], pix_global[j] = pix_local[j] + base (the sampled rows of train_pascal_GMMN.py:229-231) */
+int zs3_sample_rows(const long* order, const long* ridx, long base, long* pix_local, long* pix_global, int s,
+                    void* stream);
 /* F.interpolate(mode="nearest") of one [C][H][W] image into pixel rows [ho*wo][ldo] (train_pascal_GMMN.py:175-195) */
 int zs3_nearest_rows(const float* src, int C, int H, int W, int ho, int wo, float* rows, int ldo, void* stream);
 /* out[r] = [a[idx[r]][0:Ca] | b[r][0:Cb] | 0...]: torch.cat((embd, noise), 1) of gmmn.py:44 fused with the class mask */

@@ -209,8 +209,20 @@ __global__ void mmd_finalize_kernel(const double* tile, int ntiles, int N, float
 
 // dgen[k][d] = gout/L * ( sum_j G[k][j] X[j][d] - rowsum_k(G) * gen[k][d] ),  k < N.  One wave per 32x32 tile.
 __global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const float* loss, const float* gout, float* dgen,
-                                                    int ldo) {
+                                                    int ldo, const double* tile_ws, int ntiles) {
   __shared__ float rs[32];
+  __shared__ float loss_sh;
+  if (tile_ws) {   // loss from the tile partial sums (same serial order as mmd_finalize_kernel): saves a launch in the chain
+    if (threadIdx.x == 0) {
+      double pos = 0.0, neg = 0.0;
+      for (int k = 0; k < ntiles; ++k) {
+        pos += tile_ws[2 * k];
+        neg += tile_ws[2 * k + 1];
+      }
+      loss_sh = sqrtf((float)((pos - neg) / ((double)p.N * (double)p.N)));
+    }
+    __syncthreads();
+  }
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int TD = (p.D + 31) / 32;
   const int tk = blockIdx.x / TD, td = blockIdx.x % TD;
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const floa
   rsum += __shfl_xor(rsum, 32, 64);
   if (h == 0) rs[r] = rsum;
   __syncthreads();
-  const float coef = gout[0] / loss[0];
+  const float coef = gout[0] / (tile_ws ? loss_sh : loss[0]);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int kl = (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -317,16 +329,55 @@ extern "C" int zs3_mmd_fwd(const float* gen, int ldg, const float* real, int ldr
   const int T = (2 * N + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(mmd_tile_kernel, dim3(T * T), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)tile_ws, T * T, N, loss);
+  if (loss) hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)tile_ws, T * T, N, loss);
+  return ZS3_LAUNCH_CHECK();
+}
+
+static int mmd_bwd_impl(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
+                        const float* loss, const double* tile_ws, const float* gout, float* dgen, int ldo, void* stream) {
+  MmdArgs a;
+  float one = 1.f;
+  if (mmd_fill(a, gen, ldg, real, ldr, N, D, &one, 1, (float*)G, nullptr)) return -1;
+  const int TK = (N + 31) / 32, TD = (D + 31) / 32, T = (2 * N + 31) / 32;
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(TK * TD), dim3(64), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo, tile_ws,
+                     T * T);
   return ZS3_LAUNCH_CHECK();
 }
 
 extern "C" int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
                            const float* loss, const float* gout, float* dgen, int ldo, void* stream) {
-  MmdArgs a;
-  float one = 1.f;
-  if (mmd_fill(a, gen, ldg, real, ldr, N, D, &one, 1, (float*)G, nullptr)) return -1;
-  const int TK = (N + 31) / 32, TD = (D + 31) / 32;
-  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(TK * TD), dim3(64), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo);
+  if (!loss) return -1;
+  return mmd_bwd_impl(gen, ldg, real, ldr, N, D, G, loss, nullptr, gout, dgen, ldo, stream);
+}
+
+extern "C" int zs3_mmd_bwd_ws(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
+                              const double* tile_ws, const float* gout, float* dgen, int ldo, void* stream) {
+  if (!tile_ws) return -1;
+  return mmd_bwd_impl(gen, ldg, real, ldr, N, D, G, nullptr, tile_ws, gout, dgen, ldo, stream);
+}
+
+// End of one captured generator update: the MMD loss value from the tile sums into loss_ring[slot++], Adam step count
+// and RNG stream position advanced -- one single-thread launch instead of finalize + two counter bumps + a copy.
+__global__ void gmmn_update_epilogue_kernel(const double* tile, int ntiles, int N, float* loss_ring, long* slot, int ring_len,
+                                            long* step, long* seed, long seed_inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double pos = 0.0, neg = 0.0;
+    for (int k = 0; k < ntiles; ++k) {
+      pos += tile[2 * k];
+      neg += tile[2 * k + 1];
+    }
+    const long sl = slot[0];
+    if (sl < ring_len) loss_ring[sl] = sqrtf((float)((pos - neg) / ((double)N * (double)N)));
+    slot[0] = sl + 1;
+    step[0] += 1;
+    seed[0] += seed_inc;
+  }
+}
+
+extern "C" int zs3_gmmn_update_epilogue(const double* tile_ws, int N, float* loss_ring, void* slot_dev, int ring_len,
+                                        void* step_dev, void* seed_dev, long seed_inc, void* stream) {
+  const int T = (2 * N + 31) / 32;
+  hipLaunchKernelGGL(gmmn_update_epilogue_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tile_ws, T * T, N, loss_ring,
+                     (long*)slot_dev, ring_len, (long*)step_dev, (long*)seed_dev, seed_inc);
   return ZS3_LAUNCH_CHECK();
 }

@@ -199,6 +199,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int ldx, in
   if (ty == 0 && c < C) out[c] = (red[tx] + red[64 + tx]) + (red[128 + tx] + red[192 + tx]);
 }
 
+// pix_local[j] = order[ridx[j]], pix_global[j] = pix_local[j] + base: the sampled pixel rows of one (image, class)
+__global__ void sample_rows_kernel(const long* order, const long* ridx, long base, long* pix_local, long* pix_global, int s) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < s) {
+    const long v = order[ridx[j]];
+    pix_local[j] = v;
+    pix_global[j] = v + base;
+  }
+}
+
 // Adam for several tensors in one launch; tensors with plane pointers (Linear weights [cout][cin]) also get their bf16
 // hi/lo operands rewritten in place (forward rows = cout, transposed rows = cin; layout of zs3_prep_weight).
 // table[e] = {p, g, m, v, n, f_pk, t_pk, cout, cin, cin_pad, cout_pad}; blockmap[b] = {entry, chunk}.
@@ -381,5 +391,13 @@ extern "C" int zs3_adam_multi(const long* table, const int* blockmap, int nblock
 
 extern "C" int zs3_counter_add2(void* c0, long v0, void* c1, long v1, void* stream) {
   hipLaunchKernelGGL(counter_add2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long*)c0, v0, (long*)c1, v1);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_sample_rows(const long* order, const long* ridx, long base, long* pix_local, long* pix_global, int s,
+                               void* stream) {
+  if (s <= 0) return 0;
+  hipLaunchKernelGGL(sample_rows_kernel, dim3((s + 255) / 256), dim3(256), 0, (hipStream_t)stream, order, ridx, base,
+                     pix_local, pix_global, s);
   return ZS3_LAUNCH_CHECK();
 }

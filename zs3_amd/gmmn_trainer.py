@@ -81,6 +81,7 @@ class GMMNStep:
             "pix_local": torch.zeros(s, **i64), "pix_global": torch.zeros(s, **i64), "ridx": torch.zeros(s, **i64),
             "z": torch.zeros((s, nz), **f32), "loss": torch.zeros(1, **f32), "one": torch.ones(1, **f32),
             "seed_dev": torch.zeros(1, **i64), "step_dev": torch.zeros(1, **i64),
+            "loss_ring": torch.zeros(4096, **f32), "slot_dev": torch.zeros(1, **i64),
             "wp1": ops.prep_weight(lin1.weight, need_t=True), "wp2": ops.prep_weight(lin2.weight, need_t=True),
             "ring": torch.zeros((512, s), dtype=torch.int64).pin_memory(), "ring_pos": 0,
             "seed_base": Fz.next_seed(), "shape": (b, npix),
@@ -142,10 +143,10 @@ class GMMNStep:
         gmat = torch.empty((2 * s, 2 * s), dtype=torch.float32, device=x.device)
         tile = torch.empty(2 * t * t, dtype=torch.float64, device=x.device)
         check(lib().zs3_mmd_fwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), self._sig, I(len(self.sigma)), P(gmat), P(tile),
-                                P(st["loss"]), stream()), "zs3_mmd_fwd")
+                                None, stream()), "zs3_mmd_fwd")          # the loss value is finalised by the update epilogue
         dgen = torch.empty_like(gen_s)
-        check(lib().zs3_mmd_bwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(st["loss"]), P(st["one"]), P(dgen), I(d),
-                                stream()), "zs3_mmd_bwd")
+        check(lib().zs3_mmd_bwd_ws(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(tile), P(st["one"]), P(dgen), I(d),
+                                   stream()), "zs3_mmd_bwd_ws")
         # generator backward on the sampled rows, gradients into static buffers
         wp1, wp2 = st["wp1"], st["wp2"]
         ops.conv2d_wgrad(dgen.view(1, 1, s, -1), hd.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1, out=st["dw2"])
@@ -162,7 +163,7 @@ class GMMNStep:
             b1, b2 = group["betas"]
             check(lib().zs3_adam_multi(P(table), P(bmap), I(nblk), F(group["lr"]), F(b1), F(b2), F(group["eps"]),
                                        F(group["weight_decay"]), P(st["step_dev"]), stream()), "zs3_adam_multi")
-            ops.counter_add2(st["step_dev"], 1, st["seed_dev"], 1 << 24)
+            self._epilogue(tile)
             return
         grads = {lin1.weight: st["dw1"], lin1.bias: st["db1"], lin2.weight: st["dw2"], lin2.bias: st["db2"]}
         for group in opt.param_groups:
@@ -175,8 +176,15 @@ class GMMNStep:
                 check(lib().zs3_adam_step(P(p), P(g.contiguous()), P(state["exp_avg"]), P(state["exp_avg_sq"]),
                                           ctypes.c_long(p.numel()), F(group["lr"]), F(b1), F(b2), F(group["eps"]),
                                           F(group["weight_decay"]), I(0), P(st["step_dev"]), stream()), "zs3_adam_step")
-        ops.counter_add2(st["step_dev"], 1, st["seed_dev"], 1 << 24)
+        self._epilogue(tile)
         self._resplit()
+
+    def _epilogue(self, tile):
+        """loss value -> loss_ring[slot++], Adam step and RNG position advanced: one launch"""
+        st = self._st
+        check(lib().zs3_gmmn_update_epilogue(P(tile), I(self.bsg), P(st["loss_ring"]), P(st["slot_dev"]),
+                                             I(st["loss_ring"].numel()), P(st["step_dev"]), P(st["seed_dev"]),
+                                             ctypes.c_long(1 << 24), stream()), "zs3_gmmn_update_epilogue")
 
     def _run_sampled_update(self, training):
         if not self.use_graph:
@@ -269,6 +277,8 @@ class GMMNStep:
         n_mmd = int(sum(1 for i in range(b) for c in range(255) if hist_h[i][c] > 0))
         mmd_losses = torch.zeros(max(n_mmd, 1), dtype=torch.float32, device=dev)
         mmd_slots, slot = [], 0
+        ring_slots, n_ring = [], 0
+        st["slot_dev"].zero_()
         for i in range(b):
             classes = [c for c in range(256) if hist_h[i][c] > 0]
             has_unseen = any(c in self.unseen for c in classes)
@@ -300,12 +310,13 @@ class GMMNStep:
                     st["ring_pos"] += 1
                     ring.copy_(ridx_cpu)
                     st["ridx"].copy_(ring, non_blocking=True)
-                    torch.index_select(idx_c, 0, st["ridx"], out=st["pix_local"])
-                    torch.add(st["pix_local"], i * npix, out=st["pix_global"])
+                    check(lib().zs3_sample_rows(P(idx_c), P(st["ridx"]), ctypes.c_long(i * npix), P(st["pix_local"]),
+                                                P(st["pix_global"]), I(self.bsg), stream()), "zs3_sample_rows")
                     if z_cpu is not None:
                         st["z"].copy_(z_cpu[ridx_cpu])
                     self._run_sampled_update(training)
-                    mmd_losses[slot:slot + 1].copy_(st["loss"])
+                    ring_slots.append((slot, n_ring))     # value lands in loss_ring[n_ring] (written by the update epilogue)
+                    n_ring += 1
                     mmd_slots.append((slot, len(classes)))
                     slot += 1
                     continue
@@ -338,6 +349,11 @@ class GMMNStep:
         closs = self.criterion(out, target)
         closs.backward()
         self.optimizer.step()
+        if ring_slots:
+            if n_ring > st["loss_ring"].numel():
+                raise RuntimeError("more generator updates in one step than the loss ring holds")
+            dst = torch.tensor([a_ for a_, _ in ring_slots], dtype=torch.int64, device=dev)
+            mmd_losses.index_copy_(0, dst, st["loss_ring"][:n_ring])
         vals = torch.cat((mmd_losses, closs.detach().reshape(1))).cpu()   # the single read-back of the step
         g_batch = sum(float(vals[sl]) / nuniq for sl, nuniq in mmd_slots)
         return g_batch, float(vals[-1]), out
