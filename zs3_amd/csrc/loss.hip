@@ -114,25 +114,32 @@ __device__ __forceinline__ const float* mmd_row(const MmdArgs& p, int r) {
   return r < p.N ? p.gen + (size_t)r * p.ldg : p.real + (size_t)(r - p.N) * p.ldr;
 }
 
-__global__ __launch_bounds__(64) void mmd_tile_kernel(const MmdArgs p) {
+// W waves per tile: wave w, lane-half h own the reduction indices [(2w+h)*seg, +seg), seg = D/(2W); the W partial
+// accumulators are added in wave order by wave 0 (deterministic).  W = 4 cuts the dependent load->MFMA chain of this
+// latency-bound kernel (64 tiles on 256 CUs) by four.
+template <int W>
+__global__ __launch_bounds__(64 * W) void mmd_tile_kernel(const MmdArgs p) {
   __shared__ float nrm[2][32];
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  __shared__ float nrm_part[W > 1 ? W : 1][2][32];
+  __shared__ float acc_part[W > 1 ? W - 1 : 1][16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int T = (2 * p.N + 31) / 32;
   const int ti = blockIdx.x / T, tj = blockIdx.x % T;
   const int ra = ti * 32 + r, rb = tj * 32 + r;
   const bool va = ra < 2 * p.N, vb = rb < 2 * p.N;
   const float* pa = mmd_row(p, va ? ra : 0);
   const float* pb = mmd_row(p, vb ? rb : 0);
-  const int half = p.D / 2;  // lane-half h owns k in [h*half, (h+1)*half)
+  const int seg = p.D / (2 * W);  // this (wave, lane-half) owns k in [(2w+h)*seg, +seg)
+  const int k0 = (2 * w + h) * seg;
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   float na = 0.f, nb = 0.f;
-  if ((half & 31) == 0 && ((p.ldg | p.ldr) & 3) == 0) {
+  if ((seg & 31) == 0 && ((p.ldg | p.ldr) & 3) == 0) {
     // each lane streams its own row in 128-byte pieces (8 x float4 for A and B), then feeds 32 MFMAs from registers
-    const float* qa = pa + h * half;
-    const float* qb = pb + h * half;
-    for (int c = 0; c < half; c += 32) {
+    const float* qa = pa + k0;
+    const float* qb = pb + k0;
+    for (int c = 0; c < seg; c += 32) {
       f32x4 av[8], bv[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -151,9 +158,9 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const MmdArgs p) {
     }
   } else {
 #pragma unroll 8
-    for (int s = 0; s < half; ++s) {
-      const float a = va ? pa[h * half + s] : 0.f;
-      const float b = vb ? pb[h * half + s] : 0.f;
+    for (int s = 0; s < seg; ++s) {
+      const float a = va ? pa[k0 + s] : 0.f;
+      const float b = vb ? pb[k0 + s] : 0.f;
       na = fmaf(a, a, na);
       nb = fmaf(b, b, nb);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -161,11 +168,40 @@ __global__ __launch_bounds__(64) void mmd_tile_kernel(const MmdArgs p) {
   }
   na += __shfl_xor(na, 32, 64);
   nb += __shfl_xor(nb, 32, 64);
-  if (h == 0) {
-    nrm[0][r] = na;
-    nrm[1][r] = nb;
+  if (W > 1) {
+    if (h == 0) {
+      nrm_part[w][0][r] = na;
+      nrm_part[w][1][r] = nb;
+    }
+    if (w > 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc_part[w - 1][q][lane] = acc[q];
+    }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int ww = 1; ww < W; ++ww)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] += acc_part[ww - 1][q][lane];
+    if (h == 0) {
+      float sa = nrm_part[0][0][r], sb = nrm_part[0][1][r];
+#pragma unroll
+      for (int ww = 1; ww < W; ++ww) {
+        sa += nrm_part[ww][0][r];
+        sb += nrm_part[ww][1][r];
+      }
+      nrm[0][r] = sa;
+      nrm[1][r] = sb;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the other lane-half's LDS writes are visible within the wave
+  } else {
+    if (h == 0) {
+      nrm[0][r] = na;
+      nrm[1][r] = nb;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int j = tj * 32 + r;  // column owned by this lane
   const float nj = nrm[1][r];
   const float invN2 = 1.f / ((float)p.N * (float)p.N);
@@ -207,11 +243,16 @@ __global__ void mmd_finalize_kernel(const double* tile, int ntiles, int N, float
   }
 }
 
-// dgen[k][d] = gout/L * ( sum_j G[k][j] X[j][d] - rowsum_k(G) * gen[k][d] ),  k < N.  One wave per 32x32 tile.
-__global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const float* loss, const float* gout, float* dgen,
-                                                    int ldo, const double* tile_ws, int ntiles) {
+// dgen[k][d] = gout/L * ( sum_j G[k][j] X[j][d] - rowsum_k(G) * gen[k][d] ),  k < N.  W waves per 32x32 tile, each
+// owning a slice of the reduction over j (see mmd_tile_kernel).
+template <int W>
+__global__ __launch_bounds__(64 * W) void mmd_bwd_kernel(const MmdArgs p, const float* loss, const float* gout, float* dgen,
+                                                        int ldo, const double* tile_ws, int ntiles) {
   __shared__ float rs[32];
+  __shared__ float rs_part[W > 1 ? W : 1][32];
+  __shared__ float acc_part[W > 1 ? W - 1 : 1][16][64];
   __shared__ float loss_sh;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   if (tile_ws) {   // loss from the tile partial sums (same serial order as mmd_finalize_kernel): saves a launch in the chain
     if (threadIdx.x == 0) {
       double pos = 0.0, neg = 0.0;
@@ -221,9 +262,7 @@ __global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const floa
       }
       loss_sh = sqrtf((float)((pos - neg) / ((double)p.N * (double)p.N)));
     }
-    __syncthreads();
   }
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int TD = (p.D + 31) / 32;
   const int tk = blockIdx.x / TD, td = blockIdx.x % TD;
   const int k = tk * 32 + r;
@@ -235,16 +274,17 @@ __global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const floa
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   float rsum = 0.f;
-  const int half = twoN / 2;  // = N
-  if ((half & 31) == 0) {
-    for (int c = 0; c < half; c += 32) {
+  const int seg = twoN / (2 * W);  // this (wave, lane-half) owns j in [(2w+h)*seg, +seg)
+  const int j0 = (2 * w + h) * seg;
+  if ((seg & 31) == 0) {
+    for (int c = 0; c < seg; c += 32) {
       f32x4 av[8];
       float bv[32];
 #pragma unroll
       for (int t = 0; t < 8; ++t)
-        av[t] = vk ? *reinterpret_cast<const f32x4*>(grow + h * half + c + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+        av[t] = vk ? *reinterpret_cast<const f32x4*>(grow + j0 + c + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 32; ++t) bv[t] = vd ? mmd_row(p, h * half + c + t)[d] : 0.f;
+      for (int t = 0; t < 32; ++t) bv[t] = vd ? mmd_row(p, j0 + c + t)[d] : 0.f;
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
         const float a = av[t >> 2][t & 3];
@@ -254,8 +294,8 @@ __global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const floa
     }
   } else {
 #pragma unroll 8
-    for (int s = 0; s < half; ++s) {
-      const int j = h * half + s;
+    for (int s = 0; s < seg; ++s) {
+      const int j = j0 + s;
       const float a = vk ? grow[j] : 0.f;
       const float b = vd ? mmd_row(p, j)[d] : 0.f;
       rsum += a;
@@ -263,8 +303,26 @@ __global__ __launch_bounds__(64) void mmd_bwd_kernel(const MmdArgs p, const floa
     }
   }
   rsum += __shfl_xor(rsum, 32, 64);
-  if (h == 0) rs[r] = rsum;
+  if (h == 0) rs_part[w][r] = rsum;
+  if (W > 1 && w > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc_part[w - 1][q][lane] = acc[q];
+  }
   __syncthreads();
+  if (w > 0) return;
+  if (W > 1) {
+#pragma unroll
+    for (int ww = 1; ww < W; ++ww)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] += acc_part[ww - 1][q][lane];
+  }
+  if (h == 0) {
+    float t = rs_part[0][r];
+#pragma unroll
+    for (int ww = 1; ww < W; ++ww) t += rs_part[ww][r];
+    rs[r] = t;
+  }
+  __builtin_amdgcn_wave_barrier();
   const float coef = gout[0] / (tile_ws ? loss_sh : loss[0]);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
@@ -328,7 +386,10 @@ extern "C" int zs3_mmd_fwd(const float* gen, int ldg, const float* real, int ldr
   if (mmd_fill(a, gen, ldg, real, ldr, N, D, sigma, nsig, G, tile_ws)) return -1;
   const int T = (2 * N + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mmd_tile_kernel, dim3(T * T), dim3(64), 0, st, a);
+  if (D % 256 == 0 && ((ldg | ldr) & 3) == 0)
+    hipLaunchKernelGGL(mmd_tile_kernel<4>, dim3(T * T), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(mmd_tile_kernel<1>, dim3(T * T), dim3(64), 0, st, a);
   if (loss) hipLaunchKernelGGL(mmd_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)tile_ws, T * T, N, loss);
   return ZS3_LAUNCH_CHECK();
 }
@@ -339,8 +400,12 @@ static int mmd_bwd_impl(const float* gen, int ldg, const float* real, int ldr, i
   float one = 1.f;
   if (mmd_fill(a, gen, ldg, real, ldr, N, D, &one, 1, (float*)G, nullptr)) return -1;
   const int TK = (N + 31) / 32, TD = (D + 31) / 32, T = (2 * N + 31) / 32;
-  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(TK * TD), dim3(64), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo, tile_ws,
-                     T * T);
+  if (N % 128 == 0)
+    hipLaunchKernelGGL(mmd_bwd_kernel<4>, dim3(TK * TD), dim3(256), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo, tile_ws,
+                       T * T);
+  else
+    hipLaunchKernelGGL(mmd_bwd_kernel<1>, dim3(TK * TD), dim3(64), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo, tile_ws,
+                       T * T);
   return ZS3_LAUNCH_CHECK();
 }
 
