@@ -12,7 +12,8 @@ import torch
 from ._lib import F, I, P, check, lib, require_gpu, stream
 
 PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs
-PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event) per conv launch
+PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event, tile_cfg) per conv launch
+PROFILE_CFGS = None   # optional set of tile_cfg values to restrict the recording to (event pairs serialise kernel boundaries)
 
 
 def pick_tile(m, ncols, k=0):
@@ -126,7 +127,8 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if want_stats or bn_bwd is not None:
         mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
         stat = torch.empty((mt, 2, ncols), dtype=torch.float32, device=x.device)
-    if PROFILE is not None:
+    prof = PROFILE is not None and (PROFILE_CFGS is None or tile_cfg in PROFILE_CFGS)
+    if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if bn_bwd is not None:
@@ -145,10 +147,10 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
                                    I(pad_w), I(dil), I(ncols), I(ldy), I(ldr), I(act), F(leak), I(int(accumulate)),
                                    I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), stream()),
               "zs3_conv_igemm")
-    if PROFILE is not None:
+    if prof:
         e1.record()
         PROFILE.append(("conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
-                        2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1))
+                        2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
 
 
