@@ -9,8 +9,8 @@ train_pascal.py (forward, CE, backward, SGD; base_trainer.py:16-20) on synthetic
 gradients are SUM all-reduced over RCCL while backward runs (zs3_amd.parallel.GradSync).  The GMMN step
 (configs[2], train_pascal_GMMN.py:139-268) is timed after the main loop and reported under "gmmn".
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the 128x128 implicit-GEMM convolution)
-with HIP events recorded around every launch inside the timed region; `cpu_baseline` times the CPU oracle
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the LDS-DMA 256x128 implicit-GEMM convolution)
+with HIP events recorded around its launches inside the timed region (every 5th timed step); `cpu_baseline` times the CPU oracle
 (oracle/zs3_oracle, the checked restatement of the reference) on the host cores for a bounded sample.
 """
 import argparse
@@ -21,6 +21,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / cross-process device memory on this driver
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
