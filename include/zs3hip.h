@@ -120,6 +120,13 @@ int zs3_bilinear_fwd(const float* x, int ldx, float* out, int ldo, int N, int H,
                      void* stream);
 int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int H, int W, int Ho, int Wo, int C,
                      int accumulate, void* stream);
+/* Validation without shipping logits to the host (train_pascal.py:130-134, Evaluator._generate_matrix metrics.py:73-79):
+ * conf[gt*C + pred] += 1 for every target pixel with 0 <= gt < C, pred = first argmax over the C channels of x
+ * [N,H,W,C] bilinearly resized (align_corners=True, same arithmetic as zs3_bilinear_fwd) to Ho x Wo -- pass the
+ * low-resolution logits and the full-resolution label map and the upsampled logits never exist.  target: float32 or
+ * int64 [N,Ho,Wo]; conf: C*C int64 counters, accumulated (zero them first). */
+int zs3_argmax_confusion(const float* x, int ldx, int N, int H, int W, int C, const void* target, int target_is_i64,
+                         int Ho, int Wo, void* conf, void* stream);
 
 /* ---- losses (loss.hip) ------------------------------------------------------------------------ */
 /* SegmentationLosses.CrossEntropyLoss (zs3/utils/loss.py:31-46): logits [P][ld] (P = B*H*W pixels, C classes),

@@ -23,4 +23,6 @@ from .steps import (  # noqa: F401
     nearest_index,
     confusion_matrix,
     miou_from_confusion,
+    pixel_accuracy,
+    fw_iou,
 )

@@ -40,6 +40,21 @@ def miou_from_confusion(cm):
     return float(np.nanmean(np.nan_to_num(iou))), iou
 
 
+def pixel_accuracy(cm):
+    """metrics.py:11-12: trace / total."""
+    cm = np.asarray(cm, dtype=np.float64)
+    return float(np.diag(cm).sum() / cm.sum())
+
+
+def fw_iou(cm):
+    """metrics.py:52-59: sum over classes with freq > 0 of freq * iou."""
+    cm = np.asarray(cm, dtype=np.float64)
+    freq = cm.sum(1) / cm.sum()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = np.diag(cm) / (cm.sum(1) + cm.sum(0) - np.diag(cm))
+    return float((freq[freq > 0] * iou[freq > 0]).sum())
+
+
 # ----------------------------------------------------------------------------- synthetic data
 def nearest_index(out_size, in_size):
     """Source index of F.interpolate(mode='nearest'): floor(i * in/out) (used at train_pascal_GMMN.py:175-186)."""

@@ -133,3 +133,33 @@ def test_lr_scheduler_and_synthetic_batch(golden):
     b = zo.make_synthetic_batch(4, 65, seed=5, with_label_emb=True)
     for k in ("image", "label", "table", "label_emb"):
         assert torch.equal(a[k], b[k]), k   # the product's generator and the oracle's produce identical batches
+
+
+def test_evaluator_matches_the_reference_evaluator():
+    """zs3_amd.utils.metrics.Evaluator (host path) against zs3/utils/metrics.py run in the build container
+    (tests/golden/misc.npz): same confusion matrix, same return tuples with and without the seen/unseen split"""
+    import os
+    import numpy as np
+    from zs3_amd.utils.metrics import Evaluator
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "misc.npz"))
+    gt, pred = g["cm_gt"].astype(np.int64), g["cm_pred"].astype(np.int64)
+    seen = [c for c in range(21) if c not in (10, 14)]
+    ev = Evaluator(21, seen, [10, 14])
+    ev.add_batch(gt[:2], pred[:2])
+    ev.add_batch(torch.from_numpy(gt[2:]), torch.from_numpy(pred[2:]))     # CPU tensors take the host path too
+    assert np.array_equal(ev.confusion_matrix, g["cm"])
+    miou, by_class, miou_seen, miou_unseen = ev.Mean_Intersection_over_Union()
+    assert miou == float(g["miou"]) and miou_seen == float(g["miou_seen"]) and miou_unseen == float(g["miou_unseen"])
+    assert np.array_equal(by_class, g["miou_by_class"], equal_nan=True)
+    assert np.array_equal(np.array(ev.Pixel_Accuracy()), g["pix_acc"])
+    acc_cls, acc_by_class, acc_seen, acc_unseen = ev.Pixel_Accuracy_Class()
+    assert np.array_equal(np.array([acc_cls, acc_seen, acc_unseen]), g["pix_acc_class"])
+    assert np.array_equal(acc_by_class, g["pix_acc_by_class"], equal_nan=True)
+    assert np.array_equal(np.array(ev.Frequency_Weighted_Intersection_over_Union()), g["fwiou"])
+    plain = Evaluator(21)
+    plain.add_batch(gt, pred)
+    got = [plain.Pixel_Accuracy(), plain.Pixel_Accuracy_Class()[0], plain.Mean_Intersection_over_Union()[0],
+           plain.Frequency_Weighted_Intersection_over_Union()]
+    assert np.array_equal(np.array(got), g["plain"])
+    plain.reset()
+    assert plain.confusion_matrix.sum() == 0

@@ -260,3 +260,33 @@ def test_dropout_statistics_and_backward(dev):
     Fz.manual_seed(123)
     y2 = Fz.dropout(x, 0.5, True)
     assert torch.equal(y2, y)  # the mask is a pure function of the seed
+
+
+@pytest.mark.parametrize("classes,hw,HW", [(21, (33, 33), (129, 129)), (60, (17, 19), (65, 73)), (21, (40, 40), (40, 40))])
+def test_fused_upsample_argmax_confusion(dev, classes, hw, HW):
+    """zs3_argmax_confusion (bilinear align_corners upsample + argmax + histogram in one kernel) equals the
+    CPU oracle's confusion matrix of argmax(our own upsampled logits) exactly -- float and int64 labels, ignore label 255,
+    low- and full-resolution logits"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import numpy as np
+    import zs3_oracle as zo
+    from zs3_amd import functional as Fz, ops
+    from zs3_amd.utils.metrics import Evaluator
+    g = torch.Generator().manual_seed(classes + hw[0])
+    b = 3
+    logits = torch.randn(b, classes, *hw, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gt = torch.randint(0, classes, (b, *HW), generator=g)
+    gt[0, :5] = 255
+    up = ops.nchw(Fz.bilinear(ops.nhwc(logits), HW)) if hw != HW else logits
+    pred = up.argmax(1).cpu().numpy()
+    want = zo.confusion_matrix(gt.numpy(), pred, classes)
+    for tgt in (gt.float().to(dev), gt.to(dev)):
+        ev = Evaluator(classes)
+        ev.add_batch_logits(tgt, logits)
+        ev.add_batch_logits(tgt, logits)            # accumulates
+        assert np.array_equal(ev.confusion_matrix, 2.0 * want)
+        ev.reset()
+        ev.add_batch(tgt, up.argmax(1))             # device labels + device predictions
+        assert np.array_equal(ev.confusion_matrix, want)
+    assert abs(Evaluator(classes).Pixel_Accuracy() != 0)   # nan on an empty matrix, like the reference

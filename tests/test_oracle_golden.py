@@ -215,6 +215,8 @@ def test_host_logic_matches_reference(golden):
     seen = [c for c in range(21) if c not in (10, 14)]
     assert abs(np.nanmean(np.nan_to_num(by_class[seen])) - float(g["miou_seen"])) < 1e-12
     assert abs(np.nanmean(np.nan_to_num(by_class[[10, 14]])) - float(g["miou_unseen"])) < 1e-12
+    assert abs(zo.pixel_accuracy(cm) - float(g["pix_acc"][0])) < 1e-12
+    assert abs(zo.fw_iou(cm) - float(g["fwiou"][0])) < 1e-12
     assert np.array_equal(zo.nearest_index(129, 513), g["nearest_513_129"])
     assert np.array_equal(zo.nearest_index(17, 65), g["nearest_65_17"])
     assert list(zo.nearest_index(129, 513)[:4]) == [0, 3, 7, 11]

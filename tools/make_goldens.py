@@ -310,11 +310,21 @@ def g_misc():
     ev = RefEvaluator(21, [c for c in range(21) if c not in (10, 14)], [10, 14])
     ev.add_batch(gt, pred)
     miou, by_class, miou_seen, miou_unseen = ev.Mean_Intersection_over_Union()
+    acc, acc_seen, acc_unseen = ev.Pixel_Accuracy()
+    acc_cls, acc_by_class, acc_cls_seen, acc_cls_unseen = ev.Pixel_Accuracy_Class()
+    fw, fw_seen, fw_unseen = ev.Frequency_Weighted_Intersection_over_Union()
+    ev_plain = RefEvaluator(21)            # no seen/unseen split: scalar / 2-tuple return forms
+    ev_plain.add_batch(gt, pred)
     near = torch.nn.functional.interpolate(torch.arange(513.0).view(1, 1, 1, 513), size=(1, 129), mode="nearest").view(-1)
     near65 = torch.nn.functional.interpolate(torch.arange(65.0).view(1, 1, 1, 65), size=(1, 17), mode="nearest").view(-1)
     save("misc.npz", poly_lrs=np.array(lrs), cm_gt=gt.astype(np.uint8), cm_pred=pred.astype(np.uint8),
          cm=ev.confusion_matrix, miou=np.float64(miou), miou_by_class=by_class, miou_seen=np.float64(miou_seen),
-         miou_unseen=np.float64(miou_unseen), nearest_513_129=near.numpy().astype(np.int64),
+         miou_unseen=np.float64(miou_unseen),
+         pix_acc=np.array([acc, acc_seen, acc_unseen]), pix_acc_class=np.array([acc_cls, acc_cls_seen, acc_cls_unseen]),
+         pix_acc_by_class=acc_by_class, fwiou=np.array([fw, fw_seen, fw_unseen]),
+         plain=np.array([ev_plain.Pixel_Accuracy(), ev_plain.Pixel_Accuracy_Class()[0],
+                         ev_plain.Mean_Intersection_over_Union()[0], ev_plain.Frequency_Weighted_Intersection_over_Union()]),
+         nearest_513_129=near.numpy().astype(np.int64),
          nearest_65_17=near65.numpy().astype(np.int64))
 
 

@@ -86,6 +86,11 @@ __device__ __forceinline__ void src_index(int o, float scale, int in, int& i0, i
   lam = s - (float)i0;
 }
 
+// one bilinear sample; explicit FMA chain so that bilinear_fwd_kernel and the fused upsample+argmax kernel round identically
+__device__ __forceinline__ float bilerp(float w00, float w01, float w10, float w11, float a, float b, float c, float d) {
+  return fmaf(w11, d, fmaf(w10, c, fmaf(w01, b, w00 * a)));
+}
+
 struct ResizeArgs {
   const float* x;
   float* out;
@@ -112,15 +117,18 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const ResizeArgs p) {
     const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
     if (vec) {
       const int c = ci * 4;
-      f32x4 v = w00 * *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w0) * p.ldx + c) +
-                w01 * *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w1) * p.ldx + c) +
-                w10 * *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w0) * p.ldx + c) +
-                w11 * *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w1) * p.ldx + c);
+      const f32x4 a00 = *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w0) * p.ldx + c);
+      const f32x4 a01 = *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w1) * p.ldx + c);
+      const f32x4 a10 = *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w0) * p.ldx + c);
+      const f32x4 a11 = *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w1) * p.ldx + c);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = bilerp(w00, w01, w10, w11, a00[e], a01[e], a10[e], a11[e]);
       *reinterpret_cast<f32x4*>(p.out + m * p.ldo + c) = v;
     } else {
-      float v = w00 * b[((long)h0 * p.W + w0) * p.ldx + ci] + w01 * b[((long)h0 * p.W + w1) * p.ldx + ci] +
-                w10 * b[((long)h1 * p.W + w0) * p.ldx + ci] + w11 * b[((long)h1 * p.W + w1) * p.ldx + ci];
-      p.out[m * p.ldo + ci] = v;
+      p.out[m * p.ldo + ci] = bilerp(w00, w01, w10, w11, b[((long)h0 * p.W + w0) * p.ldx + ci],
+                                     b[((long)h0 * p.W + w1) * p.ldx + ci], b[((long)h1 * p.W + w0) * p.ldx + ci],
+                                     b[((long)h1 * p.W + w1) * p.ldx + ci]);
     }
   }
 }
@@ -209,6 +217,52 @@ extern "C" int zs3_maxpool_bwd(const float* dy, int ldd, const void* idx, float*
   return ZS3_LAUNCH_CHECK();
 }
 
+// Validation (train_pascal.py:130-134 + metrics.py:73-82) without the [B,C,H,W] logits ever leaving the GPU -- or, for
+// low-resolution logits, ever existing: per output pixel the C class scores are bilinearly sampled from x [N,H,W,C]
+// (align_corners=True, the arithmetic of bilinear_fwd_kernel; H == Ho samples exactly), the first maximum is the
+// prediction (numpy argmax), and conf[gt*C + pred] is counted for 0 <= gt < C.  Per-block LDS histogram, then integer
+// atomics: the result is exact and order-independent.
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(const ResizeArgs p, const T* target,
+                                                              unsigned long long* conf) {
+  extern __shared__ unsigned hist[];
+  const int nbin = p.C * p.C;
+  for (int i = threadIdx.x; i < nbin; i += 256) hist[i] = 0u;
+  __syncthreads();
+  const long total = (long)p.N * p.Ho * p.Wo;
+  for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (long)gridDim.x * blockDim.x) {
+    const double gtd = (double)target[m];
+    if (!(gtd >= 0.0 && gtd < (double)p.C)) continue;
+    const int gt = (int)gtd;   // astype(int) truncation of metrics.py:75
+    const int ow = (int)(m % p.Wo);
+    const long r = m / p.Wo;
+    const int oh = (int)(r % p.Ho), n = (int)(r / p.Ho);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index(oh, p.sh, p.H, h0, h1, lh);
+    src_index(ow, p.sw, p.W, w0, w1, lw);
+    const float* b = p.x + (long)n * p.H * p.W * p.ldx;
+    const float* q00 = b + ((long)h0 * p.W + w0) * p.ldx;
+    const float* q01 = b + ((long)h0 * p.W + w1) * p.ldx;
+    const float* q10 = b + ((long)h1 * p.W + w0) * p.ldx;
+    const float* q11 = b + ((long)h1 * p.W + w1) * p.ldx;
+    const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
+    int best = 0;
+    float bv = bilerp(w00, w01, w10, w11, q00[0], q01[0], q10[0], q11[0]);
+    for (int c = 1; c < p.C; ++c) {
+      const float v = bilerp(w00, w01, w10, w11, q00[c], q01[c], q10[c], q11[c]);
+      if (v > bv) {
+        bv = v;
+        best = c;
+      }
+    }
+    atomicAdd(&hist[gt * p.C + best], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nbin; i += 256)
+    if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+
 static ResizeArgs make_resize(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int Ho, int Wo, int C,
                               int accumulate) {
   ResizeArgs a;
@@ -234,5 +288,24 @@ extern "C" int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, 
   ResizeArgs a = make_resize(dout, ldd, dx, ldo, N, H, W, Ho, Wo, C, accumulate);
   long total = (long)N * H * W * ((C % 4 == 0 && ldd % 4 == 0 && ldo % 4 == 0) ? C / 4 : C);
   hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+/* conf[gt][pred] += 1 over all N*Ho*Wo target pixels with 0 <= gt < C; pred = argmax_c of x [N,H,W,C] bilinearly
+ * resized (align_corners=True) to Ho x Wo.  conf: C*C int64 counters (caller zeroes them). */
+extern "C" int zs3_argmax_confusion(const float* x, int ldx, int N, int H, int W, int C, const void* target,
+                                    int target_is_i64, int Ho, int Wo, void* conf, void* stream) {
+  if (C < 1 || C > 128 || N < 1) return -1;
+  ResizeArgs a = make_resize(x, ldx, nullptr, 0, N, H, W, Ho, Wo, C, 0);
+  const long total = (long)N * Ho * Wo;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const size_t lds = (size_t)C * C * sizeof(unsigned);
+  if (target_is_i64)
+    hipLaunchKernelGGL(argmax_confusion_kernel<long>, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, a,
+                       (const long*)target, (unsigned long long*)conf);
+  else
+    hipLaunchKernelGGL(argmax_confusion_kernel<float>, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, a,
+                       (const float*)target, (unsigned long long*)conf);
   return ZS3_LAUNCH_CHECK();
 }
