@@ -32,14 +32,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward_nhwc(self, x):
-        if self.downsample is None:
-            # identity block: conv1's node also hands the input through as the skip tensor, so that the skip gradient
-            # comes back to it and is accumulated inside its dgrad epilogue (no separate add kernel in backward)
-            # ... and, being the only consumer of x, its dgrad also sums the previous block's bn3 backward statistics
-            y, skip = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU, pass_through=True, input_has_one_consumer=True)
-        else:
-            y = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU)
-            skip = self.downsample[0].forward_nhwc(x, self.downsample[1])
+        # conv1's node also hands the input through (an alias of x) as the tensor the skip path consumes, so that the skip
+        # path's gradient comes back to conv1 and is accumulated inside its dgrad epilogue -- no separate add kernel in
+        # backward for the identity blocks, and none for the projection blocks either (the downsample conv's dgrad is the
+        # incoming skip gradient there).  Being the only consumer of x this way, conv1's dgrad also sums the previous
+        # block's bn3 backward statistics.
+        y, skip = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU, pass_through=True, input_has_one_consumer=True)
+        if self.downsample is not None:
+            skip = self.downsample[0].forward_nhwc(skip, self.downsample[1])
         y = self.conv2.forward_nhwc(y, self.bn2, act=Fz.ACT_RELU, input_has_one_consumer=True)
         return self.conv3.forward_nhwc(y, self.bn3, residual=skip, act=Fz.ACT_RELU,   # bn3 + add + relu in one pass
                                        input_has_one_consumer=True)
