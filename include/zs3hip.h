@@ -49,16 +49,20 @@ int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scal
                    int ncols, int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec,
                    int tile_cfg, const void* zero_page, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
-/* zs3_conv_igemm (no affine / activation) whose epilogue also produces the BatchNorm-backward sums of the layer
- * the output gradient belongs to: bn_partial[mtiles][2][ncols] = (sum dz, sum dz*xhat) per row tile, with
- * dz = stored value (after `res` / accumulate) * ReLU mask and xhat = (bn_y - bn_mean) * bn_invstd.  Mask: mask_bits
- * ([M][ncols/4] sign bytes of zs3_affine_act), else bn_y*mask_scale + mask_shift > 0, else none.  Saves the separate
- * zs3_bn_bwd_stats pass (one full read of the gradient) at resnet.py:33-53 / aspp.py / decoder.py backward. */
-int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const float* res, int N, int H, int W, int Ho,
-                           int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w,
-                           int dil, int ncols, int ldy, int ldr, int accumulate, int dgrad, int prec, int tile_cfg,
-                           const void* zero_page, const float* bn_y, int bn_ldy, const float* bn_mean,
-                           const float* bn_invstd, const float* mask_scale, const float* mask_shift,
+/* zs3_conv_igemm (no affine / activation) with the two backward-pass epilogue fusions of the residual network:
+ * (1) bn_partial != NULL: the epilogue also produces the BatchNorm-backward sums of the layer the output gradient belongs
+ *     to: bn_partial[mtiles][2][ncols] = (sum dz, sum dz*xhat) per row tile, with dz = stored value * ReLU mask and
+ *     xhat = (bn_y - bn_mean) * bn_invstd.  Mask: mask_bits ([M][ncols/4] sign bytes of zs3_affine_act), else
+ *     bn_y*mask_scale + mask_shift > 0, else none.  Saves the separate zs3_bn_bwd_stats pass (a full read of the gradient).
+ * (2) res_mask_bits != NULL: `res` is added through a ReLU mask (sign bytes [M][ncols/4]): the skip gradient of a residual
+ *     block, (block-output gradient) * mask, is taken from the block-output gradient itself (res may alias y) instead of
+ *     a copy written by zs3_bn_act_bwd.
+ * resnet.py:33-53 / aspp.py / decoder.py backward. */
+int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const float* res, const unsigned char* res_mask_bits,
+                           int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW,
+                           int stride, int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int accumulate, int dgrad,
+                           int prec, int tile_cfg, const void* zero_page, const float* bn_y, int bn_ldy,
+                           const float* bn_mean, const float* bn_invstd, const float* mask_scale, const float* mask_shift,
                            const unsigned char* mask_bits, float* bn_partial, void* stream);
 
 /* ---- weight gradient ------------------------------------------------------------------------- */

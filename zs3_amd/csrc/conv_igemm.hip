@@ -50,6 +50,9 @@ struct ConvArgs {
   const unsigned char* bs_mbits;  // ... or sign bits [M][ncols/4] (residual layers)
   float* bs_partial;
   int bs_ldy;
+  // optional ReLU mask applied to `res` before it is added (sign bytes [M][ncols/4]): the skip gradient of a residual
+  // block is (block-output gradient) * mask, taken straight from the block-output gradient instead of a stored copy
+  const unsigned char* res_mbits;
 };
 
 // Rows [0, nrows) of an LDS-staged output tile -> global memory as dwordx4 per lane, with the fused epilogue (affine,
@@ -76,7 +79,15 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
     if (affine) v = v * sc + sh;
     float* dst = p.y + (size_t)row * p.ldy + col;
     if (vec) {
-      if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+      if (p.res) {
+        f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+        if (p.res_mbits) {
+          const unsigned mb = p.res_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rv[e] = (mb >> e) & 1u ? rv[e] : 0.f;
+        }
+        v = v + rv;
+      }
       if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -1138,12 +1149,13 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
                            int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec, int tile_cfg,
                            const void* zero_page, void* stream, const float* bs_y, int bs_ldy, const float* bs_mean,
                            const float* bs_istd, const float* bs_msc, const float* bs_msh,
-                           const unsigned char* bs_mbits, float* bs_partial) {
+                           const unsigned char* bs_mbits, float* bs_partial, const unsigned char* res_mbits) {
   if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 1 && prec != 3)) return -1;
   if (stride < 1 || (stride & (stride - 1)) != 0 || zero_page == nullptr) return -1;
   if (((uintptr_t)x & 15) || ((uintptr_t)w_pk & 15) || ((uintptr_t)zero_page & 15)) return -2;
   if (bs_partial && (!bs_y || !bs_mean || !bs_istd || (bs_ldy & 3) || (ncols & 3) || (ldy & 3) || (res && (ldr & 3))))
     return -6;   // the fused BN-backward sums need the vectorised store path
+  if (res_mbits && (!res || (ncols & 3) || (ldy & 3) || (ldr & 3))) return -6;
   ConvArgs a;
   a.x = x; a.w_pk = (const unsigned short*)w_pk; a.y = y;
   a.scale = scale; a.shift = shift; a.res = res; a.stat_partial = stat_partial;
@@ -1154,7 +1166,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
   a.act = act; a.accumulate = accumulate; a.dgrad = dgrad; a.leak = leak;
   a.zero = (const float*)zero_page;
   a.bs_y = bs_y; a.bs_ldy = bs_ldy; a.bs_mean = bs_mean; a.bs_istd = bs_istd; a.bs_msc = bs_msc; a.bs_msh = bs_msh;
-  a.bs_mbits = bs_mbits; a.bs_partial = bs_partial;
+  a.bs_mbits = bs_mbits; a.bs_partial = bs_partial; a.res_mbits = res_mbits;
   a.stride_log2 = 0;
   while ((1 << a.stride_log2) < stride) ++a.stride_log2;
   if (a.M <= 0 || ncols <= 0) return 0;
@@ -1188,18 +1200,19 @@ extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const 
                               int accumulate, int dgrad, int prec, int tile_cfg, const void* zero_page, void* stream) {
   return conv_igemm_impl(x, w_pk, y, scale, shift, res, stat_partial, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
                          stride, pad_h, pad_w, dil, ncols, ldy, ldr, act, leak, accumulate, dgrad, prec, tile_cfg,
-                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-extern "C" int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const float* res, int N, int H, int W,
-                                      int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
-                                      int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int accumulate,
-                                      int dgrad, int prec, int tile_cfg, const void* zero_page, const float* bn_y,
-                                      int bn_ldy, const float* bn_mean, const float* bn_invstd,
-                                      const float* mask_scale, const float* mask_shift,
+extern "C" int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const float* res,
+                                      const unsigned char* res_mask_bits, int N, int H, int W, int Ho, int Wo, int cin_pad,
+                                      int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w, int dil,
+                                      int ncols, int ldy, int ldr, int accumulate, int dgrad, int prec, int tile_cfg,
+                                      const void* zero_page, const float* bn_y, int bn_ldy, const float* bn_mean,
+                                      const float* bn_invstd, const float* mask_scale, const float* mask_shift,
                                       const unsigned char* mask_bits, float* bn_partial, void* stream) {
-  if (!bn_partial) return -1;
+  if (!bn_partial && !res_mask_bits) return -1;
   return conv_igemm_impl(x, w_pk, y, nullptr, nullptr, res, nullptr, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
                          stride, pad_h, pad_w, dil, ncols, ldy, ldr, 0, 0.f, accumulate, dgrad, prec, tile_cfg, zero_page,
-                         stream, bn_y, bn_ldy, bn_mean, bn_invstd, mask_scale, mask_shift, mask_bits, bn_partial);
+                         stream, bn_y, bn_ldy, bn_mean, bn_invstd, mask_scale, mask_shift, mask_bits, bn_partial,
+                         res_mask_bits);
 }

@@ -22,6 +22,8 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # next to the dgrad / BatchNorm chain; the main stream joins it once, at the end of backward.
 WGRAD_SIDE_STREAM = True
 FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
+LAZY_SKIP_GRAD = True      # identity blocks: the skip gradient dA*mask is applied by conv1's dgrad epilogue, never stored
+_lazy_skip = {}            # data_ptr of a block-output gradient -> (tensor, sign bits) it still has to be masked with
 _side = {}
 _join_armed = [False]
 
@@ -217,6 +219,10 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.bn_training = bool(bn is not None and bn["training"])
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
+        # identity block whose skip tensor is conv1's pass-through alias: hand the *unmasked* output gradient back as the
+        # skip gradient and let conv1's dgrad epilogue apply the ReLU mask (saves writing and re-reading dz)
+        ctx.lazy_dres = bool(LAZY_SKIP_GRAD and residual is not None and mbits is not None and act == ACT_RELU and
+                             bn is not None and out is None and getattr(residual, "_zs3_skip_alias", False))
         ctx.x_shape = tuple(x.shape)
         # ReLU mask in backward: recomputed from y (y*scale + shift > 0) when there is no residual, so `a` is not re-read
         ctx.mask_from_y = bool(bn is not None and y is not None and act == ACT_RELU and residual is None)
@@ -245,7 +251,8 @@ class _ConvBnAct(torch.autograd.Function):
         dA = _dense_rows(dA)
         wp = weight_planes(weight, need_t=True)
         dgamma = dbeta = dbias = dres = None
-        if ctx.has_res and ctx.needs_input_grad[5]:
+        lazy = ctx.lazy_dres and ctx.has_bn and ctx.needs_input_grad[5] and ops._rows(dA)[2] == dA.shape[-1]
+        if ctx.has_res and ctx.needs_input_grad[5] and not lazy:
             dres = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
         m = dA.shape[0] * dA.shape[1] * dA.shape[2] if dA.dim() == 4 else dA.shape[0]
         if ctx.has_bn:
@@ -270,6 +277,11 @@ class _ConvBnAct(torch.autograd.Function):
                 c1, c2 = (fin[2], fin[3]) if ctx.bn_training else (None, None)
             dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, dres=dres, act=act, leak=leak, mask_scale=msc,
                                 mask_shift=msh, mask_bits=mbits)
+            if lazy:
+                if len(_lazy_skip) > 256:
+                    _lazy_skip.clear()
+                _lazy_skip[dA.data_ptr()] = (dA, mbits)
+                dres = dA
         else:
             cout = dA.shape[-1]
             vec_ok = cout % 4 == 0 and ops._rows(dA)[2] % 4 == 0
@@ -292,22 +304,37 @@ class _ConvBnAct(torch.autograd.Function):
                     full = dy.as_strided(dy.shape[:-1] + (ops._rows(dy)[2],), dy.stride(), dy.storage_offset())
                     dbias = ops.colstats(full)[:, 0].sum(0)[:cout]
         dx = dw = None
+        lazy_bits = None
+        if dskip is not None:
+            ent = _lazy_skip.pop(dskip.data_ptr(), None)
+            if ent is not None and tuple(ent[0].shape) == tuple(dskip.shape):
+                lazy_bits = ent[1]
         if need_x:
             if geom is None:
                 fuse = (dskip is not None and tuple(dskip.shape) == ctx.x_shape and dskip.is_contiguous()
                         and dskip.shape[-1] == wp.cin)
+                if lazy_bits is not None and not (fuse and wp.cin % 4 == 0):
+                    # cannot mask inside the epilogue: materialise the masked skip gradient first
+                    dz = torch.empty(dskip.shape, dtype=torch.float32, device=dskip.device)
+                    ops.bn_act_bwd(dskip, None, None, None, None, None, None, None, dres=dz, act=ACT_RELU, want_dy=False,
+                                   mask_bits=lazy_bits)
+                    dskip, lazy_bits = dz, None
+                    fuse = (tuple(dskip.shape) == ctx.x_shape and dskip.shape[-1] == wp.cin)
                 # identity blocks: the skip gradient is accumulated by the dgrad epilogue instead of a separate add kernel
                 in_link = cfg.get("in_link")
+                # skip gradient: accumulated in place (already masked), or -- lazy -- read through its ReLU mask as `res`
+                # and overwritten in place (each element is read and written by the same thread)
+                skip_kw = dict(out=dskip if fuse else None, accumulate=fuse and lazy_bits is None)
+                if lazy_bits is not None:
+                    skip_kw.update(res=dskip, res_mask_bits=lazy_bits)
                 if in_link is not None and in_link.y is not None and (dskip is None or fuse) and \
                         wp.cin == ctx.x_shape[-1] and wp.cin % 4 == 0:
                     dx, part_in = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec,
-                                                   out=dskip if fuse else None, accumulate=fuse,
                                                    bn_bwd=(in_link.y, in_link.mean, in_link.istd, in_link.msc,
-                                                           in_link.msh, in_link.mbits))
+                                                           in_link.msh, in_link.mbits), **skip_kw)
                     in_link.partial, in_link.for_ptr = part_in, dx.data_ptr()
                 else:
-                    dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec,
-                                          out=dskip if fuse else None, accumulate=fuse)
+                    dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec, **skip_kw)
                 if dskip is not None and not fuse:
                     dx = dx + dskip
                 if dx.shape[-1] != ctx.x_shape[-1]:  # x carried pad channels
@@ -317,6 +344,11 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 raise RuntimeError("the stem convolution has no data gradient (its input is the image)")
         elif dskip is not None and ctx.needs_input_grad[0]:
+            if lazy_bits is not None:
+                dz = torch.empty(dskip.shape, dtype=torch.float32, device=dskip.device)
+                ops.bn_act_bwd(dskip, None, None, None, None, None, None, None, dres=dz, act=ACT_RELU, want_dy=False,
+                               mask_bits=lazy_bits)
+                dskip = dz
             dx = dskip
         if need_w:
             side = wgrad_stream(dy.device) if (WGRAD_SIDE_STREAM and geom is None and not torch.cuda.is_current_stream_capturing()) else None
@@ -378,6 +410,8 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
     res = _ConvBnAct.apply(x, weight, gamma, beta, bias, residual, cfg)
     if cfg.get("out_link") is not None:
         (res[0] if pass_through else res)._zs3_bn_link = cfg["out_link"]
+    if pass_through:
+        res[1]._zs3_skip_alias = True   # lets the block's last layer know who will receive its skip gradient
     return res
 
 

@@ -108,10 +108,11 @@ def conv_out_size(h, k, stride, pad, dil):
 
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
                scale=None, shift=None, res=None, want_stats=False, act=0, leak=0.2, accumulate=False, dgrad=False,
-               prec=None, tile_cfg=0, bn_bwd=None):
+               prec=None, tile_cfg=0, bn_bwd=None, res_mask_bits=None):
     """Raw launcher.  x: NHWC [N,H,W,*]; returns (y [N,ho,wo,ncols] or `out`, stat_partial or None).
     bn_bwd = (y, mean, invstd, mask_scale, mask_shift, mask_bits): also return the BatchNorm-backward partial sums
-    (sum dz, sum dz*xhat per row tile) of the layer the output gradient belongs to (zs3_conv_igemm_bnstats)."""
+    (sum dz, sum dz*xhat per row tile) of the layer the output gradient belongs to (zs3_conv_igemm_bnstats).
+    res_mask_bits: `res` is added through a ReLU mask given as sign bytes (the residual block's skip gradient)."""
     require_gpu(x, w_pk, out, scale, shift, res)
     prec = prec or PREC_DEFAULT
     n, h, w_, _ = x.shape
@@ -131,14 +132,16 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if bn_bwd is not None:
+    if bn_bwd is not None or res_mask_bits is not None:
         assert scale is None and shift is None and act == 0 and not want_stats
-        by, bmean, bistd, bmsc, bmsh, bbits = bn_bwd
-        require_gpu(by, bmean, bistd, bmsc, bmsh, bbits)
-        check(lib().zs3_conv_igemm_bnstats(P(x), P(w_pk), P(out), P(res), I(n), I(h), I(w_), I(ho), I(wo), I(cin_pad),
+        by, bmean, bistd, bmsc, bmsh, bbits = bn_bwd if bn_bwd is not None else (None,) * 6
+        require_gpu(by, bmean, bistd, bmsc, bmsh, bbits, res_mask_bits)
+        check(lib().zs3_conv_igemm_bnstats(P(x), P(w_pk), P(out), P(res), P(res_mask_bits), I(n), I(h), I(w_), I(ho), I(wo),
+                                           I(cin_pad),
                                            I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h), I(pad_w), I(dil),
                                            I(ncols), I(ldy), I(ldr), I(int(accumulate)), I(int(dgrad)), I(prec),
-                                           I(tile_cfg), P(zero_page(x.device)), P(by), I(_check_nhwc(by)), P(bmean),
+                                           I(tile_cfg), P(zero_page(x.device)), P(by),
+                                           I(_check_nhwc(by) if by is not None else 0), P(bmean),
                                            P(bistd), P(bmsc), P(bmsh), P(bbits), P(stat), stream()),
               "zs3_conv_igemm_bnstats")
     else:
