@@ -17,6 +17,8 @@ for (h, ci, co, k) in ((129, 256, 256, 3), (33, 1024, 256, 1), (33, 256, 256, 3)
     t = dbg.cpu().view(-1, 3)[:8].double()
     KT = k * k * ci // 32
     print(f"{h}^2 {ci}->{co} k{k}: KT={KT} cycles per K step (block 0)")
+    tt = dbg.cpu()[24:27].double()
+    print(f"   block 0: prologue {tt[0]:.0f} cycles, K loop {tt[2]:.0f}, epilogue {tt[1]:.0f}  (act=99 epilogue: no activation/stats)")
     for w in (0, 3, 4, 7):
         if w < 4:
             print(f"   wave {w} consumer: compute {t[w,0]/KT:.0f}, barrier wait {t[w,2]/KT:.0f}")

@@ -743,6 +743,10 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   const int m0 = mt * BM, n0 = nt * BN;
   const int KT = p.KH * p.KW * (p.cin_pad / 32);
   const int wm = wave & 3;
+#ifdef ZS3_CONV_TIMING
+  const long t_kernel0 = __builtin_readcyclecounter();
+  long t_loop0 = 0, t_loop1 = 0;
+#endif
 
   f32x16 acc[TM][TN];
 
@@ -996,6 +1000,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
 #ifdef ZS3_CONV_TIMING
     long t_work = 0, t_bar = 0;
     long t_last = __builtin_readcyclecounter();
+    t_loop0 = t_last;
 #endif
     for (int kt = 0; kt < KT; ++kt) {
       substep(0);
@@ -1011,6 +1016,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       substep(3);                    // after the last tile this prefetches stale (unused) data
     }
 #ifdef ZS3_CONV_TIMING
+    t_loop1 = __builtin_readcyclecounter();
     if (p.act == 99 && blockIdx.x == 0 && lane == 0) {
       long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + wave * 3;
       o[0] = t_work; o[1] = 0; o[2] = t_bar;
@@ -1086,6 +1092,14 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
     store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
   }
   if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
+#ifdef ZS3_CONV_TIMING
+  if (p.act == 99 && blockIdx.x == 0 && tid == 0) {
+    long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + 24;
+    o[0] = t_loop0 - t_kernel0;                       // prologue (consumer wave 0)
+    o[1] = __builtin_readcyclecounter() - t_loop1;    // epilogue
+    o[2] = t_loop1 - t_loop0;                         // K loop
+  }
+#endif
 }
 
 template <int PREC>
