@@ -23,9 +23,9 @@ extern "C" {
 int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
                     void* stream);
 /* the same for many weights in ONE launch (after an optimizer step): table[e] = {w, f_pk, t_pk, cout, taps, cin, cin_pad,
- * cout_pad} as 8 int64 (device memory), blockmap[b] = {entry, chunk} as 2 int32, one block per zs3_prep_chunk()
- * consecutive elements of an entry's (forward ++ transposed) element space. */
-int zs3_prep_chunk(void);
+ * cout_pad} as 8 int64 (device memory), blockmap[b] = {entry, chunk} as 2 int32 with chunk in
+ * [0, zs3_prep_chunks(cout_pad, taps, cin_pad)) (one tap x 32 output channels x <= 256 input channels each). */
+int zs3_prep_chunks(int cout_pad, int taps, int cin_pad);
 int zs3_prep_weight_multi(const long* table, const int* blockmap, int nblocks, void* stream);
 /* NCHW 3-channel image -> [N][H][Wp][4] zero-padded NHWC4 (image at columns [left,left+W)).  Feeds
  * the 7x7/s2 stem (resnet.py:79) as a 7x1 conv over 32-float (8 pixel x 4 ch) windows. */

@@ -290,3 +290,23 @@ def test_fused_upsample_argmax_confusion(dev, classes, hw, HW):
         ev.add_batch(tgt, up.argmax(1))             # device labels + device predictions
         assert np.array_equal(ev.confusion_matrix, want)
     assert abs(Evaluator(classes).Pixel_Accuracy() != 0)   # nan on an empty matrix, like the reference
+
+
+def test_refresh_planes_equals_per_weight_split(dev):
+    """zs3_prep_weight_multi (one launch after the optimizer step, LDS-transposed tiles) writes exactly the planes that
+    zs3_prep_weight produces per weight -- ragged channel counts, 1x1 / 3x3 / 7x7-like taps, padded K"""
+    from zs3_amd import functional as Fz, ops
+    g = torch.Generator().manual_seed(11)
+    ws = []
+    for (co, ci, k) in [(256, 256, 3), (21, 256, 1), (48, 256, 1), (256, 304, 3), (512, 128, 1), (64, 64, 3), (2048, 1280, 1),
+                        (256, 2048, 3), (40, 36, 5)]:
+        w = torch.nn.Parameter(torch.randn(co, ci, k, k, generator=g).to(dev).contiguous(memory_format=torch.channels_last))
+        ws.append(w)
+        Fz.weight_planes(w, need_t=True)              # creates the cached plane buffers
+    for w in ws:
+        w.data.mul_(1.7).add_(0.01)                   # "optimizer step" through .data: the version counter does not move
+    Fz.refresh_planes(*ws)
+    for w in ws:
+        got = Fz.weight_planes(w, need_t=True)        # cache hit: the refreshed buffers
+        want = ops.prep_weight(w, need_t=True)
+        assert torch.equal(got.f_pk, want.f_pk) and torch.equal(got.t_pk, want.t_pk), tuple(w.shape)

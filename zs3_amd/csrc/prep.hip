@@ -46,45 +46,75 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* 
 }
 
 // All weights of a model in one launch (after the optimizer step): table[e] = {w, f_pk, t_pk, cout, taps, cin, cin_pad,
-// cout_pad}, blockmap[b] = {entry, chunk}; a block converts PREP_CHUNK consecutive elements of the (forward ++ transposed)
-// index space of its entry.  Same arithmetic as prep_weight_kernel.
-constexpr int PREP_CHUNK = 8192;
+// cout_pad}, blockmap[b] = {entry, chunk}.  A chunk is one filter tap x 32 output channels x up to 256 input channels,
+// processed as 32x32 tiles: w is read once, coalesced along ci; the forward plane is written from registers (8 bytes
+// per lane, rows = co) and the transposed plane through an LDS transpose (rows = ci, 8 bytes per lane along co).  The
+// per-element form above reads w with a row stride for the transposed plane: measured 6.7 GB of fabric reads per step.
+constexpr int PREP_CI_GROUP = 256;
 __global__ __launch_bounds__(256) void prep_weight_multi_kernel(const long* __restrict__ table,
                                                                 const int* __restrict__ blockmap) {
-  const int e = blockmap[2 * blockIdx.x], chunk = blockmap[2 * blockIdx.x + 1];
+  __shared__ unsigned short th[32][36], tl[32][36];   // [ci][co] hi / lo, padded rows
+  const int e = blockmap[2 * blockIdx.x];
+  int chunk = blockmap[2 * blockIdx.x + 1];
   const long* t = table + 8 * (long)e;
   const float* w = reinterpret_cast<const float*>(t[0]);
   unsigned short* f_pk = reinterpret_cast<unsigned short*>(t[1]);
   unsigned short* t_pk = reinterpret_cast<unsigned short*>(t[2]);
   const int cout = (int)t[3], taps = (int)t[4], cin = (int)t[5], cin_pad = (int)t[6], cout_pad = (int)t[7];
-  const long nf = (long)cout * taps * cin_pad;
-  const long nt = t_pk ? (long)cin * taps * cout_pad : 0;
-  const long i0 = (long)chunk * PREP_CHUNK;
-  const long i1 = i0 + PREP_CHUNK < nf + nt ? i0 + PREP_CHUNK : nf + nt;
-  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-    float v = 0.f;
-    unsigned short *dh, *dl;
-    if (i < nf) {
-      int ci = (int)(i % cin_pad);
-      long r = i / cin_pad;
-      int tap = (int)(r % taps), co = (int)(r / taps);
-      if (ci < cin) v = w[((long)co * taps + tap) * cin + ci];
-      const long ktot = (long)taps * cin_pad, k = (long)tap * cin_pad + ci;
-      dh = f_pk + packed_index(co, k, ktot, 0);
-      dl = f_pk + packed_index(co, k, ktot, 1);
-    } else {
-      long kk = i - nf;
-      int co = (int)(kk % cout_pad);
-      long r = kk / cout_pad;
-      int tap = (int)(r % taps), ci = (int)(r / taps);
-      if (co < cout) v = w[((long)co * taps + tap) * cin + ci];
-      const long ktot = (long)taps * cout_pad, k = (long)tap * cout_pad + co;
-      dh = t_pk + packed_index(ci, k, ktot, 0);
-      dl = t_pk + packed_index(ci, k, ktot, 1);
+  const int ngrp = (cin_pad + PREP_CI_GROUP - 1) / PREP_CI_GROUP, nco = cout_pad / 32;
+  const int grp = chunk % ngrp; chunk /= ngrp;
+  const int cot = chunk % nco;
+  const int tap = chunk / nco;
+  const int r = threadIdx.x >> 3, q = threadIdx.x & 7;   // row within the tile, 4-wide column group
+  const int co0 = cot * 32;
+  const long kf_tot = (long)taps * cin_pad, kt_tot = (long)taps * cout_pad;
+  const int ci_end = min(cin_pad, (grp + 1) * PREP_CI_GROUP);
+  for (int ci0 = grp * PREP_CI_GROUP; ci0 < ci_end; ci0 += 32) {
+    const int co = co0 + r, ci = ci0 + 4 * q;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (co < cout) {
+      const float* src = w + ((long)co * taps + tap) * cin + ci;
+      if (ci + 3 < cin && (((uintptr_t)src) & 15) == 0) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src);
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ci + k < cin) v[k] = src[k];
+      }
     }
-    unsigned short h = f32_to_bf16_rne(v);
-    *dh = h;
-    *dl = f32_to_bf16_rne(v - bf16_bits_to_f32(h));
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h[k] = f32_to_bf16_rne(v[k]);
+      l[k] = f32_to_bf16_rne(v[k] - bf16_bits_to_f32(h[k]));
+    }
+    if (co < cout) {   // forward plane: row co, k = tap*cin_pad + ci .. ci+3 (inside one 32-chunk)
+      const long k = (long)tap * cin_pad + ci;
+      unsigned short* dh = f_pk + packed_index(co, k, kf_tot, 0);
+      unsigned short* dl = f_pk + packed_index(co, k, kf_tot, 1);
+      *reinterpret_cast<u32x2*>(dh) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+      *reinterpret_cast<u32x2*>(dl) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+    }
+    if (t_pk) {
+      __syncthreads();   // previous tile's readers are done
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        th[4 * q + k][r] = h[k];
+        tl[4 * q + k][r] = l[k];
+      }
+      __syncthreads();
+      const int ci_t = ci0 + r;   // transposed plane: row ci, k' = tap*cout_pad + co0 + 4q .. +3
+      if (ci_t < cin) {
+        const long k = (long)tap * cout_pad + co0 + 4 * q;
+        unsigned short* dh = t_pk + packed_index(ci_t, k, kt_tot, 0);
+        unsigned short* dl = t_pk + packed_index(ci_t, k, kt_tot, 1);
+        *reinterpret_cast<u32x2*>(dh) = u32x2{(unsigned)th[r][4 * q] | ((unsigned)th[r][4 * q + 1] << 16),
+                                              (unsigned)th[r][4 * q + 2] | ((unsigned)th[r][4 * q + 3] << 16)};
+        *reinterpret_cast<u32x2*>(dl) = u32x2{(unsigned)tl[r][4 * q] | ((unsigned)tl[r][4 * q + 1] << 16),
+                                              (unsigned)tl[r][4 * q + 2] | ((unsigned)tl[r][4 * q + 3] << 16)};
+      }
+    }
   }
 }
 
@@ -122,7 +152,9 @@ extern "C" int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout,
   return ZS3_LAUNCH_CHECK();
 }
 
-extern "C" int zs3_prep_chunk(void) { return PREP_CHUNK; }
+extern "C" int zs3_prep_chunks(int cout_pad, int taps, int cin_pad) {
+  return taps * (cout_pad / 32) * ((cin_pad + PREP_CI_GROUP - 1) / PREP_CI_GROUP);
+}
 
 extern "C" int zs3_prep_weight_multi(const long* table, const int* blockmap, int nblocks, void* stream) {
   if (nblocks <= 0) return 0;

@@ -91,13 +91,11 @@ def refresh_planes(*params):
     key = (dev.index,) + tuple((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr()) for w, wp, _ in todo)
     tab = _refresh_tables.get(dev.index)
     if tab is None or tab[0] != key:
-        chunk = ops.lib().zs3_prep_chunk()
         recs, bmap = [], []
         for e, (w, wp, _) in enumerate(todo):
             taps = wp.kh * wp.kw
             recs.append((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr(), wp.cout, taps, wp.cin, wp.cin_pad, wp.cout_pad))
-            total = wp.cout * taps * wp.cin_pad + wp.cin * taps * wp.cout_pad
-            bmap.extend((e, c) for c in range((total + chunk - 1) // chunk))
+            bmap.extend((e, c) for c in range(ops.lib().zs3_prep_chunks(ops.I(wp.cout_pad), ops.I(taps), ops.I(wp.cin_pad))))
         table = torch.tensor(recs, dtype=torch.int64).to(dev)
         blockmap = torch.tensor(bmap, dtype=torch.int32).to(dev)
         tab = (key, table, blockmap, len(bmap))
