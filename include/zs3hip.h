@@ -204,6 +204,16 @@ int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float mo
 int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   float wd, int step, const void* step_dev, void* stream);
 
+
+/* ---- GCN-context cluster graph (train_context_GMMN_GCNcontext.py:33-102, construct_adj_mat) ------------------- */
+/* seg: [H][W] int32 class map (H*W <= zs3_cluster_graph_max_pixels()).  cmap[p] = cluster id (8-connected components
+ * of equal class, numbered in raster order of their first pixel); seed[c] = that first pixel's flat index, labels[c] its
+ * class; ncluster[0] = number of clusters; adj: [cap][cap] floats, zeroed by the caller, adj[c1][c2] = 1 when clusters of
+ * different class touch in the 8-neighbourhood (clusters >= cap are counted but not recorded).  One launch, no host sync. */
+int zs3_cluster_graph_max_pixels(void);
+int zs3_cluster_graph(const int* seg, int H, int W, int* cmap, int* seed, int* labels, int* ncluster, float* adj, int cap,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -310,3 +310,58 @@ def test_refresh_planes_equals_per_weight_split(dev):
         got = Fz.weight_planes(w, need_t=True)        # cache hit: the refreshed buffers
         want = ops.prep_weight(w, need_t=True)
         assert torch.equal(got.f_pk, want.f_pk) and torch.equal(got.t_pk, want.t_pk), tuple(w.shape)
+
+
+def test_cluster_graph_matches_reference_goldens(dev):
+    """zs3_cluster_graph (device 8-connected components + adjacency) against construct_adj_mat of the
+    reference (tests/golden/gcn_graph.npz): cluster numbering, adjacency, labels and seed embeddings bit-identical; seed
+    features bit-identical without avg_feat, within 2e-5 of the reference's re-averaging noise with it"""
+    import os
+    import numpy as np
+    from zs3_amd.gcn_context import construct_adj_mat
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gcn_graph.npz"))
+    for k in range(int(g["n"])):
+        seg = torch.from_numpy(g[f"seg{k}"]).to(dev)
+        cg = construct_adj_mat(seg, torch.from_numpy(g[f"emb{k}"]).to(dev), torch.from_numpy(g[f"feat{k}"]).to(dev),
+                               avg_feat=(k % 2 == 1))
+        assert np.array_equal(cg.cluster_map.cpu().numpy(), g[f"cmap{k}"]), k
+        assert np.array_equal(cg.labels.cpu().numpy(), g[f"lbl{k}"])
+        assert (cg.adj is not None) == bool(g[f"has_adj{k}"])
+        if cg.adj is not None:
+            assert np.array_equal(cg.adj.cpu().numpy(), g[f"adj{k}"])
+            assert np.array_equal(cg.adj_sparse().to_dense().cpu().numpy(), g[f"adj{k}"])
+        assert np.array_equal(cg.embedding.cpu().numpy(), g[f"emb_gcn{k}"])
+        feat, want = cg.feature.cpu().numpy(), g[f"feat_gcn{k}"]
+        if k % 2 == 0:
+            assert np.array_equal(feat, want)
+        else:
+            assert np.allclose(feat, want, rtol=2e-5, atol=1e-6)   # the reference's float32 re-averaging random walk
+    ref = cg.as_reference_tuple()
+    assert sorted(ref[1].keys()) == list(range(cg.num_clusters)) and sum(len(v) for v in ref[1].values()) == seg.numel()
+
+
+def test_gcn_generator_forward_backward(dev):
+    """GMMNnetwork_GCN (gmmn.py:52-67) on the row-GEMM kernels vs adj @ (x @ W) + b in fp64 (pygcn's published form)"""
+    from zs3_amd.modeling.gmmn import GMMNnetwork_GCN
+    torch.manual_seed(3)
+    n = 13
+    net = GMMNnetwork_GCN(noise_dim=12, embed_dim=20, hidden_size=64, feature_dim=32).to(dev).train()
+    net.dropout.p = 0.0
+    assert sorted(net.state_dict()) == ["gcn1.bias", "gcn1.weight", "gcn2.bias", "gcn2.weight"]
+    assert tuple(net.gcn1.weight.shape) == (32, 64)
+    adj = (torch.rand(n, n) < 0.3).float()
+    adj = ((adj + adj.t()) > 0).float().to(dev)
+    emb, z = torch.randn(n, 20, device=dev), torch.rand(n, 12, device=dev)
+    out = net(emb, z, adj.to_sparse())
+    out.square().sum().backward()
+    w1, b1, w2, b2 = (p.detach().double().cpu().requires_grad_(True) for p in (net.gcn1.weight, net.gcn1.bias, net.gcn2.weight,
+                                                                              net.gcn2.bias))
+    a = adj.double().cpu()
+    x = torch.cat((emb, z), 1).double().cpu()
+    h = torch.nn.functional.leaky_relu(a @ (x @ w1) + b1, 0.2)
+    ref = a @ (h @ w2) + b2
+    ref.square().sum().backward()
+    assert rel(out, ref) < 5e-5
+    for got, want in ((net.gcn1.weight.grad, w1.grad), (net.gcn1.bias.grad, b1.grad), (net.gcn2.weight.grad, w2.grad),
+                      (net.gcn2.bias.grad, b2.grad)):
+        assert rel(got, want) < 1e-4

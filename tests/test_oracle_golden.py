@@ -220,3 +220,16 @@ def test_host_logic_matches_reference(golden):
     assert np.array_equal(zo.nearest_index(129, 513), g["nearest_513_129"])
     assert np.array_equal(zo.nearest_index(17, 65), g["nearest_65_17"])
     assert list(zo.nearest_index(129, 513)[:4]) == [0, 3, 7, 11]
+
+
+def test_cluster_graph_matches_reference_construct_adj_mat(golden):
+    """oracle cluster_graph vs train_context_GMMN_GCNcontext.construct_adj_mat run in the build container
+    (tests/golden/gcn_graph.npz): cluster numbering, dense adjacency, labels, seed embeddings and the seed-feature quirk"""
+    g = golden("gcn_graph.npz")
+    for k in range(int(g["n"])):
+        adj, cmap, lbl, emb, feat = zo.cluster_graph(g[f"seg{k}"], g[f"emb{k}"], g[f"feat{k}"], avg_feat=(k % 2 == 1))
+        assert np.array_equal(cmap, g[f"cmap{k}"]) and np.array_equal(lbl, g[f"lbl{k}"])
+        assert (adj is not None) == bool(g[f"has_adj{k}"])
+        if adj is not None:
+            assert np.array_equal(adj, g[f"adj{k}"])
+        assert np.array_equal(emb, g[f"emb_gcn{k}"]) and np.array_equal(feat, g[f"feat_gcn{k}"])

@@ -328,10 +328,56 @@ def g_misc():
          nearest_65_17=near65.numpy().astype(np.int64))
 
 
+# --------------------------------------------------------------------------- G8: GCN-context cluster graph (8f N3)
+def _segmaps():
+    """label maps with blobs, thin diagonal structures (8-connectivity matters), single-pixel clusters, one-label maps"""
+    rng = np.random.RandomState(7)
+    maps = []
+    m = np.zeros((17, 23), dtype=np.int64)
+    m[2:9, 3:12] = 4; m[5:14, 10:20] = 7; m[12:, :6] = 4
+    for k in range(10):
+        m[k, 22 - k] = 9                       # anti-diagonal line: one cluster only under 8-connectivity
+    m[15, 15] = 3; m[0, 0] = 3
+    maps.append(m)
+    coarse = rng.randint(0, 5, size=(5, 6))
+    maps.append(np.kron(coarse, np.ones((7, 6), dtype=np.int64)))   # 35 x 36 block map
+    maps.append(rng.randint(0, 3, size=(12, 13)))                    # salt-and-pepper: many tiny clusters
+    maps.append(np.full((9, 9), 2, dtype=np.int64))                  # a single cluster (adj_mat is None)
+    big = np.zeros((33, 33), dtype=np.int64)
+    yy, xx = np.mgrid[:33, :33]
+    big[(yy - 10) ** 2 + (xx - 12) ** 2 < 49] = 5
+    big[(yy - 22) ** 2 + (xx - 20) ** 2 < 64] = 11
+    big[(yy + xx) % 17 == 0] = 2
+    big[30:, :] = 255
+    maps.append(big)
+    return maps
+
+
+def g_gcn():
+    from zs3.train_context_GMMN_GCNcontext import construct_adj_mat
+    out = {}
+    rng = np.random.RandomState(11)
+    for k, seg in enumerate(_segmaps()):
+        emb = rng.randn(6, *seg.shape).astype(np.float32)
+        feat = rng.randn(5, *seg.shape).astype(np.float32)
+        adj, c2p, c2l, emb_gcn, feat_gcn = construct_adj_mat(seg, emb, feat, avg_feat=(k % 2 == 1))
+        ncl = len(c2l)
+        cmap = np.full(seg.shape, -1, dtype=np.int64)
+        for c, pix in c2p.items():
+            for (i, j) in pix:
+                cmap[i, j] = c
+        dense = np.zeros((ncl, ncl), dtype=np.float32) if adj is None else adj.to_dense().numpy()
+        out.update({f"seg{k}": seg, f"emb{k}": emb, f"feat{k}": feat, f"cmap{k}": cmap, f"adj{k}": dense,
+                    f"has_adj{k}": np.array(adj is not None), f"lbl{k}": np.array(c2l, dtype=np.int64),
+                    f"emb_gcn{k}": np.asarray(emb_gcn), f"feat_gcn{k}": np.asarray(feat_gcn)})
+    out["n"] = np.array(len(_segmaps()))
+    save("gcn_graph.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["init", "forward", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc"]
+    which = sys.argv[1:] or ["init", "forward", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc", "gcn"]
     for w in which:
         {"init": g_init, "forward": g_forward, "supervised": g_supervised, "mmd": g_mmd, "gmmn_mlp": g_gmmn_mlp,
-         "gmmn_traj": g_gmmn_traj, "misc": g_misc}[w]()
+         "gmmn_traj": g_gmmn_traj, "misc": g_misc, "gcn": g_gcn}[w]()
