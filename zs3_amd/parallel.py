@@ -73,15 +73,21 @@ class GradSync:
         bi, off = self.where[p]
         if p in self._ready[bi]:
             return
-        st = self._comm_stream(p)
-        ctx = torch.cuda.stream(st) if st is not None else _null()
-        with ctx:
-            self.flat[bi][off:off + p.numel()].copy_(_as_flat(p.grad, p))
-            self._ready[bi].add(p)
-            if len(self._ready[bi]) == len(self.buckets[bi]):
+        self._ready[bi].add(p)
+        if len(self._ready[bi]) == len(self.buckets[bi]):
+            st = self._comm_stream(p)
+            ctx = torch.cuda.stream(st) if st is not None else _null()
+            with ctx:
                 self._launch(bi)
 
+    def _views(self, bi, params):
+        return [self.flat[bi][self.where[p][1]:self.where[p][1] + p.numel()] for p in params]
+
     def _launch(self, bi):
+        """pack the bucket's gradients (one multi-tensor copy instead of one kernel per parameter) and start its all-reduce"""
+        have = [p for p in self.buckets[bi] if p in self._ready[bi] and p.grad is not None]
+        if have:
+            torch._foreach_copy_(self._views(bi, have), [_as_flat(p.grad, p) for p in have])
         self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.bytes_reduced += self.flat[bi].numel() * 4
 
@@ -108,11 +114,9 @@ class GradSync:
             if self.average:
                 self.flat[bi].div_(self.world)
             for p in bucket:
-                _, off = self.where[p]
-                src = self.flat[bi][off:off + p.numel()]
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
-                _as_flat(p.grad, p).copy_(src)
+            torch._foreach_copy_([_as_flat(p.grad, p) for p in bucket], self._views(bi, bucket))
             self._works[bi] = None
             self._ready[bi] = set()
         self._armed = False
