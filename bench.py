@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--workload", choices=["supervised", "gmmn"], default="supervised")
     ap.add_argument("--gmmn-steps", type=int, default=2)
     ap.add_argument("--sync-bn", type=int, default=0)
+    ap.add_argument("--ddp-selftest", action="store_true",
+                    help="1-GPU run with a one-rank RCCL group and the full gradient-sync plumbing (cost of the N>1 code path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -59,6 +61,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    elif args.ddp_selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from zs3_amd import ops
@@ -80,9 +86,9 @@ def main():
         enable_sync_bn(model)
     groups = [{"params": model.get_1x_lr_params(), "lr": 0.007}, {"params": model.get_10x_lr_params(), "lr": 0.07}]
     opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
-    crit = SegmentationLosses(cuda=True, group=True if world > 1 else None).build_loss("ce")
+    crit = SegmentationLosses(cuda=True, group=True if (world > 1 or args.ddp_selftest) else None).build_loss("ce")
     sched = LR_Scheduler("poly", 0.007, 50, 1000, verbose=False)
-    sync = GradSync(list(model.parameters())) if world > 1 else None
+    sync = GradSync(list(model.parameters()), force=args.ddp_selftest) if (world > 1 or args.ddp_selftest) else None
     batch = make_batch(args.batch, args.size, args.classes, unseen, seed=1 + rank, device=dev)
     image, label = batch["image"], batch["label"]
 
@@ -212,7 +218,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or args.ddp_selftest:
         dist.destroy_process_group()
 
 
