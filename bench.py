@@ -88,7 +88,12 @@ def main():
     opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
     crit = SegmentationLosses(cuda=True, group=True if (world > 1 or args.ddp_selftest) else None).build_loss("ce")
     sched = LR_Scheduler("poly", 0.007, 50, 1000, verbose=False)
-    sync = GradSync(list(model.parameters()), force=args.ddp_selftest) if (world > 1 or args.ddp_selftest) else None
+    multi = world > 1 or args.ddp_selftest
+    if args.ddp_selftest:
+        import zs3_amd.parallel as par
+        par.FORCE_COLLECTIVES = True      # one-rank group: run every collective of the N>1 path anyway
+    # supervised step: bucketed gradient all-reduce from grad hooks; the GMMN step has its own two small exchanges (GMMNStep)
+    sync = GradSync(list(model.parameters()), force=args.ddp_selftest) if (multi and args.workload == "supervised") else None
     batch = make_batch(args.batch, args.size, args.classes, unseen, seed=1 + rank, device=dev)
     image, label = batch["image"], batch["label"]
 
@@ -127,9 +132,12 @@ def main():
         opt_g = Adam(gen.parameters(), lr=2e-4)
         w = torch.ones(args.classes, device=dev)
         w[unseen] = 100.0
-        crit_g = SegmentationLosses(weight=w, cuda=True).build_loss("ce")
+        dp = multi and args.workload == "gmmn"
+        crit_g = SegmentationLosses(weight=w, cuda=True, group=True if dp else None).build_loss("ce")
         gb = make_batch(args.batch, args.size, args.classes, unseen, seed=101 + rank, with_label_emb=True, device=dev)
-        stepper = GMMNStep(model, gen, opt, opt_g, crit_g, seen=seen, unseen=unseen, noise="device")
+        if dp:
+            broadcast_parameters(gen)
+        stepper = GMMNStep(model, gen, opt, opt_g, crit_g, seen=seen, unseen=unseen, noise="device", group=True if dp else None)
         return lambda i: stepper(gb["image"], gb["label"], gb["label_emb"])
 
     if args.workload == "supervised":

@@ -65,6 +65,26 @@ def _worker(rank, world, port, q):
         tot, _ = combine_bn_partials(big, 1)
         other = torch.full((3, 2, 4), 1e8 / 3 + (1 - rank), dtype=torch.float32)
         assert torch.equal(tot.double().sum(0), big.double().sum(0) + other.double().sum(0))
+        # the GMMN step's exchange: several small tensors (one of them channels_last, one a transposed view) in ONE
+        # collective, mean or sum, written back in place
+        from zs3_amd.parallel import all_reduce_tensors
+        torch.manual_seed(50 + rank)
+        a = torch.randn(6, 5)
+        b = torch.randn(4, 3, 2, 2).contiguous(memory_format=torch.channels_last)
+        c = torch.randn(7, 3).t()                   # non-contiguous: goes through a copy and is written back
+        mine = [a.clone(), b.clone(), c.clone()]
+        every = []
+        for r in range(world):
+            torch.manual_seed(50 + r)
+            every.append([torch.randn(6, 5), torch.randn(4, 3, 2, 2), torch.randn(7, 3).t()])
+        nbytes = all_reduce_tensors([a, None, b, c], average=True)
+        assert nbytes == 4 * (30 + 48 + 21)
+        for got, col in zip((a, b, c), zip(*every)):
+            assert torch.allclose(got, sum(col) / world, rtol=1e-6, atol=1e-7)
+        assert b.is_contiguous(memory_format=torch.channels_last) and c.shape == (3, 7)
+        all_reduce_tensors(mine, average=False)
+        for got, col in zip(mine, zip(*every)):
+            assert torch.allclose(got, sum(col), rtol=1e-6, atol=1e-7)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

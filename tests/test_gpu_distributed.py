@@ -81,3 +81,50 @@ def test_one_rank_rccl_step_equals_plain_step(dev, one_rank_group):
             err = (s0[k] - s1[k]).abs().max().item()
             # (the plain run sums the BN-backward statistics in the dgrad epilogues, the SyncBN run in a separate pass)
             assert err <= 1e-5 + 1e-4 * s0[k].abs().max().item(), (k, err)
+
+
+def _gmmn_steps(dev, ddp):
+    from zs3_amd.gmmn_trainer import GMMNStep
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.modeling.gmmn import GMMNnetwork
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.synthetic import make_batch
+    import zs3_amd.parallel as par
+    seen = [c for c in range(21) if c not in (10, 14)]
+    torch.manual_seed(4)
+    m = DeepLab(num_classes=21, pretrained=False).to(dev).train()
+    gen = GMMNnetwork(300, 300, 256, 256).to(dev).train()
+    w = torch.ones(21, device=dev)
+    w[[10, 14]] = 100.0
+    groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+    opt, opt_g = SGD(groups, momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4)
+    par.FORCE_COLLECTIVES = ddp
+    crit = SegmentationLosses(weight=w, cuda=True, group=True if ddp else None).build_loss("ce")
+    step = GMMNStep(m, gen, opt, opt_g, crit, seen=seen, unseen=[10, 14], noise="cpu", group=True if ddp else None)
+    assert step.grad_reduce == ("sum" if ddp else "mean")
+    table = torch.nn.functional.normalize(torch.randn(21, 300, generator=torch.Generator().manual_seed(5)), dim=1).to(dev)
+    out = []
+    for it in range(2):
+        b = make_batch(4, 65, 21, [10, 14], seed=300 + it, device=dev)
+        torch.manual_seed(21 + it)
+        gl, cl, _ = step(b["image"], b["label"], table=table)
+        out.append((gl, cl))
+    torch.cuda.synchronize()
+    par.FORCE_COLLECTIVES = False
+    if ddp:   # two exchanges per step: 219,648 generator parameters + pred_conv (21*256 + 21) gradients
+        assert step.bytes_reduced == 2 * 4 * (219648 + 21 * 256 + 21)
+    return out, [p.detach().clone() for p in gen.parameters()], m.decoder.pred_conv.weight.detach().clone()
+
+
+def test_one_rank_rccl_gmmn_step_equals_plain_step(dev, one_rank_group):
+    """GMMNStep(group=...): generator-parameter averaging + pred_conv gradient reduction through RCCL; with one rank both
+    are the identity, so losses and every updated weight must equal the single-process step (to fp32 rounding of the
+    globally normalised CE)."""
+    l0, g0, p0 = _gmmn_steps(dev, ddp=False)
+    l1, g1, p1 = _gmmn_steps(dev, ddp=True)
+    for (ga, ca), (gb, cb) in zip(l0, l1):
+        assert abs(ga - gb) <= 1e-6 * abs(ga) and abs(ca - cb) <= 1e-6 * abs(ca), (l0, l1)
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(p0, p1, rtol=1e-6, atol=1e-8)

@@ -18,6 +18,12 @@ What is MI355X-native here:
   dropout / noise seeds and the Adam step count live in device memory so that replays differ;
 * the scalar losses are read back once per step instead of `.item()` per (image, class).
 
+Multi-GPU (`group=`): every rank runs the frozen-backbone forward and the generator updates of its own
+images; once per step the generator parameters are averaged over the ranks (one 0.88 MB all-reduce) and the `pred_conv`
+gradients are reduced (one <= 62 KB all-reduce) before the SGD step.  The generator loop is a sequential online process with a
+data-dependent number of Adam steps per image, so trajectory parity with the reference is claimed at one GPU only; the
+number of collectives per step is fixed (two), whatever each rank's images contain.
+
 noise="cpu" draws z and the sample indices from the CPU default generator exactly like the reference
 (:216,:229) -- bit-parity mode for tests; noise="device" draws z with the counter-based device RNG.
 """
@@ -39,7 +45,10 @@ def _rows_gemm(x, wp, b, act=Fz.ACT_NONE, leak=0.2):
 class GMMNStep:
     def __init__(self, model, generator, optimizer, optimizer_generator, criterion, *, seen, unseen, noise_dim=300,
                  embed_dim=300, feature_dim=256, batch_size_generator=128, real_seen_features=True,
-                 sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True):
+                 sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True, group=None, grad_reduce=None):
+        """group: None (single process) | True (default process group) | a torch.distributed group.
+        grad_reduce: "sum" when `criterion` already normalises by the global batch / valid-pixel weight
+        (SegmentationLosses(group=...)), "mean" when it normalises per rank; default: picked from the criterion."""
         self.model = model.module if hasattr(model, "module") else model
         self.generator = generator
         self.optimizer, self.optimizer_generator = optimizer, optimizer_generator
@@ -49,6 +58,14 @@ class GMMNStep:
         self.bsg, self.real_seen_features = batch_size_generator, real_seen_features
         self.sigma = tuple(float(s) for s in sigma)
         self.noise = noise
+        self.group = group
+        if grad_reduce is None:
+            owner = getattr(criterion, "__self__", None)
+            grad_reduce = "sum" if getattr(owner, "group", None) is not None else "mean"
+        if grad_reduce not in ("sum", "mean"):
+            raise ValueError("grad_reduce must be 'sum' or 'mean'")
+        self.grad_reduce = grad_reduce
+        self.bytes_reduced = 0
         if not isinstance(generator.model, torch.nn.Sequential):
             raise NotImplementedError("GMMNStep needs the hidden-layer generator (hidden_size > 0)")
         from .optim import Adam
@@ -343,11 +360,21 @@ class GMMNStep:
                     slot += 1
                 if not use_real:
                     ops.scatter_rows(fake_c, idx_c, fake_rows[i])
+        pg = None if self.group is True else self.group
+        if self.group is not None:   # generator replicas -> their average (parameters only; Adam moments stay per rank)
+            from .parallel import all_reduce_tensors
+            gen_params = [p.data for p in self.generator.parameters()]
+            self.bytes_reduced += all_reduce_tensors(gen_params, group=pg, average=True)
+            Fz.invalidate_planes(*self.generator.parameters())
+            self._resplit()
         # ---- classifier update on the stitched features (only pred_conv receives gradients)
         self.optimizer.zero_grad()
         out = model.forward_class_prediction(ops.nchw(fake), image.shape[2:])
         closs = self.criterion(out, target)
         closs.backward()
+        if self.group is not None:
+            grads = [p.grad for g_ in self.optimizer.param_groups for p in g_["params"] if p.grad is not None]
+            self.bytes_reduced += all_reduce_tensors(grads, group=pg, average=self.grad_reduce == "mean")
         self.optimizer.step()
         if ring_slots:
             if n_ring > st["loss_ring"].numel():
