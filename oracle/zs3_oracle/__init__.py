@@ -14,10 +14,11 @@ follows (paths relative to the reference checkout).
 from .nets import DeepLab, ResNet101Dilated, ASPP, Decoder, Bottleneck  # noqa: F401
 from .gmmn import GMMNnetwork  # noqa: F401
 from .losses import SegmentationLosses, GMMNLoss, cross_entropy_2d, cross_entropy_2d_closed_form, mmd_loss  # noqa: F401
-from .gcn import cluster_graph, gcn_forward  # noqa: F401
+from .gcn import cluster_graph, gcn_forward, GraphConvolution, GMMNnetwork_GCN  # noqa: F401
 from .steps import (  # noqa: F401
     supervised_step,
     gmmn_step,
+    gcn_context_step,
     poly_lr,
     apply_lr,
     make_synthetic_batch,

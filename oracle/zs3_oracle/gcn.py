@@ -6,6 +6,8 @@ lives in the un-vendored dependency tkipf/pygcn (unpinned version; absent from /
 published form `adj @ (x @ W) + b` (pygcn/layers.py) behind the reference's call site zs3/modeling/gmmn.py:52-67, so the
 GCN layer's parity is anchored on that call site only ("parity unpinned" for the layer itself)."""
 import numpy as np
+import torch
+import torch.nn as nn
 
 
 def cluster_graph(segmap, embeddingmap, featmap=None, avg_feat=False):
@@ -72,3 +74,37 @@ def cluster_graph(segmap, embeddingmap, featmap=None, avg_feat=False):
 def gcn_forward(x, adj, weight, bias):
     """pygcn GraphConvolution: adj @ (x @ W) + b, weight stored [in, out]."""
     return adj @ (x @ weight) + bias
+
+
+class GraphConvolution(nn.Module):
+    """pygcn.layers.GraphConvolution: weight [in, out], bias [out]; forward = adj @ (x @ W) + b (adj dense or sparse)."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(in_features, out_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        stdv = 1.0 / out_features ** 0.5        # pygcn reset_parameters (overwritten by the caller's init below)
+        self.weight.data.uniform_(-stdv, stdv)
+        self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, adj):
+        support = x @ self.weight
+        return (torch.sparse.mm(adj, support) if adj.is_sparse else adj @ support) + self.bias
+
+
+class GMMNnetwork_GCN(nn.Module):
+    """zs3/modeling/gmmn.py:52-67: gcn1 -> LeakyReLU(0.2) -> Dropout(0.5) -> gcn2; xavier_uniform weights, bias 0.01."""
+
+    def __init__(self, noise_dim=300, embed_dim=300, hidden_size=256, feature_dim=256):
+        super().__init__()
+        self.gcn1 = GraphConvolution(noise_dim + embed_dim, hidden_size)
+        self.relu = nn.LeakyReLU(0.2)
+        self.dropout = nn.Dropout(p=0.5)
+        self.gcn2 = GraphConvolution(hidden_size, feature_dim)
+        for m in (self.gcn1, self.gcn2):
+            nn.init.xavier_uniform_(m.weight)
+            m.bias.data.fill_(0.01)
+
+    def forward(self, embd, noise, adj_mat):
+        x = self.gcn1(torch.cat((embd, noise), 1), adj_mat)
+        return self.gcn2(self.dropout(self.relu(x)), adj_mat)

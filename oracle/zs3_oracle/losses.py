@@ -54,8 +54,11 @@ def mmd_loss(gen, real, sigma=(2, 5, 10, 20, 40, 80)):
     loss.py:92-97; call sites always have M == N.)"""
     x = torch.cat((gen, real), 0)
     m, n = gen.shape[0], real.shape[0]
+    # the Gram product is formed BEFORE the squared norms, as in loss.py:101-102: autograd sums the two gradient
+    # contributions to x in the order the ops were recorded, so the order decides the last bit of the gradient
+    xx = x @ x.t()
     sq = (x * x).sum(1, keepdim=True)
-    e = x @ x.t() - 0.5 * sq - 0.5 * sq.t()
+    e = xx - 0.5 * sq - 0.5 * sq.t()
     s = torch.cat((torch.full((n, 1), 1.0 / n), torch.full((m, 1), -1.0 / m)), 0).to(x)
     ss = s @ s.t()
     total = 0

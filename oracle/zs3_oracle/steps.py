@@ -1,7 +1,8 @@
 """Oracle training steps, LR schedule, metrics and the synthetic batch generator.
 
 Follows zs3/base_trainer.py:5-25 (supervised), zs3/train_pascal_GMMN.py:139-268 (GMMN step; the
-train_context_GMMN.py body is identical), zs3/utils/lr_scheduler.py:46-76, zs3/utils/metrics.py:35-82.
+train_context_GMMN.py body is identical), zs3/train_context_GMMN_GCNcontext.py:239-457 (GCN-context step),
+zs3/utils/lr_scheduler.py:46-76, zs3/utils/metrics.py:35-82.
 Test infrastructure only.
 """
 import numpy as np
@@ -150,3 +151,81 @@ def gmmn_step(model, generator, optimizer, optimizer_generator, criterion, crite
     loss.backward()
     optimizer.step()
     return g_batch, float(loss.item())
+
+
+def gcn_context_step(model, generator, generator_gcn, optimizer, optimizer_generator, optimizer_generator_gcn, criterion,
+                     criterion_generator, image, target, embedding, *, seen, unseen, noise_dim=300, embed_dim=300,
+                     feature_dim=256, batch_size_generator=128, real_seen_features=True, context_aware=False,
+                     gcn_weight=0.1, gcn_avg_feat=False):
+    """One iteration of train_context_GMMN_GCNcontext.py:239-457 (LR scheduling by the caller): the GMMN step plus,
+    per image, a cluster-graph generator update (MMD between the GCN generator's cluster features and the clusters' real
+    seed features, :399-415) and, per batch, a CE term on the clusters' features through `pred_conv` (:431-454).
+    Noise, sample indices and dropout masks come from the CPU default generator in the reference's call order.
+    Returns (generator_loss_batch, generator_GCN_loss_batch, classifier_loss)."""
+    from .gcn import cluster_graph
+    with torch.no_grad():
+        real = model.forward_before_class_prediction(image)  # :259-262
+    b, _, fh, fw = real.shape
+    fake = torch.zeros_like(real)
+    g_batch, g_gcn_batch = 0.0, 0.0
+    feats_gcn, target_gcn = [], []
+    unseen_f, seen_f = [float(u) for u in unseen], [float(s) for s in seen]
+    for i in range(b):
+        real_map = real[i].permute(1, 2, 0).contiguous()                       # [fh, fw, D] (:280)
+        real_i = real_map.view(-1, feature_dim)
+        tgt_map = F.interpolate(target[i][None, None], size=(fh, fw), mode="nearest")  # :282-286
+        tgt_i = tgt_map.reshape(-1)
+        emb_map = F.interpolate(embedding[i][None], size=(fh, fw), mode="nearest")    # :288-297
+        classes = torch.unique(tgt_i)
+        has_unseen = any(float(c) in unseen_f for c in classes)               # :301-304
+        adj, _, labels, emb_gcn, feat_gcn = cluster_graph(tgt_map.numpy().squeeze(), emb_map.numpy().squeeze(),
+                                                          real_map.numpy().transpose(2, 0, 1), avg_feat=gcn_avg_feat)  # :307-322
+        if adj is not None:
+            target_gcn = target_gcn + list(labels)                            # :323-324
+        emb_i = emb_map.permute(0, 2, 3, 1).reshape(-1, embed_dim)             # :327-331
+        fake_i = torch.zeros_like(real_i)
+        g_sample = 0.0
+        for c in classes:                                                     # "normal generator" (:337-376)
+            if float(c) == 255:
+                continue
+            optimizer_generator.zero_grad()
+            mask = tgt_i == c
+            n_c = int(mask.sum())
+            if context_aware:
+                z = emb_i[tgt_i != 255].mean(0).repeat(n_c, 1)                # :345-348
+            else:
+                z = torch.rand((n_c, noise_dim))                              # :350
+            fake_c = generator(emb_i[mask], z.float())
+            if float(c) in seen_f and not has_unseen:                         # :358-373
+                idx = torch.randint(low=0, high=n_c, size=(batch_size_generator,))
+                g_loss = criterion_generator(fake_c[idx], real_i[mask][idx])
+                g_sample += float(g_loss.item())
+                g_loss.backward()
+                optimizer_generator.step()
+            fake_i[mask] = fake_c.detach()                                    # :375
+        g_batch += g_sample / len(classes)                                    # :376
+        chosen = real_i if (real_seen_features and not has_unseen) else fake_i  # :380-396
+        fake[i] = chosen.reshape(fh, fw, feature_dim).permute(2, 0, 1)
+        if adj is not None:                                                   # "GCN generator" (:399-425)
+            optimizer_generator_gcn.zero_grad()
+            emb_gcn_t = torch.from_numpy(np.asarray(emb_gcn)).float()
+            z_gcn = torch.rand((emb_gcn_t.shape[0], noise_dim))               # :402
+            fake_gcn = generator_gcn(emb_gcn_t, z_gcn.float(), torch.from_numpy(adj))
+            real_gcn = torch.from_numpy(np.asarray(feat_gcn)).float()
+            if not has_unseen:                                                # :412-418
+                g_gcn_loss = criterion_generator(fake_gcn, real_gcn)
+                g_gcn_loss.backward()
+                optimizer_generator_gcn.step()
+                g_gcn_batch += float(g_gcn_loss.item())
+            feats_gcn.append((real_gcn if (real_seen_features and not has_unseen) else fake_gcn).detach().numpy())  # :420-427
+    optimizer.zero_grad()                                                      # classification (:431-457)
+    out = model.forward_class_prediction(fake.detach(), image.shape[2:])
+    loss = criterion(out, target)
+    loss.backward()
+    if feats_gcn:
+        f_gcn = torch.from_numpy(np.vstack(feats_gcn).transpose(1, 0).copy())[None, :, :, None]     # [1, D, K, 1] (:438-441)
+        out_gcn = model.decoder.forward_class_prediction(f_gcn)
+        t_gcn = torch.tensor(np.array(target_gcn), dtype=torch.float32)[None, :, None]              # [1, K, 1] (:445-448)
+        (gcn_weight * criterion(out_gcn, t_gcn)).backward()
+    optimizer.step()
+    return g_batch, g_gcn_batch, float(loss.item())

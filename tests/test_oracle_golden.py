@@ -204,6 +204,49 @@ def test_gmmn_trajectory_matches_reference(golden, torch_threads):
     assert np.allclose(stats(m.backbone.conv1.weight), g["stem_stats"], rtol=0, atol=0)  # backbone untouched
 
 
+@pytest.mark.parametrize("tag,avg_feat,context_aware", [("a", False, False), ("b", True, True)])
+def test_gcn_context_trajectory_matches_reference(golden, torch_threads, tag, avg_feat, context_aware):
+    """11 iterations of train_context_GMMN_GCNcontext.py:239-457 at 65x65, B=4: per-iteration classifier / generator /
+    GCN-generator losses and the final generator, GCN generator and pred_conv weights.  (In this container the oracle
+    reproduces the reference's 11-iteration trajectory bit for bit -- which needs the MMD's ops recorded in the
+    reference's order, see mmd_loss; the tolerances leave room for a different CPU / thread count.)"""
+    g = golden("gcn_traj.npz")
+    seen = [c for c in range(21) if c not in (10, 14)]
+    torch.manual_seed(1)
+    m = zo.DeepLab(num_classes=21, pretrained=False)
+    gen = zo.GMMNnetwork(300, 300, 256, 256)
+    gcn = zo.GMMNnetwork_GCN(300, 300, 256, 256)
+    torch.manual_seed(3)
+    for layer in (gcn.gcn1, gcn.gcn2):
+        nn.init.xavier_uniform_(layer.weight)
+    assert np.array_equal(gcn.gcn1.weight.detach().numpy()[:8, :8], g[f"{tag}_gcn1_w0_corner"])
+    params = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+    opt = torch.optim.SGD(params, momentum=0.9, weight_decay=5e-4, nesterov=False)
+    opt_g = torch.optim.Adam(gen.parameters(), lr=2e-4)
+    opt_c = torch.optim.Adam(gcn.parameters(), lr=2e-4)
+    w = torch.ones(21)
+    w[[10, 14]] = 100.0
+    crit = zo.SegmentationLosses(weight=w).build_loss("ce")
+    mmd = zo.GMMNLoss().build_loss()
+    m.train(), gen.train(), gcn.train()
+    torch.manual_seed(17)
+    closs, gloss, gcnloss = [], [], []
+    for it in range(11):
+        b = zo.make_synthetic_batch(4, 65, seed=400 + it, with_label_emb=True)
+        zo.apply_lr(opt, zo.poly_lr(0.007, it, 0, 11, 2))
+        gl, gcl, cl = zo.gcn_context_step(m, gen, gcn, opt, opt_g, opt_c, crit, mmd, b["image"], b["label"], b["label_emb"],
+                                          seen=seen, unseen=[10, 14], gcn_avg_feat=avg_feat, context_aware=context_aware)
+        closs.append(cl), gloss.append(gl), gcnloss.append(gcl)
+    assert np.allclose(closs, g[f"{tag}_closs"], rtol=1e-5), (closs, g[f"{tag}_closs"])
+    assert np.allclose(gloss, g[f"{tag}_gloss"], rtol=1e-5), (gloss, g[f"{tag}_gloss"])
+    assert np.allclose(gcnloss, g[f"{tag}_gcnloss"], rtol=1e-5), (gcnloss, g[f"{tag}_gcnloss"])
+    check_table(gen.state_dict().items(), g[f"{tag}_gen_names"], g[f"{tag}_gen_stats"], rtol=1e-3, atol=1e-4, what="gen")
+    check_table(gcn.state_dict().items(), g[f"{tag}_gcn_names"], g[f"{tag}_gcn_stats"], rtol=1e-3, atol=1e-4, what="gcn")
+    sub = {k: v for k, v in m.state_dict().items() if "pred_conv" in k}
+    check_table(sub.items(), g[f"{tag}_model_names"], g[f"{tag}_model_stats"], rtol=1e-3, atol=1e-4, what="model")
+    assert np.allclose(gcn.gcn1.weight.detach().numpy()[:8, :8], g[f"{tag}_gcn1_w_corner"], rtol=1e-3, atol=1e-5)
+
+
 def test_host_logic_matches_reference(golden):
     g = golden("misc.npz")
     lrs = [[zo.poly_lr(0.007, it, ep, 11, 3), 10 * zo.poly_lr(0.007, it, ep, 11, 3)] for ep in range(3) for it in range(11)]

@@ -374,10 +374,73 @@ def g_gcn():
     save("gcn_graph.npz", **out)
 
 
+# --------------------------------------------------------------------------- G9: GCN-context trajectory (8f N3)
+def g_gcn_traj():
+    """train_context_GMMN_GCNcontext.py Trainer.training driven on CPU.  The loop calls .cuda() unconditionally on the
+    cluster tensors (:400-412, :441-449); for this CPU run Tensor.cuda is replaced by the identity while it executes."""
+    import zs3.train_context_GMMN_GCNcontext as T
+    from zs3.modeling.gmmn import GMMNnetwork_GCN as RefGCN
+
+    seen = [c for c in range(21) if c not in (10, 14)]
+    unseen = [10, 14]
+    out = {}
+    for tag, avg_feat, context_aware in (("a", False, False), ("b", True, True)):
+        args = types.SimpleNamespace(cuda=False, batch_size=2, dataset="pascal", no_val=False, feature_dim=256, embed_dim=300,
+                                     noise_dim=300, batch_size_generator=128, unseen_classes_idx_metric=unseen,
+                                     seen_classes_idx_metric=seen, real_seen_features=True, context_aware=context_aware,
+                                     GCN_weight=0.1, GCN_avg_feat=avg_feat, semantic_reconstruction=False)
+        torch.manual_seed(1)
+        m = RefDeepLab(num_classes=21, pretrained=False, sync_bn=False)
+        gen = RefGMMN(300, 300, 256, 256)
+        gcn = RefGCN(300, 300, 256, 256)
+        # pygcn's own reset_parameters (not reproduced by the import stub) consumes RNG before the reference's xavier
+        # init: re-draw the weights under their own seed so that a checker can start from the same generator
+        torch.manual_seed(3)
+        for layer in (gcn.gcn1, gcn.gcn2):
+            torch.nn.init.xavier_uniform_(layer.weight)
+        params = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+        tr = T.Trainer.__new__(T.Trainer)
+        tr.args = args
+        tr.model = _Module(m)
+        tr.generator, tr.generator_GCN = gen, gcn
+        tr.optimizer = torch.optim.SGD(params, momentum=0.9, weight_decay=5e-4, nesterov=False)
+        tr.optimizer_generator = torch.optim.Adam(gen.parameters(), lr=2e-4)
+        tr.optimizer_generator_GCN = torch.optim.Adam(gcn.parameters(), lr=2e-4)
+        w = torch.ones(21)
+        w[unseen] = 100.0
+        tr.criterion = RefSegLoss(weight=w, cuda=False).build_loss("ce")
+        tr.criterion_generator = RefGMMNLoss(sigma=[2, 5, 10, 20, 40, 80]).build_loss()
+        tr.scheduler = RefLR("poly", 0.007, 2, 11)
+        tr.best_pred = 0.0
+        tr.writer = _Writer()
+        tr.summary = _Summary()
+        tr.train_loader = _loader(11, 4, 65, 400, True)
+        init = {k: v.clone() for k, v in gcn.state_dict().items()}
+        torch.manual_seed(17)
+        real_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            tr.training(0, args)
+        finally:
+            torch.Tensor.cuda = real_cuda
+        sc = tr.writer.scalars
+        gn, gs = table(gen.state_dict().items())
+        cn, cs = table(gcn.state_dict().items())
+        mn, ms = table((k, v) for k, v in m.state_dict().items() if "pred_conv" in k)
+        out.update({f"{tag}_closs": np.array([v for _, v in sc["train/total_loss_iter"]]),
+                    f"{tag}_gloss": np.array([v for _, v in sc["train/generator_loss"]]),
+                    f"{tag}_gcnloss": np.array([v for _, v in sc["train/generator_GCN_loss"]]),
+                    f"{tag}_gen_names": gn, f"{tag}_gen_stats": gs, f"{tag}_gcn_names": cn, f"{tag}_gcn_stats": cs,
+                    f"{tag}_model_names": mn, f"{tag}_model_stats": ms,
+                    f"{tag}_gcn1_w_corner": gcn.gcn1.weight.detach().numpy()[:8, :8].copy(),
+                    f"{tag}_gcn1_w0_corner": init["gcn1.weight"].numpy()[:8, :8].copy()})
+    save("gcn_traj.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["init", "forward", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc", "gcn"]
+    which = sys.argv[1:] or ["init", "forward", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc", "gcn", "gcn_traj"]
     for w in which:
         {"init": g_init, "forward": g_forward, "supervised": g_supervised, "mmd": g_mmd, "gmmn_mlp": g_gmmn_mlp,
-         "gmmn_traj": g_gmmn_traj, "misc": g_misc, "gcn": g_gcn}[w]()
+         "gmmn_traj": g_gmmn_traj, "misc": g_misc, "gcn": g_gcn, "gcn_traj": g_gcn_traj}[w]()
