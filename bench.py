@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=513)
     ap.add_argument("--classes", type=int, default=21)
-    ap.add_argument("--workload", choices=["supervised", "gmmn"], default="supervised")
+    ap.add_argument("--workload", choices=["supervised", "gmmn", "gcn_context"], default="supervised")
     ap.add_argument("--gmmn-steps", type=int, default=2)
     ap.add_argument("--sync-bn", type=int, default=0)
     ap.add_argument("--ddp-selftest", action="store_true",
@@ -132,12 +132,22 @@ def main():
         opt_g = Adam(gen.parameters(), lr=2e-4)
         w = torch.ones(args.classes, device=dev)
         w[unseen] = 100.0
-        dp = multi and args.workload == "gmmn"
+        dp = multi and args.workload != "supervised"
         crit_g = SegmentationLosses(weight=w, cuda=True, group=True if dp else None).build_loss("ce")
         gb = make_batch(args.batch, args.size, args.classes, unseen, seed=101 + rank, with_label_emb=True, device=dev)
         if dp:
             broadcast_parameters(gen)
-        stepper = GMMNStep(model, gen, opt, opt_g, crit_g, seen=seen, unseen=unseen, noise="device", group=True if dp else None)
+        if args.workload == "gcn_context":    # train_context_GMMN_GCNcontext.py step (BASELINE configs[4] flow)
+            from zs3_amd.gcn_trainer import GCNContextStep
+            from zs3_amd.modeling.gmmn import GMMNnetwork_GCN
+            gcn = GMMNnetwork_GCN(300, 300, 256, 256).to(dev).train()
+            if dp:
+                broadcast_parameters(gcn)
+            stepper = GCNContextStep(model, gen, gcn, opt, opt_g, Adam(gcn.parameters(), lr=2e-4), crit_g, seen=seen,
+                                     unseen=unseen, noise="device", group=True if dp else None)
+        else:
+            stepper = GMMNStep(model, gen, opt, opt_g, crit_g, seen=seen, unseen=unseen, noise="device",
+                               group=True if dp else None)
         return lambda i: stepper(gb["image"], gb["label"], gb["label_emb"])
 
     if args.workload == "supervised":
@@ -189,7 +199,9 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate; fp32 storage)", "data": "synthetic",
         "config": {"workload": ("train_pascal.py supervised step: DeepLabv3+ ResNet-101 fwd+CE+bwd+SGD (BASELINE configs[1])"
-                                if args.workload == "supervised" else "train_pascal_GMMN.py step (BASELINE configs[2])"),
+                                if args.workload == "supervised" else
+                                "train_pascal_GMMN.py step (BASELINE configs[2])" if args.workload == "gmmn" else
+                                "train_context_GMMN_GCNcontext.py step (GCN-context flow of BASELINE configs[4], fp32 arithmetic as above)"),
                    "image": f"{args.size}x{args.size}", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "classes": args.classes, "parallelism": f"dp{world}", "sync_bn": bool(args.sync_bn)},
         "model_tflops": value * gflop_img / 1e3,

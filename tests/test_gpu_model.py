@@ -250,3 +250,62 @@ def test_gmmn_step_vs_oracle(dev):
     assert torch.equal(m.backbone.conv1.weight.detach(), stem0)           # backbone receives no gradient
     assert not torch.equal(m.backbone.bn1.running_mean, rm0)              # but BN statistics drift (train() mode)
     assert rel(m.backbone.bn1.running_mean, ref.backbone.bn1.running_mean) < 1e-3
+
+
+@pytest.mark.parametrize("context_aware,avg_feat", [(False, False), (True, True)])
+def test_gcn_context_step_vs_oracle(dev, context_aware, avg_feat):
+    """train_context_GMMN_GCNcontext.py:239-457 with the reference's CPU noise stream: per-step generator,
+    graph-generator and classifier losses and the updated generators / pred_conv agree with the oracle (which reproduces
+    the reference's own trajectory bit for bit, tests/test_oracle_golden.py)."""
+    import zs3_oracle as zo
+    from zs3_amd.gcn_trainer import GCNContextStep
+    from zs3_amd.modeling.gmmn import GMMNnetwork, GMMNnetwork_GCN
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    seen = [c for c in range(21) if c not in (10, 14)]
+    m, ref = build_pair(tame=True)
+    torch.manual_seed(2)
+    gen, gcn = GMMNnetwork(300, 300, 256, 256), GMMNnetwork_GCN(300, 300, 256, 256)
+    gen_r, gcn_r = zo.GMMNnetwork(300, 300, 256, 256), zo.GMMNnetwork_GCN(300, 300, 256, 256)
+    gen_r.load_state_dict(gen.state_dict())
+    gcn_r.load_state_dict(gcn.state_dict())
+    for net in (gen, gen_r):
+        net.model[2].p = 0.0
+    for net in (gcn, gcn_r):
+        net.dropout.p = 0.0
+    m, gen, gcn = m.to(dev).train(), gen.to(dev).train(), gcn.to(dev).train()
+    ref.train(), gen_r.train(), gcn_r.train()
+    w = torch.ones(21)
+    w[[10, 14]] = 100.0
+
+    def groups(mod, lr):
+        return [{"params": mod.get_1x_lr_params(), "lr": lr}, {"params": mod.get_10x_lr_params(), "lr": lr * 10}]
+
+    opt, opt_g, opt_c = SGD(groups(m, 0.007), momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4), \
+        Adam(gcn.parameters(), lr=2e-4)
+    opt_r = torch.optim.SGD(groups(ref, 0.007), momentum=0.9, weight_decay=5e-4)
+    opt_gr, opt_cr = torch.optim.Adam(gen_r.parameters(), lr=2e-4), torch.optim.Adam(gcn_r.parameters(), lr=2e-4)
+    step = GCNContextStep(m, gen, gcn, opt, opt_g, opt_c, SegmentationLosses(weight=w.to(dev), cuda=True).build_loss("ce"),
+                          seen=seen, unseen=[10, 14], noise="cpu", GCN_weight=0.1, GCN_avg_feat=avg_feat,
+                          context_aware=context_aware)
+    for it in range(2):
+        b = zo.make_synthetic_batch(4, 65, seed=500 + it, with_label_emb=True)
+        torch.manual_seed(31 + it)
+        gl_r, gcl_r, cl_r = zo.gcn_context_step(ref, gen_r, gcn_r, opt_r, opt_gr, opt_cr,
+                                                zo.SegmentationLosses(weight=w).build_loss("ce"), zo.GMMNLoss().build_loss(),
+                                                b["image"], b["label"], b["label_emb"], seen=seen, unseen=[10, 14],
+                                                gcn_weight=0.1, gcn_avg_feat=avg_feat, context_aware=context_aware)
+        torch.manual_seed(31 + it)
+        gl, gcl, cl, out = step(b["image"].to(dev), b["label"].to(dev), b["label_emb"].to(dev))
+        assert step.last_num_clusters > 100           # 4 images x (up to 49 cells + border) clusters
+        assert abs(gl - gl_r) < 2e-3 * abs(gl_r), (it, gl, gl_r)
+        assert abs(gcl - gcl_r) < 2e-3 * abs(gcl_r), (it, gcl, gcl_r)
+        assert abs(cl - cl_r) < 1e-3 * abs(cl_r), (it, cl, cl_r)
+        assert out.shape == (4, 21, 65, 65)
+    for net, net_r in ((gen, gen_r), (gcn, gcn_r)):
+        for (k, p), (_, pr) in zip(net.named_parameters(), net_r.named_parameters()):
+            # Adam: see test_gmmn_step_vs_oracle (elements with ~0 gradient move by +-lr on rounding noise)
+            assert rel(p, pr) < 2e-2, k
+            assert ((p.detach().cpu() - pr.detach()).abs().mean() / pr.detach().abs().mean()).item() < 2e-3, k
+    assert rel(m.decoder.pred_conv.weight, ref.decoder.pred_conv.weight) < 2e-3
+    assert rel(m.decoder.pred_conv.bias, ref.decoder.pred_conv.bias) < 2e-3

@@ -244,6 +244,18 @@ def test_mmd_against_golden_and_oracle(dev, golden):
         assert rel(gen.grad, g64.grad) < 5e-4, name
     real = torch.randn(128, 256, generator=torch.Generator().manual_seed(5)).to(dev)
     assert crit(real.clone(), real).item() == 0.0  # identical inputs -> exactly 0, like the reference
+    # sample counts that are not a multiple of the 32-wide tiles (the GCN-context cluster update: N = number of clusters)
+    gq = torch.Generator().manual_seed(6)
+    for n in (2, 44, 97, 161):
+        gen_c, real_c = torch.randn(n, 256, generator=gq) * 0.3, torch.randn(n, 256, generator=gq) * 0.3
+        gen = gen_c.clone().to(dev).requires_grad_(True)
+        loss = crit(gen, real_c.to(dev))
+        loss.backward()
+        g64 = gen_c.double().requires_grad_(True)
+        ref = zo.mmd_loss(g64, real_c.double())
+        ref.backward()
+        assert abs(loss.item() ** 2 - ref.item() ** 2) <= 2e-6, n
+        assert rel(gen.grad, g64.grad) < 5e-4, n
 
 
 def test_dropout_statistics_and_backward(dev):

@@ -46,6 +46,33 @@ class ClusterGraph:
         return (self.adj_sparse(), self.pixel_index(), self.labels.cpu().tolist(), self.embedding.cpu().numpy(), feat)
 
 
+def cluster_graph_rows(seg, emb_rows, feat_rows=None, max_clusters=2048):
+    """seg: [H, W] label map (any dtype); emb_rows: [H*W, E], feat_rows: [H*W, D] or None -- pixel-major rows, the layout
+    the GMMN step already holds.  -> ClusterGraph.  One kernel + one 4-byte read-back (the graph size decides the shapes
+    of everything downstream) + two row gathers."""
+    require_gpu(seg, emb_rows, feat_rows)
+    h, w = seg.shape
+    if h * w > lib().zs3_cluster_graph_max_pixels():
+        raise ValueError(f"label map of {h}x{w} pixels exceeds the single-workgroup limit of zs3_cluster_graph")
+    dev = seg.device
+    seg = seg.to(torch.int32).contiguous()
+    cmap = torch.empty((h, w), dtype=torch.int32, device=dev)
+    cap = int(max_clusters)
+    seed = torch.zeros(cap, dtype=torch.int32, device=dev)
+    labels = torch.zeros(cap, dtype=torch.int32, device=dev)
+    ncl = torch.zeros(1, dtype=torch.int32, device=dev)
+    adj = torch.zeros((cap, cap), dtype=torch.float32, device=dev)
+    check(lib().zs3_cluster_graph(P(seg), I(h), I(w), P(cmap), P(seed), P(labels), P(ncl), P(adj), I(cap), stream()),
+          "zs3_cluster_graph")
+    n = int(ncl.item())
+    if n > cap:
+        raise ValueError(f"{n} clusters in the label map, max_clusters={cap}")
+    seeds = seed[:n].long()
+    emb = ops.gather_rows(emb_rows.float().contiguous(), seeds)
+    feat = ops.gather_rows(feat_rows.float().contiguous(), seeds) if feat_rows is not None else None
+    return ClusterGraph(adj[:n, :n].contiguous() if n > 1 else None, cmap, labels[:n].long(), seeds, emb, feat)
+
+
 def construct_adj_mat(segmap, embeddingmap, featmap=None, avg_feat=False, max_clusters=2048):
     """segmap: [H, W] class map; embeddingmap: [E, H, W]; featmap: [D, H, W] or None -- CUDA tensors.
 
@@ -55,26 +82,6 @@ def construct_adj_mat(segmap, embeddingmap, featmap=None, avg_feat=False, max_cl
     reference's value; bit-identical for avg_feat=False)."""
     require_gpu(segmap, embeddingmap, featmap)
     h, w = segmap.shape
-    if h * w > lib().zs3_cluster_graph_max_pixels():
-        raise ValueError(f"label map of {h}x{w} pixels exceeds the single-workgroup limit of zs3_cluster_graph")
-    dev = segmap.device
-    seg = segmap.to(torch.int32).contiguous()
-    cmap = torch.empty((h, w), dtype=torch.int32, device=dev)
-    cap = int(max_clusters)
-    seed = torch.zeros(cap, dtype=torch.int32, device=dev)
-    labels = torch.zeros(cap, dtype=torch.int32, device=dev)
-    ncl = torch.zeros(1, dtype=torch.int32, device=dev)
-    adj = torch.zeros((cap, cap), dtype=torch.float32, device=dev)
-    check(lib().zs3_cluster_graph(P(seg), I(h), I(w), P(cmap), P(seed), P(labels), P(ncl), P(adj), I(cap), stream()),
-          "zs3_cluster_graph")
-    n = int(ncl.item())   # the one host read: the graph size decides tensor shapes downstream
-    if n > cap:
-        raise ValueError(f"{n} clusters in the label map, max_clusters={cap}")
-    seeds = seed[:n].long()
     emb_rows = embeddingmap.reshape(embeddingmap.shape[0], h * w).t().contiguous()
-    emb = ops.gather_rows(emb_rows.float(), seeds)
-    feat = None
-    if featmap is not None:
-        feat_rows = featmap.reshape(featmap.shape[0], h * w).t().contiguous()
-        feat = ops.gather_rows(feat_rows.float(), seeds)
-    return ClusterGraph(adj[:n, :n].contiguous() if n > 1 else None, cmap, labels[:n].long(), seeds, emb, feat)
+    feat_rows = featmap.reshape(featmap.shape[0], h * w).t().contiguous() if featmap is not None else None
+    return cluster_graph_rows(segmap, emb_rows, feat_rows, max_clusters)

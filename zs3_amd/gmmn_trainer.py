@@ -45,10 +45,13 @@ def _rows_gemm(x, wp, b, act=Fz.ACT_NONE, leak=0.2):
 class GMMNStep:
     def __init__(self, model, generator, optimizer, optimizer_generator, criterion, *, seen, unseen, noise_dim=300,
                  embed_dim=300, feature_dim=256, batch_size_generator=128, real_seen_features=True,
-                 sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True, group=None, grad_reduce=None):
+                 sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True, group=None, grad_reduce=None,
+                 context_aware=False):
         """group: None (single process) | True (default process group) | a torch.distributed group.
         grad_reduce: "sum" when `criterion` already normalises by the global batch / valid-pixel weight
-        (SegmentationLosses(group=...)), "mean" when it normalises per rank; default: picked from the criterion."""
+        (SegmentationLosses(group=...)), "mean" when it normalises per rank; default: picked from the criterion.
+        context_aware: the generator's second input is the image's mean embedding over labelled pixels instead of
+        noise (train_context_GMMN_GCNcontext.py:345-348)."""
         self.model = model.module if hasattr(model, "module") else model
         self.generator = generator
         self.optimizer, self.optimizer_generator = optimizer, optimizer_generator
@@ -58,6 +61,9 @@ class GMMNStep:
         self.bsg, self.real_seen_features = batch_size_generator, real_seen_features
         self.sigma = tuple(float(s) for s in sigma)
         self.noise = noise
+        self.context_aware = bool(context_aware)
+        if self.context_aware and noise_dim != embed_dim:
+            raise ValueError("context_aware feeds the mean embedding where the noise goes: noise_dim must equal embed_dim")
         self.group = group
         if grad_reduce is None:
             owner = getattr(criterion, "__self__", None)
@@ -145,7 +151,7 @@ class GMMNStep:
         lin1, lrelu, drop, lin2 = self._layers()
         s, d = self.bsg, self.feature_dim
         width = self.embed_dim + self.noise_dim
-        if self.noise != "cpu":   # noise drawn inside the gather (same stream as zs3_uniform on a [S, noise_dim] tensor)
+        if self.noise != "cpu" and not self.context_aware:   # noise drawn inside the gather (same stream as zs3_uniform on a [S, noise_dim] tensor)
             x = ops.gather_cat_noise(st["emb"], st["pix_local"], self.embed_dim, self.noise_dim, width, s, st["seed_base"],
                                      seed_dev=st["seed_dev"])
         else:
@@ -207,7 +213,7 @@ class GMMNStep:
         if not self.use_graph:
             self._sampled_update(training)
         else:
-            key = (training, self.noise)
+            key = (training, self.noise, self.context_aware)
             if self._graph is None or self._graph[0] != key:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
@@ -257,6 +263,17 @@ class GMMNStep:
         lin2.weight.grad, lin2.bias.grad = dw2.view(lin2.weight.shape), db2
         self.optimizer_generator.step()
         self._resplit()
+
+    # ------------------------------------------------------------------ extension points (GCN-context step)
+    def _after_image(self, i, label_map, real_rows_i, has_unseen):
+        """called after image i's generator updates; self._st["emb"] holds its embedding rows at feature resolution"""
+
+    def _extra_classifier_terms(self):
+        """called after the CE backward of the stitched batch, before the gradient exchange and the SGD step"""
+
+    def _replica_parameters(self):
+        """parameters averaged over the ranks once per step in multi-GPU runs"""
+        return list(self.generator.parameters())
 
     # ------------------------------------------------------------------ one iteration
     def __call__(self, image, target, embedding=None, table=None):
@@ -311,6 +328,11 @@ class GMMNStep:
                 fake_rows[i].copy_(real_rows[i])
             else:
                 fake_rows[i].zero_()   # ignore-label pixels keep zero features (:198, :242)
+            ctx = None
+            if self.context_aware:    # mean embedding over the labelled pixels (255 sorts last in `order`)
+                n_valid = npix - int(hist_h[i][255])
+                ctx = ops.colsum(ops.gather_rows(st["emb"], order[i, :n_valid])) / max(n_valid, 1)
+                st["z"].copy_(ctx.view(1, -1).expand(self.bsg, -1))
             off = 0
             for c in classes:
                 n_c = int(hist_h[i][c])
@@ -320,7 +342,7 @@ class GMMNStep:
                     continue
                 do_mmd = c in self.seen and not has_unseen
                 sampled_only = do_mmd and use_real and self.fused_adam
-                z_cpu = torch.rand((n_c, self.noise_dim)) if self.noise == "cpu" else None
+                z_cpu = torch.rand((n_c, self.noise_dim)) if (self.noise == "cpu" and ctx is None) else None
                 ridx_cpu = torch.randint(low=0, high=n_c, size=(self.bsg,)) if do_mmd else None
                 if sampled_only:
                     ring = st["ring"][st["ring_pos"] % 512]
@@ -338,7 +360,10 @@ class GMMNStep:
                     slot += 1
                     continue
                 # full-class generator call (image with an unseen class, or caller-supplied optimizer)
-                z = z_cpu.to(dev) if z_cpu is not None else ops.uniform((n_c, self.noise_dim), Fz.next_seed(), dev)
+                if ctx is not None:
+                    z = ctx.view(1, -1).expand(n_c, -1).contiguous()
+                else:
+                    z = z_cpu.to(dev) if z_cpu is not None else ops.uniform((n_c, self.noise_dim), Fz.next_seed(), dev)
                 x = ops.gather_cat(st["emb"], idx_c, self.embed_dim, z, self.noise_dim, self.embed_dim + self.noise_dim)
                 fake_c, h, hd, seed = self._generator_forward(x, training)
                 if do_mmd:
@@ -360,18 +385,20 @@ class GMMNStep:
                     slot += 1
                 if not use_real:
                     ops.scatter_rows(fake_c, idx_c, fake_rows[i])
+            self._after_image(i, tgt_l[i].view(fh, fw), real_rows[i], has_unseen)
         pg = None if self.group is True else self.group
         if self.group is not None:   # generator replicas -> their average (parameters only; Adam moments stay per rank)
             from .parallel import all_reduce_tensors
-            gen_params = [p.data for p in self.generator.parameters()]
+            gen_params = [p.data for p in self._replica_parameters()]
             self.bytes_reduced += all_reduce_tensors(gen_params, group=pg, average=True)
-            Fz.invalidate_planes(*self.generator.parameters())
+            Fz.invalidate_planes(*self._replica_parameters())
             self._resplit()
         # ---- classifier update on the stitched features (only pred_conv receives gradients)
         self.optimizer.zero_grad()
         out = model.forward_class_prediction(ops.nchw(fake), image.shape[2:])
         closs = self.criterion(out, target)
         closs.backward()
+        self._extra_classifier_terms()
         if self.group is not None:
             grads = [p.grad for g_ in self.optimizer.param_groups for p in g_["params"] if p.grad is not None]
             self.bytes_reduced += all_reduce_tensors(grads, group=pg, average=self.grad_reduce == "mean")
