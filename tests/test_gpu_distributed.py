@@ -91,8 +91,10 @@ def _gmmn_steps(dev, ddp):
     from zs3_amd.utils.loss import SegmentationLosses
     from zs3_amd.utils.synthetic import make_batch
     import zs3_amd.parallel as par
+    from zs3_amd import functional as Fz
     seen = [c for c in range(21) if c not in (10, 14)]
     torch.manual_seed(4)
+    Fz.manual_seed(77)          # device dropout masks (decoder, generator) are a function of this counter
     m = DeepLab(num_classes=21, pretrained=False).to(dev).train()
     gen = GMMNnetwork(300, 300, 256, 256).to(dev).train()
     w = torch.ones(21, device=dev)

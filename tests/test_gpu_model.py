@@ -304,8 +304,46 @@ def test_gcn_context_step_vs_oracle(dev, context_aware, avg_feat):
         assert out.shape == (4, 21, 65, 65)
     for net, net_r in ((gen, gen_r), (gcn, gcn_r)):
         for (k, p), (_, pr) in zip(net.named_parameters(), net_r.named_parameters()):
-            # Adam: see test_gmmn_step_vs_oracle (elements with ~0 gradient move by +-lr on rounding noise)
-            assert rel(p, pr) < 2e-2, k
-            assert ((p.detach().cpu() - pr.detach()).abs().mean() / pr.detach().abs().mean()).item() < 2e-3, k
+            # Adam: see test_gmmn_step_vs_oracle -- an element whose gradient is ~0 moves by +-lr = 2e-4 per update on the
+            # sign of rounding noise, whatever its magnitude.  The graph generator took 6 updates (3 trainable images x 2
+            # steps); its 0.01-sized biases (bias gradient = column sum of the MMD gradient, which nearly cancels) get the
+            # absolute bound of those 6 updates, everything else the relative bounds of the GMMN test.
+            diff = (p.detach().cpu() - pr.detach()).abs()
+            if net is gcn and k.endswith("bias"):
+                assert diff.max().item() <= 6 * 2e-4 * 1.01 and diff.mean().item() < 3 * 2e-4, (k, diff.max().item())
+            else:
+                assert diff.max().item() < 2e-2 * pr.detach().abs().max().item(), (k, diff.max().item())
+                assert (diff.mean() / pr.detach().abs().mean()).item() < 2e-3, k
     assert rel(m.decoder.pred_conv.weight, ref.decoder.pred_conv.weight) < 2e-3
     assert rel(m.decoder.pred_conv.bias, ref.decoder.pred_conv.bias) < 2e-3
+
+
+def test_gradient_accumulation_over_two_backwards(dev):
+    """a second backward before the optimizer step adds into the existing .grad tensors.  Weight gradients are produced on
+    a side stream, and in this case they are read (accumulated) inside the backward pass instead of after its
+    end-of-backward join: the sum must equal the separately computed gradients exactly."""
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.synthetic import make_batch
+    torch.manual_seed(3)
+    m = DeepLab(num_classes=21, pretrained=False).to(dev).train()
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.momentum = 0.0          # keep the running statistics fixed: the three passes see the same model
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    b1, b2 = make_batch(4, 193, seed=11, device=dev), make_batch(4, 193, seed=12, device=dev)
+    single = []
+    for b in (b1, b2):
+        for p in m.parameters():
+            p.grad = None
+        crit(m(b["image"]), b["label"]).backward()
+        single.append([p.grad.clone() for p in m.parameters()])
+    for p in m.parameters():
+        p.grad = None
+    crit(m(b1["image"]), b1["label"]).backward()
+    crit(m(b2["image"]), b2["label"]).backward()
+    torch.cuda.synchronize()
+    for (name, p), g1, g2 in zip(m.named_parameters(), *single):
+        assert torch.equal(p.grad, g1 + g2), name

@@ -358,6 +358,11 @@ class _ConvBnAct(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec)
                 dw.record_stream(main)
+                if not (weight.is_leaf and weight.grad is None):
+                    # the gradient is READ inside this backward pass -- accumulated into an existing .grad (a second
+                    # backward before the optimizer step) or propagated through a non-leaf weight (a transposed /
+                    # computed operand) -- so the main stream cannot wait for the end-of-backward join
+                    main.wait_stream(side)
                 if not _join_armed[0]:
                     _join_armed[0] = True
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
