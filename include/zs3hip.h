@@ -213,6 +213,11 @@ int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
 int zs3_cluster_graph_max_pixels(void);
 int zs3_cluster_graph(const int* seg, int H, int W, int* cmap, int* seed, int* labels, int* ncluster, float* adj, int cap,
                       void* stream);
+/* B label maps in one launch (one workgroup each): seg/cmap [B][H][W], seed/labels [B][cap], ncluster [B], adj [B][cap][cap].
+ * The GCN-context step (train_context_GMMN_GCNcontext.py:307-322 inside the per-image loop) builds the graphs of the whole
+ * batch up front and reads the B cluster counts back once. */
+int zs3_cluster_graph_batch(const int* seg, int B, int H, int W, int* cmap, int* seed, int* labels, int* ncluster, float* adj,
+                            int cap, void* stream);
 
 #ifdef __cplusplus
 }

@@ -352,6 +352,37 @@ def test_cluster_graph_matches_reference_goldens(dev):
     assert sorted(ref[1].keys()) == list(range(cg.num_clusters)) and sum(len(v) for v in ref[1].values()) == seg.numel()
 
 
+def test_cluster_graph_batch_matches_oracle(dev):
+    """zs3_cluster_graph_batch: the graphs of a whole batch from one launch equal the (reference-pinned) oracle's graphs of
+    the single maps -- maps with very different cluster counts side by side, including a one-cluster map"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import numpy as np
+    import zs3_oracle as zo
+    from zs3_amd.gcn_context import ClusterGraphBatch
+    rng = np.random.RandomState(5)
+    h, w = 33, 29
+    maps = [np.kron(rng.randint(0, 6, size=(11, 1)), np.ones((3, w), dtype=np.int64)),       # horizontal bands
+            rng.randint(0, 3, size=(h, w)),                                                   # salt and pepper
+            np.full((h, w), 7, dtype=np.int64),                                               # a single cluster
+            np.where(rng.rand(h, w) < 0.1, 255, np.kron(rng.randint(0, 20, size=(3, 1)), np.ones((11, w), dtype=np.int64)))]
+    emb = rng.randn(len(maps), h * w, 6).astype(np.float32)
+    feat = rng.randn(len(maps), h * w, 5).astype(np.float32)
+    batch = ClusterGraphBatch(torch.from_numpy(np.stack(maps)).to(dev), max_clusters=1024)
+    assert len(batch.counts) == len(maps)
+    for i, seg in enumerate(maps):
+        adj, cmap, labels, e, f = zo.cluster_graph(seg, emb[i].T.reshape(6, h, w), feat[i].T.reshape(5, h, w))
+        g = batch.graph(i, torch.from_numpy(emb[i]).to(dev), torch.from_numpy(feat[i]).to(dev))
+        assert batch.counts[i] == len(labels) == g.num_clusters
+        assert np.array_equal(g.cluster_map.cpu().numpy(), cmap) and np.array_equal(g.labels.cpu().numpy(), labels)
+        assert (g.adj is None) == (adj is None)
+        if adj is not None:
+            assert np.array_equal(g.adj.cpu().numpy(), adj)
+        assert np.array_equal(g.embedding.cpu().numpy(), e) and np.array_equal(g.feature.cpu().numpy(), f)
+    with pytest.raises(ValueError):
+        ClusterGraphBatch(torch.from_numpy(np.stack(maps)).to(dev), max_clusters=16).counts
+
+
 def test_gcn_generator_forward_backward(dev):
     """GMMNnetwork_GCN (gmmn.py:52-67) on the row-GEMM kernels vs adj @ (x @ W) + b in fp64 (pygcn's published form)"""
     from zs3_amd.modeling.gmmn import GMMNnetwork_GCN

@@ -3,7 +3,8 @@
 // image) -- 8-connected components of equal label numbered in raster order of their first pixel, the symmetric
 // "touches in the 8-neighbourhood" adjacency between them, and each cluster's seed pixel.
 //
-// One workgroup per label map (the maps are at feature resolution, <= 129x129): labels live in LDS, every pass
+// One workgroup per label map (the maps are at feature resolution, <= 129x129; a batch of maps is one launch, blockIdx.x =
+// image, so that the training step reads all cluster counts back at once): labels live in LDS, every pass
 // replaces a pixel's label by the minimum over its same-class neighbours followed by a pointer jump; the fixed
 // point (label = smallest pixel index of the component) does not depend on the order in which threads run, so
 // the result is deterministic.  Component roots are ranked with a block-wide prefix sum: rank = cluster id in
@@ -23,6 +24,15 @@ __global__ __launch_bounds__(CCL_THREADS) void ccl_graph_kernel(const int* __res
   extern __shared__ int lab[];          // [H*W] labels, then [CCL_THREADS] scan scratch
   __shared__ int changed;
   const int n = H * W, tid = threadIdx.x;
+  {                                      // this block's image
+    const long b = blockIdx.x;
+    seg += b * n;
+    cmap += b * n;
+    seed += b * cap;
+    labels += b * cap;
+    ncluster += b;
+    adj += b * cap * (long)cap;
+  }
   int* scan = lab + n;
   for (int p = tid; p < n; p += CCL_THREADS) lab[p] = p;
   __syncthreads();
@@ -103,9 +113,10 @@ __global__ __launch_bounds__(CCL_THREADS) void ccl_graph_kernel(const int* __res
 
 extern "C" int zs3_cluster_graph_max_pixels(void) { return CCL_MAX_PIX; }
 
-extern "C" int zs3_cluster_graph(const int* seg, int H, int W, int* cmap, int* seed, int* labels, int* ncluster, float* adj,
-                                 int cap, void* stream) {
+extern "C" int zs3_cluster_graph_batch(const int* seg, int B, int H, int W, int* cmap, int* seed, int* labels, int* ncluster,
+                                       float* adj, int cap, void* stream) {
   const int n = H * W;
+  if (B < 1) return 0;
   if (n < 1 || n > CCL_MAX_PIX || cap < 1) return -1;
   const size_t lds = (size_t)(n + CCL_THREADS) * sizeof(int);
   static bool configured = false;
@@ -115,7 +126,12 @@ extern "C" int zs3_cluster_graph(const int* seg, int H, int W, int* cmap, int* s
       return -4;
     configured = true;
   }
-  hipLaunchKernelGGL(ccl_graph_kernel, dim3(1), dim3(CCL_THREADS), lds, (hipStream_t)stream, seg, H, W, cmap, seed, labels,
+  hipLaunchKernelGGL(ccl_graph_kernel, dim3(B), dim3(CCL_THREADS), lds, (hipStream_t)stream, seg, H, W, cmap, seed, labels,
                      ncluster, adj, cap);
   return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_cluster_graph(const int* seg, int H, int W, int* cmap, int* seed, int* labels, int* ncluster, float* adj,
+                                 int cap, void* stream) {
+  return zs3_cluster_graph_batch(seg, 1, H, W, cmap, seed, labels, ncluster, adj, cap, stream);
 }

@@ -46,31 +46,53 @@ class ClusterGraph:
         return (self.adj_sparse(), self.pixel_index(), self.labels.cpu().tolist(), self.embedding.cpu().numpy(), feat)
 
 
+class ClusterGraphBatch:
+    """Cluster graphs of a batch of label maps from ONE launch (zs3_cluster_graph_batch) and one read-back of the B cluster
+    counts; `graph(i, emb_rows, feat_rows)` then assembles image i's ClusterGraph from device slices and two row gathers,
+    without touching the host again."""
+
+    def __init__(self, seg, max_clusters=1024):
+        require_gpu(seg)
+        b, h, w = seg.shape
+        if h * w > lib().zs3_cluster_graph_max_pixels():
+            raise ValueError(f"label map of {h}x{w} pixels exceeds the single-workgroup limit of zs3_cluster_graph")
+        dev = seg.device
+        cap = int(max_clusters)
+        seg = seg.to(torch.int32).contiguous()
+        self.cap = cap
+        self.cmap = torch.empty((b, h, w), dtype=torch.int32, device=dev)
+        self.seed = torch.zeros((b, cap), dtype=torch.int32, device=dev)
+        self.labels = torch.zeros((b, cap), dtype=torch.int32, device=dev)
+        self.ncl = torch.zeros(b, dtype=torch.int32, device=dev)
+        self.adj = torch.zeros((b, cap, cap), dtype=torch.float32, device=dev)
+        check(lib().zs3_cluster_graph_batch(P(seg), I(b), I(h), I(w), P(self.cmap), P(self.seed), P(self.labels), P(self.ncl),
+                                            P(self.adj), I(cap), stream()), "zs3_cluster_graph_batch")
+        self._counts = None
+
+    @property
+    def counts(self):
+        if self._counts is None:
+            self._counts = [int(v) for v in self.ncl.tolist()]     # the one host read
+            if max(self._counts) > self.cap:
+                raise ValueError(f"{max(self._counts)} clusters in a label map, max_clusters={self.cap}")
+        return self._counts
+
+    def graph(self, i, emb_rows, feat_rows=None):
+        n = self.counts[i]
+        seeds = self.seed[i, :n].long()
+        emb = ops.gather_rows(emb_rows, seeds)
+        feat = ops.gather_rows(feat_rows, seeds) if feat_rows is not None else None
+        adj = self.adj[i, :n, :n].contiguous() if n > 1 else None
+        return ClusterGraph(adj, self.cmap[i], self.labels[i, :n].long(), seeds, emb, feat)
+
+
 def cluster_graph_rows(seg, emb_rows, feat_rows=None, max_clusters=2048):
     """seg: [H, W] label map (any dtype); emb_rows: [H*W, E], feat_rows: [H*W, D] or None -- pixel-major rows, the layout
     the GMMN step already holds.  -> ClusterGraph.  One kernel + one 4-byte read-back (the graph size decides the shapes
     of everything downstream) + two row gathers."""
     require_gpu(seg, emb_rows, feat_rows)
-    h, w = seg.shape
-    if h * w > lib().zs3_cluster_graph_max_pixels():
-        raise ValueError(f"label map of {h}x{w} pixels exceeds the single-workgroup limit of zs3_cluster_graph")
-    dev = seg.device
-    seg = seg.to(torch.int32).contiguous()
-    cmap = torch.empty((h, w), dtype=torch.int32, device=dev)
-    cap = int(max_clusters)
-    seed = torch.zeros(cap, dtype=torch.int32, device=dev)
-    labels = torch.zeros(cap, dtype=torch.int32, device=dev)
-    ncl = torch.zeros(1, dtype=torch.int32, device=dev)
-    adj = torch.zeros((cap, cap), dtype=torch.float32, device=dev)
-    check(lib().zs3_cluster_graph(P(seg), I(h), I(w), P(cmap), P(seed), P(labels), P(ncl), P(adj), I(cap), stream()),
-          "zs3_cluster_graph")
-    n = int(ncl.item())
-    if n > cap:
-        raise ValueError(f"{n} clusters in the label map, max_clusters={cap}")
-    seeds = seed[:n].long()
-    emb = ops.gather_rows(emb_rows.float().contiguous(), seeds)
-    feat = ops.gather_rows(feat_rows.float().contiguous(), seeds) if feat_rows is not None else None
-    return ClusterGraph(adj[:n, :n].contiguous() if n > 1 else None, cmap, labels[:n].long(), seeds, emb, feat)
+    batch = ClusterGraphBatch(seg.unsqueeze(0), max_clusters)
+    return batch.graph(0, emb_rows.float(), feat_rows.float() if feat_rows is not None else None)
 
 
 def construct_adj_mat(segmap, embeddingmap, featmap=None, avg_feat=False, max_clusters=2048):

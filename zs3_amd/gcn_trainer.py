@@ -4,8 +4,9 @@
 It is the GMMN step (gmmn_trainer.GMMNStep: frozen-backbone features, per-(image, class) generator updates as hipGraph
 replays, stitched features, CE/SGD step of `pred_conv`) plus
 
-* per image, the cluster graph of the label map at feature resolution (8-connected components, adjacency; :307-322): one
-  kernel (zs3_cluster_graph) in place of the reference's pure-Python depth-first search (0.3-0.5 s per 129x129 image);
+* the cluster graph of every label map at feature resolution (8-connected components, adjacency; :307-322): one launch for
+  the whole batch (zs3_cluster_graph_batch, a workgroup per image) in place of the reference's pure-Python depth-first
+  search (0.3-0.5 s per 129x129 image);
 * per image, one update of the graph generator `GMMNnetwork_GCN` on the clusters (:399-418): embeddings / real features of the
   clusters' seed pixels, noise, two graph convolutions as MFMA row-GEMMs, the MMD between generated and real cluster features
   (N = number of clusters), Adam;
@@ -16,19 +17,20 @@ Reference quirks kept: clusters of label 255 are nodes of the graph and their fe
 are ignored by the loss); a cluster's feature is its *seed* pixel's feature (with GCN_avg_feat the reference re-averages that
 same seed feature, see gcn_context.construct_adj_mat); images with an unseen class train neither generator and contribute
 generated cluster features; an image whose label map is a single cluster contributes nothing (adj_mat is None, :323,:399).
-Host synchronisation: one 4-byte read per image (the number of clusters decides tensor shapes) and the per-step loss read-back.
+Host synchronisation: the B cluster counts (they decide tensor shapes) are read together with the step's class histogram; the
+losses are read back once per step.
 """
 import torch
 
 from . import functional as Fz
 from . import ops
-from .gcn_context import cluster_graph_rows
+from .gcn_context import ClusterGraphBatch
 from .gmmn_trainer import GMMNStep, GMMNTrainer
 
 
 class GCNContextStep(GMMNStep):
     def __init__(self, model, generator, generator_GCN, optimizer, optimizer_generator, optimizer_generator_GCN, criterion,
-                 criterion_generator=None, *, GCN_weight=0.1, GCN_avg_feat=False, max_clusters=2048, **kw):
+                 criterion_generator=None, *, GCN_weight=0.1, GCN_avg_feat=False, max_clusters=1024, **kw):
         """criterion_generator: the MMD callable for the cluster update (default: zs3_amd GMMNLoss with GMMNStep's sigma).
         Remaining keywords: GMMNStep's (seen, unseen, noise_dim, ..., noise, group, context_aware)."""
         super().__init__(model, generator, optimizer, optimizer_generator, criterion, **kw)
@@ -45,9 +47,13 @@ class GCNContextStep(GMMNStep):
     def _replica_parameters(self):
         return list(self.generator.parameters()) + list(self.generator_GCN.parameters())
 
-    # ---- per image: cluster graph + one update of the graph generator (:307-322, :399-427)
+    # ---- per batch: every image's cluster graph in one launch (:307-322), counts read back with the class histogram
+    def _before_images(self, label_maps):
+        self._graphs = ClusterGraphBatch(label_maps, self.max_clusters)
+
+    # ---- per image: one update of the graph generator on its clusters (:399-427)
     def _after_image(self, i, label_map, real_rows_i, has_unseen):
-        graph = cluster_graph_rows(label_map, self._st["emb"], real_rows_i, self.max_clusters)
+        graph = self._graphs.graph(i, self._st["emb"], real_rows_i)
         if graph.adj is None:
             return
         k = graph.num_clusters

@@ -265,6 +265,9 @@ class GMMNStep:
         self._resplit()
 
     # ------------------------------------------------------------------ extension points (GCN-context step)
+    def _before_images(self, label_maps):
+        """called once per step with the [B, fh, fw] label maps at feature resolution, before the step's host read-back"""
+
     def _after_image(self, i, label_map, real_rows_i, has_unseen):
         """called after image i's generator updates; self._st["emb"] holds its embedding rows at feature resolution"""
 
@@ -303,6 +306,7 @@ class GMMNStep:
         tgt_l = ops.nearest_rows(target.contiguous().float(), (fh, fw)).t().contiguous().long()      # [B, npix]
         hist = torch.zeros((b, 256), dtype=torch.int64, device=dev).scatter_add_(1, tgt_l, torch.ones_like(tgt_l))
         order = torch.argsort(tgt_l, dim=1, stable=True)                                          # pixels grouped by class
+        self._before_images(tgt_l.view(b, fh, fw))
         hist_h = hist.cpu().tolist()
         if table is not None:
             table_f = table.contiguous().float()
