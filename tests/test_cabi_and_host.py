@@ -163,3 +163,37 @@ def test_evaluator_matches_the_reference_evaluator():
     assert np.array_equal(np.array(got), g["plain"])
     plain.reset()
     assert plain.confusion_matrix.sum() == 0
+
+
+def test_gcn_context_surface(libpath):
+    """GCN-context pieces: state-dict keys / [in, out] weight layout of the pygcn-based generator
+    (zs3/modeling/gmmn.py:52-67), the step object's constructor contract, host-side limits of the cluster-graph kernel"""
+    from zs3_amd.gcn_trainer import GCNContextStep
+    from zs3_amd.gmmn_trainer import GMMNStep
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.modeling.gmmn import GMMNnetwork, GMMNnetwork_GCN
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    lib = ctypes.CDLL(libpath)
+    assert lib.zs3_cluster_graph_max_pixels() >= 129 * 129
+    assert lib.zs3_cluster_graph_batch(None, 0, 4, 4, None, None, None, None, None, 8, None) == 0      # empty batch: no launch
+    assert lib.zs3_cluster_graph_batch(None, 2, 1000, 1000, None, None, None, None, None, 8, None) == -1   # too many pixels
+    torch.manual_seed(0)
+    gcn = GMMNnetwork_GCN(300, 300, 256, 256)
+    sd = gcn.state_dict()
+    assert list(sd) == ["gcn1.weight", "gcn1.bias", "gcn2.weight", "gcn2.bias"]
+    assert tuple(sd["gcn1.weight"].shape) == (600, 256) and tuple(sd["gcn2.weight"].shape) == (256, 256)
+    assert torch.all(sd["gcn1.bias"] == 0.01) and abs(sd["gcn1.weight"].abs().max().item() - (6 / 856) ** 0.5) < 2e-3
+    m = DeepLab(num_classes=21, pretrained=False, sync_bn=False)
+    gen = GMMNnetwork(300, 300, 256, 256)
+    opt = SGD([{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}], momentum=0.9)
+    crit = SegmentationLosses(cuda=False, group=True).build_loss("ce")
+    step = GCNContextStep(m, gen, gcn, opt, Adam(gen.parameters(), lr=2e-4), Adam(gcn.parameters(), lr=2e-4), crit,
+                          seen=range(19), unseen=[19, 20], GCN_weight=0.25, GCN_avg_feat=True, context_aware=True)
+    assert isinstance(step, GMMNStep) and step.GCN_weight == 0.25 and step.context_aware
+    assert step.grad_reduce == "sum"                       # the criterion normalises globally (group=...)
+    assert len(step._replica_parameters()) == 8            # both generators are averaged over the ranks
+    with pytest.raises(ValueError):                        # context_aware feeds the mean embedding in place of the noise
+        GMMNStep(m, GMMNnetwork(100, 300, 256, 256), opt, None, crit, seen=[0], unseen=[1], noise_dim=100, context_aware=True)
+    with pytest.raises(ValueError):
+        step(torch.zeros(2, 3, 65, 65), torch.zeros(2, 65, 65))      # neither `embedding` nor `table`
