@@ -27,6 +27,8 @@ def pick_tile(m, ncols, k=0):
         return 14
     if m >= 8192 and k >= 512 and (ncols >= 256 or k >= 1152):
         return 31
+    if ncols >= 256 and 128 <= k <= 256:
+        return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
 
 
