@@ -22,11 +22,14 @@ def pick_tile(m, ncols, k=0):
     (11: 128x128, 14: 64x64 block tile), 31 = wave-specialised 256x128 kernel fed by LDS-DMA."""
     # measured on MI355X over the 28 layer shapes of the network, forward and dgrad (tools/probe/conv_bench.py).
     # The LDS-DMA kernel wins wherever there is enough K per tile to amortise its 3-stage ring (K >= 512) and at least
-    # two 128-wide column tiles (or a 3x3-sized K); short-K / narrow layers keep the small-tile kernels: 128x128 when
-    # the launch has >= ~1000 tiles (>= 2 resident per CU for several rounds), else 64x64 (4 blocks per CU).
+    # two 128-wide column tiles; short-K / narrow layers keep the small-tile kernels: 128x128 when the launch has
+    # >= ~1000 tiles (>= 2 resident per CU for several rounds), else 64x64 (4 blocks per CU).  The rules were re-checked
+    # inside the whole step (same-box A/B runs of bench.py): layers that are a toss-up in isolation favour the small
+    # tiles there (3x3 128->128: -0.24 ms per step on 64x64 tiles although the DMA kernel is level in isolation), and
+    # the DMA kernel must keep the 1x1 1024->256 layers (+1.1 ms per step without it).
     if ncols <= 64:
         return 14
-    if m >= 8192 and k >= 512 and (ncols >= 256 or k >= 1152):
+    if m >= 8192 and k >= 512 and ncols >= 256:
         return 31
     if ncols >= 256 and 128 <= k <= 256:
         return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
