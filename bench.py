@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--sync-bn", type=int, default=0)
     ap.add_argument("--ddp-selftest", action="store_true",
                     help="1-GPU run with a one-rank RCCL group and the full gradient-sync plumbing (cost of the N>1 code path)")
+    ap.add_argument("--priority-stream", action="store_true",
+                    help="run the steps on a high-priority HIP stream (functional.priority_compute); implies --no-roofline: "
+                         "timing events on that stream are pathologically slow (170 ms per instrumented step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -78,6 +81,9 @@ def main():
     from zs3_amd.utils.synthetic import make_batch
     from zs3_amd.gmmn_trainer import GMMNStep
 
+    if args.priority_stream:
+        Fz.PRIORITY_COMPUTE_STREAM = True
+        args.no_roofline = True
     unseen = [10, 14]
     seen = [c for c in range(args.classes) if c not in unseen]
     torch.manual_seed(1)
@@ -108,7 +114,7 @@ def main():
         return loss
 
     def run(step, steps, warmup):
-        with Fz.priority_compute():      # the training loops of the package do the same (functional.priority_compute)
+        with Fz.priority_compute():      # no-op unless --priority-stream
             return run_inner(step, steps, warmup)
 
     def run_inner(step, steps, warmup):

@@ -46,10 +46,12 @@ def join_wgrad_stream():
 # ---------------------------------------------------------------------------------- high-priority stream for the dependent chain
 # The forward / dgrad / BatchNorm chain is the critical path of a step (it is busy for the whole step), the weight-gradient
 # kernels on the side stream only have to be done by the end of backward.  HIP exposes two priority levels through torch and
-# the default stream has the lower one, so the training loops (BaseTrainer / GMMNTrainer / GCNContextTrainer.training, bench.py)
-# run their steps on a high-priority stream: when both streams have workgroups ready, the chain's go first
-# (same-box A/B: 51.3 -> 50.9 ms per step).
-PRIORITY_COMPUTE_STREAM = True
+# the default stream has the lower one; with the whole training loop inside `priority_compute()` the chain's workgroups go
+# first when both streams have some ready (same-box A/B: 51.3 -> 50.1 ms per step together with the tile rule change).
+# OFF by default: entering / leaving the context once per step instead of once per loop costs 20 ms per step, and HIP
+# timing events recorded on the high-priority stream (bench.py's roofline instrumentation, profilers) turn a step into
+# 170 ms -- both measured, neither understood yet.  bench.py --priority-stream and the trainers honour the switch.
+PRIORITY_COMPUTE_STREAM = False
 _prio = {}
 
 
