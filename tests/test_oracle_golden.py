@@ -172,7 +172,9 @@ def test_gmmn_mlp_matches_reference(golden):
 
 
 def test_gmmn_trajectory_matches_reference(golden, torch_threads):
-    """11 iterations of train_pascal_GMMN.py:139-268 at 65x65, B=4 (image 3 holds an unseen class)."""
+    """11 iterations of train_pascal_GMMN.py:139-268 at 65x65, B=4 (image 3 holds an unseen class).  In this container
+    the oracle reproduces the reference's trajectory exactly (difference 0.0 in every logged loss); the tolerances leave
+    room for another CPU / thread count."""
     g = golden("gmmn_traj.npz")
     seen = [c for c in range(21) if c not in (10, 14)]
     torch.manual_seed(1)
@@ -196,8 +198,8 @@ def test_gmmn_trajectory_matches_reference(golden, torch_threads):
                               unseen=[10, 14])
         closs.append(cl)
         gloss.append(gl)
-    assert np.allclose(closs, g["closs"], rtol=1e-4), (closs, g["closs"])
-    assert np.allclose(gloss, g["gloss"], rtol=1e-4), (gloss, g["gloss"])
+    assert np.allclose(closs, g["closs"], rtol=1e-5), (closs, g["closs"])
+    assert np.allclose(gloss, g["gloss"], rtol=1e-5), (gloss, g["gloss"])
     check_table(gen.state_dict().items(), g["gen_names"], g["gen_stats"], rtol=1e-3, atol=1e-4, what="gen")
     sub = {k: v for k, v in m.state_dict().items() if ("pred_conv" in k or "running_mean" in k)}
     check_table(sub.items(), g["model_names"], g["model_stats"], rtol=1e-3, atol=1e-4, what="model")
