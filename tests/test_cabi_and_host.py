@@ -197,3 +197,18 @@ def test_gcn_context_surface(libpath):
         GMMNStep(m, GMMNnetwork(100, 300, 256, 256), opt, None, crit, seen=[0], unseen=[1], noise_dim=100, context_aware=True)
     with pytest.raises(ValueError):
         step(torch.zeros(2, 3, 65, 65), torch.zeros(2, 65, 65))      # neither `embedding` nor `table`
+
+
+def test_priority_compute_is_a_noop_without_a_gpu_and_when_disabled():
+    """functional.priority_compute (the training loops and bench.py wrap their steps in it) must not touch CUDA state on a
+    CPU-only host, nor when the switch is off (the default)"""
+    from zs3_amd import functional as Fz
+    assert Fz.PRIORITY_COMPUTE_STREAM is False
+    with Fz.priority_compute() as ctx:
+        assert ctx._ctx is None
+    Fz.PRIORITY_COMPUTE_STREAM = True
+    try:
+        with Fz.priority_compute() as ctx:
+            assert ctx._ctx is None or torch.cuda.is_available()
+    finally:
+        Fz.PRIORITY_COMPUTE_STREAM = False
