@@ -5,7 +5,6 @@ contiguous).  Each Function is one *fused layer* (conv + BatchNorm + residual + 
 training step is ~150 autograd nodes instead of ~700 ATen ops.  Nothing here falls back to torch
 compute: tensors must live on the GPU and libzs3hip.so must be present.
 """
-import os
 import random
 import weakref
 

@@ -6,7 +6,6 @@ map on the device, and what the training loop needs from it.
 features are row gathers.  Returned objects differ from the reference's only in container type: tensors on the device
 instead of numpy arrays / a scipy-built sparse tensor, and the cluster -> pixels dictionary is built lazily
 (`ClusterGraph.pixel_index()`), because the training loop never reads it (:307-330, :399-425)."""
-import ctypes
 
 import torch
 

@@ -6,7 +6,7 @@ import torch.nn as nn
 
 from .. import functional as Fz
 from .. import ops
-from .layers import BatchNorm2d, Conv2d, Dropout, to_channels_last_
+from .layers import Conv2d, Dropout, to_channels_last_
 
 
 def _kaiming_all(module):

@@ -5,7 +5,6 @@ pixel stride (`ld`) may exceed C (channel-slice views of a wider buffer).  Logic
 channels_last strides are the same memory: `nhwc(t)` / `nchw(t)` convert without copying.
 """
 import ctypes
-import os
 from dataclasses import dataclass
 
 import torch

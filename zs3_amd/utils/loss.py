@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from .. import ops
-from .._lib import F, I, P, check, lib, require_gpu, stream
+from .._lib import I, P, check, lib, require_gpu, stream
 
 
 class _CrossEntropy(torch.autograd.Function):
