@@ -127,8 +127,7 @@ def test_supervised_trajectory_matches_reference(golden, torch_threads):
         zo.apply_lr(opt, zo.poly_lr(1e-5, it, 0, 11, 2))
         loss, _ = zo.supervised_step(m, opt, crit, b["image"], b["label"])
         losses.append(loss)
-    assert np.allclose(losses, g["losses"], rtol=1e-4), (losses, g["losses"])
-    assert np.allclose(losses, g["losses"], rtol=2e-2), (losses, g["losses"])
+    assert np.allclose(losses, g["losses"], rtol=1e-5), (losses, g["losses"])    # exact (0.0) in this container
     assert np.allclose([pg["lr"] for pg in opt.param_groups], g["final_lr"], rtol=1e-12)
     assert int(m.state_dict()["backbone.bn1.num_batches_tracked"]) == int(g["nbt"]) == 11
     sd = m.state_dict()
