@@ -68,6 +68,28 @@ def test_eval_logits_and_argmax_vs_golden_and_oracle(dev, golden):
     assert np.allclose(feat.cpu()[:, :8, ::4, ::4].numpy(), g["eval_feat_slice"], rtol=2e-3, atol=2e-4 * float(np.abs(g["eval_feat_slice"]).max()))
 
 
+def test_baseline_config0_forward_and_loss(dev, golden):
+    """BASELINE.json configs[0]: forward + CE loss on one random 3x129x129 tensor against the reference's own output
+    (tests/golden/config0_129.npz): logits within 1e-3 rel (delivered: < 2e-4), argmax identical on all 16641 pixels (the
+    reference's smallest top-2 margin is 1.05), loss within 1e-3; train() mode with B = 1 raises like aspp.py:87."""
+    import zs3_oracle as zo
+    from zs3_amd.utils.loss import SegmentationLosses
+    g = golden("config0_129.npz")
+    m, _ = build_pair(tame=False)
+    m = m.to(dev).eval()
+    b = zo.make_synthetic_batch(1, 129, seed=129, with_label_emb=False)
+    with torch.no_grad():
+        logits = m(b["image"].to(dev))
+        loss = SegmentationLosses(cuda=True).build_loss("ce")(logits, b["label"].to(dev))
+    ref = torch.from_numpy(g["logits"])
+    assert logits.shape == ref.shape
+    assert rel(logits, ref) < 2e-4
+    assert np.array_equal(logits.argmax(1).cpu().numpy(), g["argmax"])
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * float(g["loss"])
+    with pytest.raises(ValueError):
+        m.train()(b["image"].to(dev))
+
+
 def test_train_forward_backward_vs_oracle(dev):
     import zs3_oracle as zo
     from zs3_amd.utils.loss import SegmentationLosses

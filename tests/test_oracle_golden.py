@@ -110,6 +110,25 @@ def test_deeplab_forward_backward_matches_reference(golden, torch_threads):
         assert np.allclose(stats(t), g[key], rtol=2e-4, atol=1e-4), key
 
 
+def test_baseline_config0_forward_and_loss(golden, torch_threads):
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): forward + CE loss on one random 3x129x129 tensor"""
+    g = golden("config0_129.npz")
+    torch.manual_seed(1)
+    m = zo.DeepLab(num_classes=21, pretrained=False).eval()
+    b = zo.make_synthetic_batch(1, 129, seed=129, with_label_emb=False)
+    assert np.allclose(stats(b["image"]), g["in_stats"], rtol=1e-12) and np.allclose(stats(b["label"]), g["label_stats"], rtol=1e-12)
+    with torch.no_grad():
+        logits = m(b["image"])
+        loss = zo.SegmentationLosses().build_loss("ce")(logits, b["label"])
+    ref = torch.from_numpy(g["logits"])
+    assert ((logits - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    assert np.array_equal(logits.argmax(1).numpy(), g["argmax"])
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 * float(g["loss"])
+    assert bool(g["train_b1_raises"])
+    with pytest.raises(ValueError):          # aspp.py:87: the pooled-branch BN sees one value per channel
+        m.train()(b["image"])
+
+
 def test_supervised_trajectory_matches_reference(golden, torch_threads):
     """11 SGD iterations of base_trainer.py:5-25 at 65x65, B=2, dropout active (CPU RNG stream identical)."""
     g = golden("supervised_traj.npz")

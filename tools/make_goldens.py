@@ -158,6 +158,30 @@ def g_forward():
     save("deeplab_forward.npz", **out)
 
 
+# --------------------------------------------------------------------------- G2b: BASELINE configs[0]
+def g_config0():
+    """BASELINE.json configs[0]: DeepLabv3+ ResNet-101, 21 classes, forward + CE loss on ONE random 3x129x129 tensor.
+    (B = 1 raises in train() mode at the pooled-branch BN, aspp.py:87, so the reference's plumbing case is eval mode.)"""
+    torch.manual_seed(1)
+    m = RefDeepLab(num_classes=21, pretrained=False, sync_bn=False)
+    m.eval()
+    batch = zo.make_synthetic_batch(1, 129, seed=129, with_label_emb=False)
+    x, y = batch["image"], batch["label"]
+    with torch.no_grad():
+        logits = m(x)
+        loss = RefSegLoss(cuda=False).build_loss("ce")(logits, y)
+    top2 = logits.topk(2, dim=1).values
+    raised = False
+    m.train()
+    try:
+        m(x)
+    except ValueError:
+        raised = True
+    save("config0_129.npz", in_stats=stats(x), label_stats=stats(y), logits=logits.numpy(), loss=np.float64(loss.item()),
+         argmax=logits.argmax(1).numpy().astype(np.uint8), margin=(top2[:, 0] - top2[:, 1]).numpy(),
+         train_b1_raises=np.array(raised))
+
+
 # --------------------------------------------------------------------------- G3: supervised trajectory
 class _Writer:
     def __init__(self):
@@ -440,7 +464,7 @@ def g_gcn_traj():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["init", "forward", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc", "gcn", "gcn_traj"]
+    which = sys.argv[1:] or ["init", "forward", "config0", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc", "gcn", "gcn_traj"]
     for w in which:
-        {"init": g_init, "forward": g_forward, "supervised": g_supervised, "mmd": g_mmd, "gmmn_mlp": g_gmmn_mlp,
+        {"init": g_init, "forward": g_forward, "config0": g_config0, "supervised": g_supervised, "mmd": g_mmd, "gmmn_mlp": g_gmmn_mlp,
          "gmmn_traj": g_gmmn_traj, "misc": g_misc, "gcn": g_gcn, "gcn_traj": g_gcn_traj}[w]()
