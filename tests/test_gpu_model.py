@@ -220,6 +220,49 @@ def test_supervised_step_vs_oracle(dev):
         assert ((d - dr).norm() / dr.norm()).item() < 3e-2, k
 
 
+def test_context_60_classes_forward_and_step(dev):
+    """BASELINE configs[3]/[4] shape of the head: 60 classes (datasets/context.py:22) with global_avg_pool_bn=False and
+    labels up to 59 + ignore 255: eval logits / argmax and one supervised training step against the oracle"""
+    import zs3_oracle as zo
+    from zs3_amd.optim import SGD
+    from zs3_amd.utils.loss import SegmentationLosses
+    m, ref = build_pair(num_classes=60, tame=True, global_avg_pool_bn=False)
+    assert len(m.state_dict()) == 675
+    g = torch.Generator().manual_seed(60)
+    image = torch.randn(2, 3, 65, 65, generator=g)
+    label = torch.randint(0, 60, (2, 9, 9), generator=g).float().repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :65, :65]
+    label = torch.nn.functional.pad(label, (0, 65 - label.shape[2], 0, 65 - label.shape[1]), value=255.0)
+    label[:, :3] = 255
+    m = m.to(dev).eval()
+    ref.eval()
+    with torch.no_grad():
+        out, out_r = m(image.to(dev)), ref(image)
+    assert out.shape == (2, 60, 65, 65) and rel(out, out_r) < 2e-4
+    top2 = out_r.topk(2, dim=1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 2e-4 * out_r.abs().max()
+    assert torch.equal(out.argmax(1).cpu()[sure], out_r.argmax(1)[sure]) and sure.float().mean() > 0.99
+    m.train()
+    ref = ref.double().train()
+
+    def groups(mod, lr):
+        return [{"params": mod.get_1x_lr_params(), "lr": lr}, {"params": mod.get_10x_lr_params(), "lr": lr * 10}]
+
+    opt = SGD(groups(m, 1e-3), momentum=0.9, weight_decay=5e-4, nesterov=False)
+    opt_r = torch.optim.SGD(groups(ref, 1e-3), momentum=0.9, weight_decay=5e-4, nesterov=False)
+    w = torch.ones(60)
+    w[[5, 17]] = 100.0
+    init = ref.decoder.pred_conv.weight.detach().clone()
+    opt.zero_grad()
+    loss = SegmentationLosses(weight=w.to(dev), cuda=True).build_loss("ce")(m(image.to(dev)), label.to(dev))
+    loss.backward()
+    opt.step()
+    loss_r, _ = zo.supervised_step(ref, opt_r, zo.SegmentationLosses(weight=w.double()).build_loss("ce"), image.double(), label)
+    assert abs(loss.item() - loss_r) < 2e-4 * abs(loss_r), (loss.item(), loss_r)
+    d = m.decoder.pred_conv.weight.detach().double().cpu() - init
+    dr = ref.decoder.pred_conv.weight.detach() - init
+    assert ((d - dr).norm() / dr.norm()).item() < 3e-2
+
+
 def test_gmmn_step_vs_oracle(dev):
     """train_pascal_GMMN.py:139-268 with the reference's CPU noise stream: per-step G/C losses and the updated
     generator / pred_conv agree with the oracle; the backbone is untouched; BN running stats moved."""
