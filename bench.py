@@ -28,6 +28,8 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_GFLOP_PER_IMG = {21: 185.64, 60: 185.97}          # BASELINE.md section 3 (2*MAC, convs only)
 TRAIN_GFLOP_PER_IMG = {21: 555.7, 60: 556.7}          # fwd + dgrad + wgrad, no dgrad for the stem
+DTYPE_NOTE = {"bf16x3": "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate; fp32 storage)",
+              "bf16": "bf16 (plain bf16 MFMA products, fp32 accumulate; fp32 master weights and BN statistics)"}
 PEAK_BF16_TF = 2500.0                                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -40,7 +42,10 @@ def parse():
     ap.add_argument("--size", type=int, default=513)
     ap.add_argument("--classes", type=int, default=21)
     ap.add_argument("--workload", choices=["supervised", "gmmn", "gcn_context"], default="supervised")
-    ap.add_argument("--gmmn-steps", type=int, default=2)
+    ap.add_argument("--gmmn-steps", type=int, default=10, help="timed GMMN steps (configs[2]) after the supervised loop; 0 = skip")
+    ap.add_argument("--dtype", choices=["bf16x3", "bf16"], default="bf16x3",
+                    help="conv arithmetic: bf16x3 = fp32 semantics as three bf16 MFMA products (configs[1-3]); "
+                         "bf16 = plain bf16 products, fp32 accumulate (configs[4])")
     ap.add_argument("--sync-bn", type=int, default=0)
     ap.add_argument("--ddp-selftest", action="store_true",
                     help="1-GPU run with a one-rank RCCL group and the full gradient-sync plumbing (cost of the N>1 code path)")
@@ -52,8 +57,25 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -68,7 +90,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     from zs3_amd import functional as Fz
     from zs3_amd import ops
@@ -84,6 +107,7 @@ def main():
     if args.priority_stream:
         Fz.PRIORITY_COMPUTE_STREAM = True
         args.no_roofline = True
+    ops.PREC_DEFAULT = 1 if args.dtype == "bf16" else 3
     unseen = [10, 14]
     seen = [c for c in range(args.classes) if c not in unseen]
     torch.manual_seed(1)
@@ -159,7 +183,34 @@ def main():
         else:
             stepper = GMMNStep(model, gen, opt, opt_g, crit_g, seen=seen, unseen=unseen, noise="device",
                                group=True if dp else None)
-        return lambda i: stepper(gb["image"], gb["label"], gb["label_emb"])
+        fn = lambda i: stepper(gb["image"], gb["label"], gb["label_emb"])
+        fn.stepper, fn.image = stepper, gb["image"]
+        return fn
+
+    def gmmn_report(gstep, steps):
+        """configs[2]: the GMMN step as a first-class line -- images/s over `steps` timed steps plus where the time goes:
+        the frozen-backbone feature pass (timed alone with HIP events) and the per-(image, class) generator updates."""
+        gdt, _ = run(gstep, steps, 2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.no_grad():
+            model.forward_before_class_prediction(gstep.image)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                model.forward_before_class_prediction(gstep.image)
+            e1.record()
+        torch.cuda.synchronize()
+        fwd_ms = e0.elapsed_time(e1) / 3
+        step_ms = 1e3 * gdt / steps
+        upd = int(getattr(gstep.stepper, "last_updates", 0))
+        return {"value": args.batch * steps / gdt, "unit": "images/sec", "ms_per_step": step_ms, "steps": steps,
+                "workload": "train_pascal_GMMN.py step (BASELINE configs[2]): frozen DeepLabv3+ feature pass + per-(image, class) "
+                            "GMMN/MMD/Adam updates + pred_conv CE/SGD, device noise",
+                "breakdown": {"backbone_forward_ms": fwd_ms, "generator_updates_per_step": upd,
+                              "generator_loop_and_classifier_ms": step_ms - fwd_ms,
+                              "us_per_generator_update": (1e3 * (step_ms - fwd_ms) / upd) if upd else None},
+                "model_tflops": args.batch * steps / gdt * 193.5 / 1e3,
+                "model_frac_of_bf16_peak": args.batch * steps / gdt * 193.5 / 1e3 / PEAK_BF16_TF}
 
     if args.workload == "supervised":
         if not args.no_roofline:
@@ -193,10 +244,7 @@ def main():
             prof, warm_prof = [], []
         gflop_img = TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7)
         if args.gmmn_steps > 0 and world == 1:
-            gstep = build_gmmn()
-            gdt, _ = run(gstep, args.gmmn_steps, 1)
-            gmmn_info = {"value": args.batch * args.gmmn_steps / gdt, "unit": "images/sec", "ms_per_step": 1e3 * gdt / args.gmmn_steps,
-                         "steps": args.gmmn_steps, "workload": "train_pascal_GMMN.py step (configs[2]), device noise"}
+            gmmn_info = gmmn_report(build_gmmn(), args.gmmn_steps)
     else:
         gstep = build_gmmn()
         prof, warm_prof = [], []
@@ -205,11 +253,11 @@ def main():
 
     value = world * args.batch * args.steps / dt
     result = {
-        "metric": "train images/sec, DeepLabv3+ (ResNet-101 dilated, ASPP, decoder) 513x513",
+        "metric": "train images/sec, DeepLabv3+ + GMMN 513x513",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate; fp32 storage)", "data": "synthetic",
-        "config": {"workload": ("train_pascal.py supervised step: DeepLabv3+ ResNet-101 fwd+CE+bwd+SGD (BASELINE configs[1])"
+        "dtype": DTYPE_NOTE[args.dtype], "data": "synthetic",
+        "config": {"workload": ("train_pascal.py supervised step: DeepLabv3+ ResNet-101 fwd+CE+bwd+SGD (BASELINE configs[1]); the +GMMN step (configs[2]) is the `gmmn` object of this line"
                                 if args.workload == "supervised" else
                                 "train_pascal_GMMN.py step (BASELINE configs[2])" if args.workload == "gmmn" else
                                 "train_context_GMMN_GCNcontext.py step (GCN-context flow of BASELINE configs[4], fp32 arithmetic as above)"),
@@ -218,6 +266,8 @@ def main():
         "model_tflops": value * gflop_img / 1e3,
         "model_frac_of_bf16_peak": value * gflop_img / 1e3 / (PEAK_BF16_TF * world),
     }
+    if sync is not None:
+        result["rccl_bytes_per_rank_per_step"] = sync.bytes_reduced // max(1, args.steps + args.warmup)
     if gmmn_info:
         result["gmmn"] = gmmn_info
     if rank == 0 and prof:
@@ -240,8 +290,8 @@ def main():
             "traffic": traffic, "traffic_source": traffic_src, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
             "instrumented_timed_steps": instrumented,
             "note": "achieved = algorithmic 2*M*N*K flops of the launches / HIP-event time (events around every launch of this "
-                    "kernel in every 5th timed step); each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation is "
-                    "3x this fraction",
+                    "kernel in every 5th timed step)" + ("; each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation "
+                    "is 3x this fraction" if args.dtype == "bf16x3" else "; one bf16 MFMA per product"),
             "all_conv_igemm_last_warmup_step": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms": 1e3 * v[2]}
                                                 for k, v in warm.items()},
         }
@@ -277,8 +327,7 @@ def cpu_baseline(args):
     import zs3_oracle as zo
 
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
+    torch.set_num_threads(cores)
     torch.manual_seed(1)
     m = zo.DeepLab(num_classes=args.classes, pretrained=False).train()
     groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
@@ -288,14 +337,14 @@ def cpu_baseline(args):
     b = zo.make_synthetic_batch(bsz, args.size, args.classes, seed=1, with_label_emb=False)
     zo.supervised_step(m, opt, crit, b["image"], b["label"])  # warm-up (oneDNN primitive creation)
     times = []
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         zo.supervised_step(m, opt, crit, b["image"], b["label"])
         times.append(time.perf_counter() - t0)
     t = sorted(times)[len(times) // 2]
-    return {"value": bsz / t, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle supervised step (fwd+CE+bwd+SGD), B={bsz} at {args.size}x{args.size}, 1 warm-up + 2 timed steps, "
-                      f"median; torch CPU fp32 with {threads} threads on a {cores}-core host"}
+    return {"value": bsz / t, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle supervised step (fwd+CE+bwd+SGD), B={bsz} at {args.size}x{args.size}, 1 warm-up + 3 timed steps, "
+                      f"median; torch CPU fp32 with torch.set_num_threads({cores}) = every core of the host"}
 
 
 if __name__ == "__main__":

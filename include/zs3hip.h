@@ -166,9 +166,11 @@ int zs3_uniform(float* out, long n, unsigned long long seed, const void* seed_de
 /* counter[0] += v (device int64 / uint64): advances the stream position / step count between graph replays */
 int zs3_counter_add(void* counter, long v, void* stream);
 /* ---- fused pieces of the GMMN generator update (train_pascal_GMMN.py:205-236, replayed per image and class) ---- */
-/* zs3_uniform + zs3_gather_cat in one launch: out[r] = [a[idx[r]][0:Ca] | U[0,1)^Cb | 0...] */
+/* zs3_uniform + zs3_gather_cat in one launch: out[r] = [a[idx[r]][0:Ca] | U[0,1)^Cb | 0...].  The noise of row r is keyed
+   on noise_key[r] (r itself when NULL): with noise_key = the sampled within-class pixel index, duplicate samples share
+   their noise row exactly like z[random_idx] of train_pascal_GMMN.py:216,229-236 */
 int zs3_gather_cat_noise(const float* a, int lda, const long* idx, int Ca, int Cb, float* out, int ldo, long n,
-                         unsigned long long seed, const void* seed_dev, void* stream);
+                         unsigned long long seed, const void* seed_dev, const long* noise_key, void* stream);
 /* out = dropout_backward(dy; p, seed, row_idx) * leaky_relu'(h; leak): Dropout + LeakyReLU backward of gmmn.py:19-22 */
 int zs3_dropout_act_bwd(const float* dy, int ldd, const float* h, int ldh, float* out, int ldo, long M, int C, float p,
                         unsigned long long seed, const long* row_idx, const void* seed_dev, float leak, void* stream);

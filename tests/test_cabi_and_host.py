@@ -212,3 +212,30 @@ def test_priority_compute_is_a_noop_without_a_gpu_and_when_disabled():
             assert ctx._ctx is None or torch.cuda.is_available()
     finally:
         Fz.PRIORITY_COMPUTE_STREAM = False
+
+
+def test_evaluator_seen_unseen_matches_the_reference(golden):
+    """zs3/utils/metrics.py:88-196 (imported by eval_pascal.py:14): overall / seen / unseen / per-class score tuples on the
+    fixture's four label maps equal the reference's, NaN pattern included (classes absent from the ground truth)."""
+    import warnings
+    from zs3_amd.utils.metrics import Evaluator_seen_unseen
+    g = golden("seen_unseen.npz")
+    gt, pred = list(g["gt"].astype(np.int64)), list(g["pred"].astype(np.int64))
+
+    def flat(x, out):
+        if isinstance(x, (tuple, list)):
+            for y in x:
+                flat(y, out)
+        else:
+            out.append(float(x))
+        return np.array(out)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        split = flat(Evaluator_seen_unseen(21, [10, 14]).label_accuracy_score(gt, pred, by_class=True), [])
+        plain = flat(Evaluator_seen_unseen(21, None).label_accuracy_score(gt, pred), [])
+    assert split.shape == g["split"].shape and np.array_equal(np.isnan(split), np.isnan(g["split"]))
+    assert np.allclose(split, g["split"], rtol=1e-12, atol=0, equal_nan=True)
+    assert np.allclose(plain, g["plain"], rtol=1e-12, atol=0)
+    ev = Evaluator_seen_unseen(21, [10, 14])
+    h = ev._fast_hist(gt[0].ravel(), pred[0].ravel(), 21, target="unseen", unseen=[10, 14])
+    assert h.sum() == np.isin(gt[0], [10, 14]).sum() and h[[c for c in range(21) if c not in (10, 14)]].sum() == 0

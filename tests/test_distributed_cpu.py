@@ -17,6 +17,73 @@ def _free_port():
     return p
 
 
+def _zero_copy_and_global_ce(rank, world):
+    """(1) a layer that writes its weight gradient straight into the GradSync bucket slice (what the fused HIP layers do
+    through functional.grad_buffer): autograd adopts the slice as .grad and the all-reduce runs in place, no pack / unpack;
+    (2) the product's global CE normalisation (utils.loss.global_ce_normalise) + GradSync's SUM on two DIFFERENT shards
+    equals the single-process gradient of the CE over the concatenated batch (loss.py:31-46 on the gathered batch)."""
+    import torch.nn.functional as F
+    from zs3_amd import functional as Fz
+    from zs3_amd.parallel import GradSync
+    from zs3_amd.utils.loss import global_ce_normalise
+
+    class BucketLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            buf = Fz.grad_buffer(w)
+            dw = buf.view(w.shape) if buf is not None else torch.empty_like(w)
+            torch.mm(dy.t(), x, out=dw)
+            return dy @ w, dw
+
+    torch.manual_seed(3)
+    classes, feat = 5, 6
+    w1 = torch.nn.Parameter(torch.randn(7, feat) * 0.3)
+    w2 = torch.nn.Parameter(torch.randn(classes, 7) * 0.3)
+    bias = torch.nn.Parameter(torch.zeros(classes))
+    cw = torch.tensor([1.0, 2.0, 0.5, 100.0, 1.0])
+    sync = GradSync([w1, w2, bias], bucket_mb=0.0001)
+    torch.manual_seed(40)
+    xs = [torch.randn(3, 4, 4, feat) for _ in range(world)]          # [B, H, W, feat] per rank, different per rank
+    ts = [torch.randint(0, classes, (3, 4, 4)) for _ in range(world)]
+    ts[0][0, 0, :] = 255
+    ts[1][2, 1:, :] = 255
+
+    def logits(x, a, b, c, fn):
+        return fn(torch.relu(fn(x.reshape(-1, feat), a)), b) + c
+
+    for it in range(2):
+        for p in (w1, w2, bias):
+            p.grad = None
+        z = logits(xs[rank], w1, w2, bias, BucketLinear.apply)
+        t = ts[rank].reshape(-1)
+        keep = t != 255
+        nll = F.cross_entropy(z[keep], t[keep], reduction="none")
+        wt = cw[t[keep]]
+        s_local = (wt * nll).sum()
+        ws = torch.tensor([0.0, float(wt.sum()), float(s_local)])
+        loss_glob, batch_glob = global_ce_normalise(ws, xs[rank].shape[0], True)
+        assert batch_glob == 3 * world
+        (s_local / ws[1] / batch_glob).backward()      # this rank's share of the global loss
+        assert sync._in_place(w1) and sync._in_place(w2) and not sync._in_place(bias)
+        # single process, concatenated batch: CE = sum(w*nll)/sum(w) over valid pixels, then / B
+        ref = [p.detach().clone().requires_grad_(True) for p in (w1, w2, bias)]
+        zc = logits(torch.cat(xs), *ref, lambda a_, b_: a_ @ b_.t())
+        tc = torch.cat(ts).reshape(-1)
+        lc = F.cross_entropy(zc, tc, weight=cw, ignore_index=255, reduction="mean") / (3 * world)
+        gs = torch.autograd.grad(lc, ref)
+        assert abs(float(loss_glob) - float(lc)) < 1e-6 * abs(float(lc))
+        for p, g_ in zip((w1, w2, bias), gs):
+            assert torch.allclose(p.grad, g_, rtol=1e-5, atol=1e-7), (p.shape, (p.grad - g_).abs().max())
+    sync.remove()
+    assert Fz.grad_buffer(w1) is None
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -55,6 +122,8 @@ def _worker(rank, world, port, q):
                 assert torch.allclose(g_, w_, rtol=1e-5, atol=1e-6)
             assert net[0].weight.grad.is_contiguous(memory_format=torch.channels_last)
         assert sync.bytes_reduced > 0
+        sync.remove()
+        _zero_copy_and_global_ce(rank, world)
         # SyncBN statistics: global sums / count from per-rank chunk partials
         part = torch.arange(2 * 2 * 4, dtype=torch.float32).reshape(2, 2, 4) * (rank + 1)
         tot, cnt = combine_bn_partials(part, 10 * (rank + 1))

@@ -66,6 +66,9 @@ def _step(dev, ddp):
     torch.cuda.synchronize()
     if sync is not None:
         assert sync.bytes_reduced == 2 * 4 * sum(p.numel() for p in m.parameters())
+        # zero-copy buckets: the conv weights' .grad ARE their bucket slices (written there by the wgrad kernels)
+        convs = [p for p in m.parameters() if p.dim() == 4 and p.grad is not None and p is not m.backbone.conv1.weight]
+        assert sum(sync._in_place(p) for p in convs) == len(convs) > 100
         sync.remove()
     par.FORCE_COLLECTIVES = False
     return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}

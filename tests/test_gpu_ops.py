@@ -408,3 +408,64 @@ def test_gcn_generator_forward_backward(dev):
     for got, want in ((net.gcn1.weight.grad, w1.grad), (net.gcn1.bias.grad, b1.grad), (net.gcn2.weight.grad, w2.grad),
                       (net.gcn2.bias.grad, b2.grad)):
         assert rel(got, want) < 1e-4
+
+
+def test_sgd_resumes_from_a_torch_optim_state_dict(dev):
+    """a checkpoint written by the reference holds torch.optim.SGD momentum buffers in NCHW-contiguous order,
+    the fused kernel walks parameter / gradient / buffer by raw pointer in the parameter's channels_last order: the buffer
+    is re-laid once after load_state_dict.  3x3 and 1x1 conv weights + a bias, two steps before and two after the resume."""
+    from zs3_amd.optim import SGD
+    g = torch.Generator().manual_seed(3)
+    shapes = [(8, 6, 3, 3), (16, 8, 1, 1), (5,), (4, 3, 7, 7)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(4)]
+
+    def ref_params():
+        return [torch.nn.Parameter(t.clone()) for t in init]
+
+    # reference run: four plain torch.optim.SGD steps on NCHW-contiguous CPU tensors
+    pr = ref_params()
+    opt_r = torch.optim.SGD([{"params": pr[:2], "lr": 0.1}, {"params": pr[2:], "lr": 0.3}], momentum=0.9, weight_decay=5e-4)
+    state_after_two = None
+    for it in range(4):
+        for p, gr in zip(pr, grads[it]):
+            p.grad = gr.clone()
+        opt_r.step()
+        if it == 1:
+            import copy
+            state_after_two = copy.deepcopy(opt_r.state_dict())
+            params_after_two = [p.detach().clone() for p in pr]
+    # product: channels_last parameters on the GPU, resumed from the torch state dict
+    pp = []
+    for t in params_after_two:
+        t = t.to(dev)
+        pp.append(torch.nn.Parameter(t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t))
+    opt = SGD([{"params": pp[:2], "lr": 0.1}, {"params": pp[2:], "lr": 0.3}], momentum=0.9, weight_decay=5e-4)
+    opt.load_state_dict(state_after_two)
+    assert opt.state[pp[0]]["momentum_buffer"].is_contiguous()          # NCHW strides survive load_state_dict
+    for it in (2, 3):
+        for p, gr in zip(pp, grads[it]):
+            g_ = gr.to(dev)
+            p.grad = g_.contiguous(memory_format=torch.channels_last) if g_.dim() == 4 else g_
+        opt.step()
+    for p, r in zip(pp, pr):
+        assert rel(p, r) < 1e-6, p.shape
+    buf = opt.state[pp[0]]["momentum_buffer"]
+    assert buf.stride() == pp[0].stride() and rel(buf, opt_r.state[pr[0]]["momentum_buffer"]) < 1e-6
+
+
+def test_sampled_noise_is_keyed_on_the_sampled_pixel(dev):
+    """train_pascal_GMMN.py:216,229-236: z is drawn per class pixel and indexed with random_idx, so a pixel sampled twice
+    brings the same noise row.  zs3_gather_cat_noise keys row r's noise on noise_key[r]."""
+    from zs3_amd import ops
+    a = torch.randn(50, 300, device=dev)
+    idx = torch.tensor([3, 7, 3, 9, 7, 3], device=dev)
+    key = torch.tensor([1, 4, 1, 5, 4, 1], device=dev)      # within-class indices of the sampled pixels
+    out = ops.gather_cat_noise(a, idx, 300, 300, 600, 6, 1234, noise_key=key)
+    assert torch.equal(out[:, :300], a[idx])
+    z = out[:, 300:]
+    assert torch.equal(z[0], z[2]) and torch.equal(z[0], z[5]) and torch.equal(z[1], z[4])
+    assert not torch.equal(z[0], z[1]) and not torch.equal(z[3], z[1])
+    assert 0.0 <= z.min().item() and z.max().item() < 1.0 and abs(z.mean().item() - 0.5) < 0.05
+    plain = ops.gather_cat_noise(a, idx, 300, 300, 600, 6, 1234)
+    assert not torch.equal(plain[0, 300:], plain[2, 300:])   # without a key: per-row noise

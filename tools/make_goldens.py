@@ -352,6 +352,32 @@ def g_misc():
          nearest_65_17=near65.numpy().astype(np.int64))
 
 
+def g_seen_unseen():
+    """Evaluator_seen_unseen.label_accuracy_score (metrics.py:88-196; eval_pascal.py:83) on four seeded label / prediction
+    maps with an ignore band and one class missing from an image: overall / seen / unseen tuples and the per-class list."""
+    import warnings
+    from zs3.utils.metrics import Evaluator_seen_unseen as RefESU
+    rng = np.random.RandomState(5)
+    gt = rng.randint(0, 21, size=(4, 33, 33))
+    gt[:, :3] = 255
+    gt[1][gt[1] == 5] = 7
+    pred = np.where(rng.rand(4, 33, 33) < 0.6, np.minimum(gt, 20), rng.randint(0, 21, size=(4, 33, 33)))
+
+    def flat(x, out):
+        if isinstance(x, (tuple, list)):
+            for y in x:
+                flat(y, out)
+        else:
+            out.append(float(x))
+        return out
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        split = RefESU(21, [10, 14]).label_accuracy_score(list(gt), list(pred), by_class=True)
+        plain = RefESU(21, None).label_accuracy_score(list(gt), list(pred))
+    save("seen_unseen.npz", gt=gt.astype(np.uint8), pred=pred.astype(np.uint8), split=np.array(flat(split, [])),
+         plain=np.array(flat(plain, [])))
+
+
 # --------------------------------------------------------------------------- G8: GCN-context cluster graph (8f N3)
 def _segmaps():
     """label maps with blobs, thin diagonal structures (8-connectivity matters), single-pixel clusters, one-label maps"""
@@ -464,7 +490,7 @@ def g_gcn_traj():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["init", "forward", "config0", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc", "gcn", "gcn_traj"]
+    which = sys.argv[1:] or ["init", "forward", "config0", "supervised", "mmd", "gmmn_mlp", "gmmn_traj", "misc", "seen_unseen", "gcn", "gcn_traj"]
     for w in which:
-        {"init": g_init, "forward": g_forward, "config0": g_config0, "supervised": g_supervised, "mmd": g_mmd, "gmmn_mlp": g_gmmn_mlp,
+        {"seen_unseen": g_seen_unseen, "init": g_init, "forward": g_forward, "config0": g_config0, "supervised": g_supervised, "mmd": g_mmd, "gmmn_mlp": g_gmmn_mlp,
          "gmmn_traj": g_gmmn_traj, "misc": g_misc, "gcn": g_gcn, "gcn_traj": g_gcn_traj}[w]()

@@ -15,6 +15,7 @@ SHAPES = [(23, 33, 256, 1024, 1, 1, 1), (22, 33, 1024, 256, 1, 1, 1), (22, 33, 2
           (1, 33, 1280, 256, 1, 1, 1), (1, 129, 256, 48, 1, 1, 1), (1, 129, 304, 256, 3, 1, 1), (1, 129, 256, 256, 3, 1, 1)]
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]
 mode = sys.argv[2] if len(sys.argv) > 2 else "fwd"
+ops.PREC_DEFAULT = int(os.environ.get("ZS3_PREC", "3"))   # 1 = plain bf16 products
 B = 16
 def timeit(fn, iters=5):
     for _ in range(2): fn()

@@ -152,7 +152,8 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
 // out[r][0:Ca] = a[idx[r]][0:Ca]; out[r][Ca:Ca+Cb] = U[0,1) noise with the stream of uniform_kernel on a [n][Cb]
 // tensor (element r*Cb + c); out[r][Ca+Cb:ldo] = 0
 __global__ void gather_cat_noise_kernel(const float* a, int lda, const long* idx, int Ca, int Cb, float* out, int ldo,
-                                        long n, unsigned long long seed, const unsigned long long* seed_dev) {
+                                        long n, unsigned long long seed, const unsigned long long* seed_dev,
+                                        const long* noise_key) {
   if (seed_dev) seed += seed_dev[0];
   const long total = n * ldo;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -160,7 +161,7 @@ __global__ void gather_cat_noise_kernel(const float* a, int lda, const long* idx
     const int c = (int)(i - r * ldo);
     float v = 0.f;
     if (c < Ca) v = a[(idx ? idx[r] : r) * lda + c];
-    else if (c < Ca + Cb) v = u01(seed, (unsigned long long)(r * Cb + (c - Ca)));
+    else if (c < Ca + Cb) v = u01(seed, (unsigned long long)((noise_key ? noise_key[r] : r) * Cb + (c - Ca)));
     out[i] = v;
   }
 }
@@ -356,10 +357,10 @@ extern "C" int zs3_counter_add(void* counter, long v, void* stream) {
 }
 
 extern "C" int zs3_gather_cat_noise(const float* a, int lda, const long* idx, int Ca, int Cb, float* out, int ldo, long n,
-                                    unsigned long long seed, const void* seed_dev, void* stream) {
+                                    unsigned long long seed, const void* seed_dev, const long* noise_key, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(gather_cat_noise_kernel, dim3(ew_blocks(n * ldo)), dim3(256), 0, (hipStream_t)stream, a, lda, idx, Ca,
-                     Cb, out, ldo, n, seed, (const unsigned long long*)seed_dev);
+                     Cb, out, ldo, n, seed, (const unsigned long long*)seed_dev, noise_key);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -106,6 +106,27 @@ def invalidate_planes(*params):
         _planes.pop(id(w), None)
 
 
+# ---------------------------------------------------------------------------------- gradient buckets (parallel.GradSync)
+_grad_buffers = {}
+
+
+def register_grad_buffer(param, flat_view):
+    """flat_view: 1-D fp32 view (param.numel() elements) of a GradSync bucket, or None to forget the parameter."""
+    if flat_view is None:
+        _grad_buffers.pop(id(param), None)
+    else:
+        _grad_buffers[id(param)] = (weakref.ref(param), flat_view)
+
+
+def grad_buffer(param):
+    """The bucket slice a fresh gradient of `param` should be written into, or None: only when the parameter has no .grad
+    yet (otherwise autograd accumulates into the existing one and the slice may already hold it)."""
+    ent = _grad_buffers.get(id(param))
+    if ent is None or ent[0]() is not param or not param.is_leaf or param.grad is not None:
+        return None
+    return ent[1]
+
+
 _refresh_tables = {}
 
 
@@ -396,7 +417,8 @@ class _ConvBnAct(torch.autograd.Function):
                 dy.record_stream(side)          # keep their memory from being recycled while the side stream reads it
                 x.record_stream(side)
                 with torch.cuda.stream(side):
-                    dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec)
+                    dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec,
+                                          out=_bucket_out(weight, wp))
                 dw.record_stream(main)
                 if not (weight.is_leaf and weight.grad is None):
                     # the gradient is READ inside this backward pass -- accumulated into an existing .grad (a second
@@ -407,7 +429,8 @@ class _ConvBnAct(torch.autograd.Function):
                     _join_armed[0] = True
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
             elif geom is None:
-                dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec)
+                dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec,
+                                      out=_bucket_out(weight, wp))
             if geom is None:
                 dw = dw.permute(0, 3, 1, 2)  # logical OIHW, channels_last memory like the parameter
                 if weight.dim() == 2:
@@ -415,6 +438,17 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 dw = cfg["wgrad"](dy, x)
         return dx, dw, dgamma, dbeta, dbias, dres, None
+
+
+def _bucket_out(weight, wp):
+    """wgrad output buffer inside the data-parallel gradient bucket (zero-copy all-reduce), when one is registered"""
+    buf = grad_buffer(weight)
+    if buf is None or buf.numel() != wp.cout * wp.kh * wp.kw * wp.cin:
+        return None
+    w4 = weight if weight.dim() == 4 else weight[:, :, None, None]
+    if not w4.permute(0, 2, 3, 1).is_contiguous():   # the slice is laid out like the parameter's own storage
+        return None
+    return buf.view(wp.cout, wp.kh, wp.kw, wp.cin)
 
 
 def _act_grad(a, act, leak):

@@ -11,8 +11,10 @@ divides by len(unique labels) including 255.
 What is MI355X-native here:
 * class masks come from one stable device sort per batch instead of boolean indexing (no per-class host sync);
 * for images whose generated features are discarded anyway (no unseen pixel => real features are used) the
-  generator only runs on the *sampled* rows -- rows of an MLP are independent, so the Adam update is the one
-  the reference computes -- which makes the whole per-(image, class) update fixed-shape;
+  generator only runs on the *sampled* rows -- rows of an MLP are independent and the noise / dropout of a sampled
+  row are keyed on the class pixel it was drawn from (duplicate samples share them, like z[random_idx] of the
+  reference), so the Adam update is the one the reference computes -- which makes the whole per-(image, class)
+  update fixed-shape;
 * that fixed-shape update (gather + cat, two MFMA row-GEMMs, MMD fwd/bwd, MLP backward, fused Adam, weight
   re-split) is captured ONCE into a hipGraph and replayed per (image, class): ~30 launches become one replay;
   dropout / noise seeds and the Adam step count live in device memory so that replays differ;
@@ -153,7 +155,7 @@ class GMMNStep:
         width = self.embed_dim + self.noise_dim
         if self.noise != "cpu" and not self.context_aware:   # noise drawn inside the gather (same stream as zs3_uniform on a [S, noise_dim] tensor)
             x = ops.gather_cat_noise(st["emb"], st["pix_local"], self.embed_dim, self.noise_dim, width, s, st["seed_base"],
-                                     seed_dev=st["seed_dev"])
+                                     seed_dev=st["seed_dev"], noise_key=st["ridx"])   # z[random_idx]: duplicates share noise
         else:
             x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, width)
         h = _rows_gemm(x, st["wp1"], lin1.bias, Fz.ACT_LEAKY, lrelu.negative_slope)
@@ -317,6 +319,11 @@ class GMMNStep:
         mmd_slots, slot = [], 0
         ring_slots, n_ring = [], 0
         st["slot_dev"].zero_()
+        # pinned staging ring of the sample indices: one row per update of THIS step (the host syncs once, at the end of the
+        # step, so a row must not be reused before that); every copy of the previous step completed at its read-back
+        if n_mmd > st["ring"].shape[0]:
+            st["ring"] = torch.zeros((n_mmd, self.bsg), dtype=torch.int64).pin_memory()
+        st["ring_pos"] = 0
         for i in range(b):
             classes = [c for c in range(256) if hist_h[i][c] > 0]
             has_unseen = any(c in self.unseen for c in classes)
@@ -349,7 +356,7 @@ class GMMNStep:
                 z_cpu = torch.rand((n_c, self.noise_dim)) if (self.noise == "cpu" and ctx is None) else None
                 ridx_cpu = torch.randint(low=0, high=n_c, size=(self.bsg,)) if do_mmd else None
                 if sampled_only:
-                    ring = st["ring"][st["ring_pos"] % 512]
+                    ring = st["ring"][st["ring_pos"]]
                     st["ring_pos"] += 1
                     ring.copy_(ridx_cpu)
                     st["ridx"].copy_(ring, non_blocking=True)
@@ -414,6 +421,7 @@ class GMMNStep:
             mmd_losses.index_copy_(0, dst, st["loss_ring"][:n_ring])
         vals = torch.cat((mmd_losses, closs.detach().reshape(1))).cpu()   # the single read-back of the step
         g_batch = sum(float(vals[sl]) / nuniq for sl, nuniq in mmd_slots)
+        self.last_updates = len(mmd_slots)
         return g_batch, float(vals[-1]), out
 
 

@@ -381,11 +381,12 @@ def counter_add2(c0, v0, c1, v1):
     check(lib().zs3_counter_add2(P(c0), ctypes.c_long(v0), P(c1), ctypes.c_long(v1), stream()), "zs3_counter_add2")
 
 
-def gather_cat_noise(a, idx, ca, cb, ldo, n, seed, seed_dev=None):
-    """[a[idx] | U[0,1)^cb | 0] rows: zs3_gather_cat on a zs3_uniform tensor without materialising the noise."""
+def gather_cat_noise(a, idx, ca, cb, ldo, n, seed, seed_dev=None, noise_key=None):
+    """[a[idx] | U[0,1)^cb | 0] rows: zs3_gather_cat on a zs3_uniform tensor without materialising the noise.  noise_key:
+    optional int64 [n] -- the noise of row r is the noise of "pixel" noise_key[r] (duplicate samples share it)."""
     out = torch.empty((n, ldo), dtype=torch.float32, device=a.device)
     check(lib().zs3_gather_cat_noise(P(a), I(a.stride(0)), P(idx), I(ca), I(cb), P(out), I(ldo), ctypes.c_long(n),
-                                     ctypes.c_ulonglong(seed), P(seed_dev), stream()), "zs3_gather_cat_noise")
+                                     ctypes.c_ulonglong(seed), P(seed_dev), P(noise_key), stream()), "zs3_gather_cat_noise")
     return out
 
 

@@ -47,6 +47,11 @@ class SGD(torch.optim.SGD):
                     state["momentum_buffer"] = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
                     first = 1
                 buf = state.get("momentum_buffer") if mom != 0 else None
+                if buf is not None and not _same_layout(buf, p):
+                    # a buffer restored by load_state_dict keeps the strides it was saved with (torch.optim.SGD on the
+                    # reference: NCHW-contiguous); the kernel walks p, grad and buffer by raw pointer, so re-lay it once
+                    buf = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(buf)
+                    state["momentum_buffer"] = buf
                 rec = by_cfg.setdefault((p.device, float(mom), bool(nest)), [])
                 rec.append((p.data_ptr(), g.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel(), packed, first))
                 touched.append(p)

@@ -43,6 +43,13 @@ class GradSync:
             for p in bucket:
                 self.where[p] = (bi, off)
                 off += p.numel()
+        # zero-copy hand-off: the fused layers write a weight gradient straight into its slice of the flat bucket
+        # (functional.grad_buffer) and autograd adopts that slice as .grad, so the all-reduce works on the gradients in
+        # place -- no pack before and no unpack after the collective for the conv / linear weights (99.9 % of the bytes)
+        from . import functional as Fz
+        for p in self.params:
+            bi, off = self.where[p]
+            Fz.register_grad_buffer(p, self.flat[bi][off:off + p.numel()])
         self._pending = [len(b) for b in self.buckets]
         self._ready = [set() for _ in self.buckets]
         self._works = [None] * len(self.buckets)
@@ -80,12 +87,18 @@ class GradSync:
             with ctx:
                 self._launch(bi)
 
+    def _in_place(self, p):
+        """p.grad already IS its slice of the flat bucket (written there by the layer's wgrad kernel)"""
+        bi, off = self.where[p]
+        return p.grad is not None and p.grad.data_ptr() == self.flat[bi].data_ptr() + 4 * off and \
+            p.grad.untyped_storage().data_ptr() == self.flat[bi].untyped_storage().data_ptr()
+
     def _views(self, bi, params):
         return [self.flat[bi][self.where[p][1]:self.where[p][1] + p.numel()] for p in params]
 
     def _launch(self, bi):
         """pack the bucket's gradients (one multi-tensor copy instead of one kernel per parameter) and start its all-reduce"""
-        have = [p for p in self.buckets[bi] if p in self._ready[bi] and p.grad is not None]
+        have = [p for p in self.buckets[bi] if p in self._ready[bi] and p.grad is not None and not self._in_place(p)]
         if have:
             torch._foreach_copy_(self._views(bi, have), [_as_flat(p.grad, p) for p in have])
         self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -116,14 +129,19 @@ class GradSync:
             for p in bucket:
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
-            torch._foreach_copy_([_as_flat(p.grad, p) for p in bucket], self._views(bi, bucket))
+            back = [p for p in bucket if not self._in_place(p)]
+            if back:
+                torch._foreach_copy_([_as_flat(p.grad, p) for p in back], self._views(bi, back))
             self._works[bi] = None
             self._ready[bi] = set()
         self._armed = False
 
     def remove(self):
+        from . import functional as Fz
         for h in self._handles:
             h.remove()
+        for p in self.params:
+            Fz.register_grad_buffer(p, None)
 
 
 class _null:
@@ -154,6 +172,9 @@ def broadcast_parameters(module, src=0, group=None):
             flat = _as_flat(t.data, t).clone()
             dist.broadcast(flat, src, group=group)
             _as_flat(t.data, t).copy_(flat)
+    # writes through .data do not bump the autograd version counter the bf16 weight-plane cache is keyed on
+    from . import functional as Fz
+    Fz.invalidate_planes(*module.parameters())
 
 
 def all_reduce_tensors(tensors, group=None, average=False, force=False):

@@ -27,14 +27,7 @@ class _CrossEntropy(torch.autograd.Function):
                                I(c), I(ignore_index), I(batch), P(part), P(loss_ws), stream()), "zs3_ce_fwd")
         loss = loss_ws[0].clone()
         if group is not None:
-            # exact multi-rank normalisation: global sum(w*nll) / global sum(w) / global batch (loss.py:33-46 on the
-            # gathered batch of DataParallel); gradients are then SUM-reduced by GradSync
-            import torch.distributed as dist
-            pg = None if group is True else group
-            dist.all_reduce(loss_ws[1:3], group=pg)
-            world = dist.get_world_size(pg)
-            batch = batch * world
-            loss = loss_ws[2] / loss_ws[1] / (batch if batch > 0 else 1)
+            loss, batch = global_ce_normalise(loss_ws, batch, group)
         ctx.save_for_backward(z, target, weight, loss_ws)
         ctx.meta = (b, c, h, w, ld, ignore_index, batch)
         return loss
@@ -49,6 +42,18 @@ class _CrossEntropy(torch.autograd.Function):
                                ctypes.c_long(b * h * w), I(c), I(ignore_index), I(batch), P(loss_ws), P(gout), P(dz), I(c),
                                stream()), "zs3_ce_bwd")
         return ops.nchw(dz), None, None, None, None, None
+
+
+def global_ce_normalise(loss_ws, batch, group):
+    """Exact multi-rank normalisation of the CE (loss.py:33-46 evaluated on the gathered batch of nn.DataParallel):
+    loss_ws = [local loss, local sum(w), local sum(w * nll)]; entries 1-2 are SUM all-reduced IN PLACE (the backward kernel
+    scales by the global sum(w) it finds there) and the returned loss is global sum(w*nll) / global sum(w) / global batch.
+    Every rank's gradient is then its share of that loss' gradient, so GradSync's SUM reproduces the single-process one."""
+    import torch.distributed as dist
+    pg = None if group is True else group
+    dist.all_reduce(loss_ws[1:3], group=pg)
+    batch = batch * dist.get_world_size(pg)
+    return loss_ws[2] / loss_ws[1] / (batch if batch > 0 else 1), batch
 
 
 def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True, group=None):

@@ -133,3 +133,64 @@ class Evaluator:
         self._host = np.zeros((self.num_class,) * 2)
         if self._dev is not None:
             self._dev.zero_()
+
+
+class Evaluator_seen_unseen:
+    """Score tuples of zs3/utils/metrics.py:88-196 (`eval_pascal.py:83` builds one): overall / seen-rows / unseen-rows /
+    per-class-rows (accuracy, mean class accuracy, mean IU, frequency-weighted IU).  The reference histograms every image
+    up to 2 + num_class times with different ground-truth masks; a masked histogram is the full confusion matrix with the
+    other ground-truth rows zeroed, so one histogram per image is enough here and the metrics are identical."""
+
+    def __init__(self, num_class, unseen_classes_idx):
+        self.num_class = num_class
+        self.unseen_classes_idx = unseen_classes_idx
+
+    def _fast_hist(self, label_true, label_pred, n_class, target="all", unseen=None):
+        label_true, label_pred = np.asarray(label_true), np.asarray(label_pred)
+        keep = (label_true >= 0) & (label_true < n_class)
+        hist = np.bincount(n_class * label_true[keep].astype(int) + label_pred[keep], minlength=n_class ** 2)
+        return self._rows(hist.reshape(n_class, n_class), target, unseen)
+
+    def _fast_hist_specific_class(self, label_true, label_pred, n_class, target_class):
+        return self._rows(self._fast_hist(label_true, label_pred, n_class), "class", target_class)
+
+    @staticmethod
+    def _rows(hist, target, which):
+        """ground-truth rows of `hist` selected by the reference's `target` modes"""
+        if target == "all":
+            return hist
+        n = hist.shape[0]
+        sel = np.zeros(n, dtype=bool)
+        sel[np.atleast_1d(np.asarray(which, dtype=int))] = True
+        if target == "seen":
+            sel = ~sel
+        return hist * sel[:, None]
+
+    def _hist_to_metrics(self, hist):
+        hist = np.asarray(hist, dtype=np.float64)
+        diag, rows, total = np.diag(hist), hist.sum(axis=1), hist.sum()
+        acc = 0.0 if total == 0 else diag.sum() / total
+        acc_cls = np.nanmean(_safe_div(diag, rows))
+        iu = _safe_div(diag, rows + hist.sum(axis=0) - diag)
+        freq = _safe_div(rows, total)
+        return acc, acc_cls, np.nanmean(iu), (freq[freq > 0] * iu[freq > 0]).sum()
+
+    def label_accuracy_score(self, label_trues, label_preds, by_class=False):
+        n = self.num_class
+        hist = np.zeros((n, n))
+        class_hist = [np.zeros((n, n)) for _ in range(n)] if by_class else None
+        for lt, lp in zip(label_trues, label_preds):
+            lt, lp = np.asarray(lt).flatten(), np.asarray(lp).flatten()
+            h = self._fast_hist(lt, lp, n)
+            hist += h
+            if by_class:   # the reference adds a class's rows only for images that contain the class: the same rows
+                for c in np.unique(lt).astype(np.int32):
+                    if c != 255:
+                        class_hist[c] += self._rows(h, "class", c)
+        metrics = self._hist_to_metrics(hist)
+        if self.unseen_classes_idx:
+            metrics = (metrics, self._hist_to_metrics(self._rows(hist, "seen", self.unseen_classes_idx)),
+                       self._hist_to_metrics(self._rows(hist, "unseen", self.unseen_classes_idx)))
+        if by_class:
+            return metrics, [self._hist_to_metrics(h) for h in class_hist]
+        return metrics
