@@ -155,6 +155,28 @@ int zs3_mmd_bwd_ws(const float* gen, int ldg, const float* real, int ldr, int N,
 int zs3_gmmn_update_epilogue(const double* tile_ws, int N, float* loss_ring, void* slot_dev, int ring_len, void* step_dev,
                              void* seed_dev, long seed_inc, void* stream);
 
+/* ---- the GMMN generator update as latency-shaped kernels (gmmn.hip; train_pascal_GMMN.py:209-242, gmmn.py:17-22) ---------
+ * Row-GEMMs on 32x16 output tiles whose workgroups load their whole reduction extent in one burst (<= 20 chunks of 32), bf16x3
+ * on v_mfma_f32_16x16x32_bf16; w_pk / wt_pk are the forward / transposed operands of zs3_prep_weight (kchunks = K_pad / 32).
+ * fwd1: x[r] = [emb[pix[r]][0:Ca] | U[0,1)^Cb keyed on key[r] | 0] (stored to x_out, ld ldx); h = LeakyReLU(x W1^T + b1);
+ *       hd = Dropout(h; p_drop, mask keyed on key[r]) -- replaces zs3_gather_cat_noise + nn.Linear + LeakyReLU + nn.Dropout.
+ * fwd2: gen = hd W2^T + b2; also real_out[r] = real[gidx[r]] (the MMD's real samples; pass NULL to skip).
+ * dgrad: dpre = LeakyReLU'(h) * Dropout'(dgen W2) -- backward of fwd2, the dropout and the activation in one launch.
+ * wgrad: dw2 = dy2^T x2 ([co2][ci2]), db2 = column sums of dy2, and the same for layer 1, reduction over R <= 128 rows;
+ *        one launch for both layers.  All leading dimensions and channel counts: multiples of 4. */
+int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, const long* key, int Ca, int Cb, const void* w_pk,
+                      int kchunks, const float* bias, float* x_out, int ldx, float* h, float* hd, int ldo, int M, int N,
+                      float leak, float p_drop, unsigned long long seed_noise, unsigned long long seed_drop,
+                      const void* seed_dev, void* stream);
+int zs3_gmmn_mlp_fwd2(const float* hd, int lda, const void* w_pk, int kchunks, const float* bias, float* gen, int ldo, int M,
+                      int N, int K, const float* real, int ld_real, const long* gidx, float* real_out, void* stream);
+int zs3_gmmn_mlp_dgrad(const float* dgen, int lda, const void* wt_pk, int kchunks, const float* h, int ldh, const long* key,
+                       float* dpre, int ldo, int M, int N, int K, float leak, float p_drop, unsigned long long seed_drop,
+                       const void* seed_dev, void* stream);
+int zs3_gmmn_mlp_wgrad(const float* dy2, int ldy2, const float* x2, int ldx2, int co2, int ci2, float* dw2, float* db2,
+                       const float* dy1, int ldy1, const float* x1, int ldx1, int co1, int ci1, float* dw1, float* db1, int R,
+                       void* stream);
+
 /* ---- GMMN step helpers and optimisers (misc.hip) ---------------------------------------------- */
 /* nn.Dropout (aspp.py:100, decoder.py:19,23, gmmn.py:20): y = keep ? x/(1-p) : 0 with a counter-based mask
  * that is a pure function of (seed, element index); the backward is the same call on dy.  row_idx (optional,

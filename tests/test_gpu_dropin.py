@@ -324,7 +324,8 @@ def test_base_trainer_training_epoch(dev, golden):
 
 def test_gmmn_trainer_training_epoch(dev):
     """`GMMNTrainer.training(epoch, args)` (train_pascal_GMMN.py:134-311 surface): loader of dict batches, scheduler before
-    every step, two scalars per iteration; equals driving GMMNStep by hand on the same seeds."""
+    every step, two scalars per iteration, one batch of lookahead for the pipelined feature pass; equals driving GMMNStep
+    by hand on the same seeds."""
     import zs3_oracle as zo
     from zs3_amd import functional as Fz
     from zs3_amd.gmmn_trainer import GMMNStep, GMMNTrainer
@@ -342,7 +343,7 @@ def test_gmmn_trainer_training_epoch(dev):
     for it in range(2):
         b = zo.make_synthetic_batch(4, 65, seed=200 + it, with_label_emb=True)
         loader.append({k: b[k] for k in ("image", "label", "label_emb")})
-    loader.insert(1, {k: v[:1] for k, v in loader[0].items()})     # single-sample batch: skipped
+    loader.append({k: v[:1] for k, v in loader[0].items()})        # single-sample batch: skipped
 
     def build():
         torch.manual_seed(1)
@@ -361,18 +362,18 @@ def test_gmmn_trainer_training_epoch(dev):
     c_it = [v for t, v, _ in rec.scalars if t == "train/total_loss_iter"]
     g_it = [v for t, v, _ in rec.scalars if t == "train/generator_loss"]
     assert len(c_it) == len(g_it) == 2 and abs(total - sum(c_it)) < 1e-6 * total
-    assert [s for t, _, s in rec.scalars if t == "train/total_loss_iter"] == [0, 2]
+    assert [s for t, _, s in rec.scalars if t == "train/total_loss_iter"] == [0, 1]
     net2, gen2, opt2, opt_g2, crit2 = build()
     step = GMMNStep(net2, gen2, opt2, opt_g2, crit2, seen=seen, unseen=[10, 14], noise="cpu")
     sched = LR_Scheduler("poly", 0.007, 2, 3, verbose=False)
     torch.manual_seed(31)
-    for i, sample in enumerate(loader):
-        if len(sample["image"]) <= 1:
-            continue
+    # the trainer looks one batch ahead: batch 1's feature pass is started next to batch 0's generator loop
+    images = [loader[0]["image"].to(dev), loader[1]["image"].to(dev)]
+    for i in range(2):
         sched(opt2, i, 0, 0.0)
-        gl, cl, _ = step(sample["image"].to(dev), sample["label"].to(dev), sample["label_emb"].to(dev))
-        j = 0 if i == 0 else 1
-        assert abs(gl - g_it[j]) <= 1e-6 * abs(gl) and abs(cl - c_it[j]) <= 1e-6 * abs(cl)
+        gl, cl, _ = step(images[i], loader[i]["label"].to(dev), loader[i]["label_emb"].to(dev),
+                         next_image=images[1] if i == 0 else None)
+        assert abs(gl - g_it[i]) <= 1e-6 * abs(gl) and abs(cl - c_it[i]) <= 1e-6 * abs(cl)
     for a, b in zip(gen.parameters(), gen2.parameters()):
         assert torch.equal(a, b)
 

@@ -108,16 +108,35 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
   }
 }
 
-// one wave per channel: combine `chunks` partials in fp64
-__device__ __forceinline__ void combine_partials(const float* partial, int chunks, int C, int c, double& s, double& q) {
-  const int lane = threadIdx.x & 63;
+// 32 channels per 256-thread block: thread (ty, tx) sums the partial rows ty, ty+8, ... of channel c0 + tx in fp64 (a
+// half-wave reads 128 contiguous bytes of a partial row), the eight row groups are combined through LDS in a fixed order
+// (deterministic); the result is valid in the threads with ty == 0.  (The previous one-wave-per-channel form read one
+// 4-byte value per lane with stride C: ~10 us per call, 226 calls on the step's dependent chain.)
+constexpr int FIN_CH = 32, FIN_GROUPS = 8;
+__device__ __forceinline__ bool combine_partials(const float* partial, int chunks, int C, int& c, double& s, double& q) {
+  __shared__ double red[2][FIN_GROUPS][FIN_CH];
+  const int tx = threadIdx.x & (FIN_CH - 1), ty = threadIdx.x / FIN_CH;
+  c = blockIdx.x * FIN_CH + tx;
   double ls = 0.0, lq = 0.0;
-  for (int k = lane; k < chunks; k += 64) {
-    ls += (double)partial[((size_t)k * 2 + 0) * C + c];
-    lq += (double)partial[((size_t)k * 2 + 1) * C + c];
+  if (c < C) {
+#pragma unroll 4
+    for (int k = ty; k < chunks; k += FIN_GROUPS) {
+      ls += (double)partial[((size_t)k * 2 + 0) * C + c];
+      lq += (double)partial[((size_t)k * 2 + 1) * C + c];
+    }
   }
-  s = wave_sum_d(ls);
-  q = wave_sum_d(lq);
+  red[0][ty][tx] = ls;
+  red[1][ty][tx] = lq;
+  __syncthreads();
+  if (ty != 0 || c >= C) return false;
+  s = 0.0;
+  q = 0.0;
+#pragma unroll
+  for (int g = 0; g < FIN_GROUPS; ++g) {
+    s += red[0][g][tx];
+    q += red[1][g][tx];
+  }
+  return true;
 }
 
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* partial, int chunks, int C, double count,
@@ -126,12 +145,11 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* parti
                                                              float* mean_out, float* invstd_out, float* scale_out,
                                                              float* shift_out, long* num_batches_tracked) {
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  int c;
   double s, q;
-  combine_partials(partial, chunks, C, c, s, q);
+  const bool owner = combine_partials(partial, chunks, C, c, s, q);
   if (count_dev) count = *count_dev;  // cross-rank sample count produced on the device by the SyncBN all-reduce
-  if ((threadIdx.x & 63) == 0) {
+  if (owner) {
     double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -166,12 +184,11 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int chunks, int C, double count,
                                                              const double* count_dev, float* dgamma, float* dbeta, float* c1, float* c2,
                                                              int use_batch_stats) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  int c;
   double s, q;
-  combine_partials(partial, chunks, C, c, s, q);
+  const bool owner = combine_partials(partial, chunks, C, c, s, q);
   if (count_dev) count = *count_dev;
-  if ((threadIdx.x & 63) == 0) {
+  if (owner) {
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
     c1[c] = use_batch_stats ? (float)(s / count) : 0.f;
@@ -356,7 +373,7 @@ extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, doub
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_out, float* invstd_out, float* scale_out,
                                    float* shift_out, long* num_batches_tracked, void* stream) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
                      count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
                      shift_out, num_batches_tracked);
   return ZS3_LAUNCH_CHECK();
@@ -373,7 +390,7 @@ extern "C" int zs3_bn_eval_affine(const float* gamma, const float* beta, const f
 extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
                                    float* dgamma, float* dbeta,
                                    float* c1, float* c2, int use_batch_stats, void* stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
                      count, count_dev, dgamma, dbeta, c1, c2, use_batch_stats);
   return ZS3_LAUNCH_CHECK();
 }

@@ -452,10 +452,20 @@ int launch_wgrad_dma_prec(const WgradArgs& a, int taps, int splitk, hipStream_t 
   return ZS3_LAUNCH_CHECK();
 }
 
+// dw = sum over the split-K slabs (fixed order: deterministic); n4 = slab / 4 when slab and the pointers allow 16-byte accesses
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int splitk, long slab) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < splitk; ++k) s += part[(size_t)k * slab + i];
+    dw[i] = s;
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dw, long n4,
+                                                           int splitk, long slab4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 s = part[i];
+#pragma unroll 4
+    for (int k = 1; k < splitk; ++k) s += part[(size_t)k * slab4 + i];
     dw[i] = s;
   }
 }
@@ -471,9 +481,19 @@ int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, hipStream_t
   return ZS3_LAUNCH_CHECK();
 }
 
+static int wgrad_cus() {   // CUs one launch is sized for: 256 / (streams of the wgrad pool), ZS3_WGRAD_CUS
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ZS3_WGRAD_CUS");
+    v = e ? atoi(e) : 256;
+    if (v < 8 || v > 256) v = 256;
+  }
+  return v;
+}
+
 int pick_splitk(int M, int tiles) {
   int chunks = (M + 31) / 32;
-  int want = (768 + tiles - 1) / tiles;   // aim at >= ~768 workgroups (3 per CU); every split costs a [Cout][K] slab of traffic
+  int want = (3 * wgrad_cus() + tiles - 1) / tiles;   // aim at >= ~768 workgroups (3 per CU); every split costs a [Cout][K] slab of traffic
   if (want < 1) want = 1;
   int maxs = chunks / 16;                 // at least 16 K-steps (512 pixels) per split
   if (maxs < 1) maxs = 1;
@@ -519,13 +539,14 @@ static int pick_splitk_dma(int M, int tiles, long out_elems) {
   static int forced = -1;
   if (forced < 0) forced = env_int("ZS3_WGRAD_SPLIT");   // debug knob
   if (forced > 0) return forced < maxs ? forced : maxs;
+  const int cus = wgrad_cus();
   const double slab_units = (double)out_elems * 4.0 * 2.0 / 1e12 / 1.5e-6;
   const long ksteps = (M + 15) / 16;
   int best = 1;
   double best_t = 1e30;
   for (int s = 1; s <= maxs; ++s) {
     const long n = (long)tiles * s;
-    const double t = (double)((n + 255) / 256) * ((double)((ksteps + s - 1) / s) + 12.0) + (s > 1 ? s * slab_units : 0.0);
+    const double t = (double)((n + cus - 1) / cus) * ((double)((ksteps + s - 1) / s) + 12.0) + (s > 1 ? s * slab_units : 0.0);
     if (t < best_t) {
       best_t = t;
       best = s;
@@ -599,7 +620,14 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
     long n = a.slab;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, splitk, a.slab);
+    if ((n & 3) == 0 && (((uintptr_t)workspace | (uintptr_t)dw) & 15) == 0) {
+      blocks = (int)((n / 4 + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)workspace, (f32x4*)dw, n / 4,
+                         splitk, a.slab / 4);
+    } else {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, splitk, a.slab);
+    }
     rc = ZS3_LAUNCH_CHECK();
   }
   return rc;

@@ -1,0 +1,386 @@
+// The GMMN generator's per-(image, class) update as latency-shaped kernels (train_pascal_GMMN.py:209-242).
+//
+// One update runs the two-layer MLP (gmmn.py:17-22: Linear 600->256, LeakyReLU(0.2), Dropout(0.5), Linear 256->256) on
+// S = 128 sampled rows, the MMD loss, the MLP backward and one Adam step, and the NEXT update needs the new weights: a
+// dependent chain of ~10 stages of a few MFLOP each, 225 times per training step.  Nothing here is throughput-bound; what
+// counts is the length of the chain and the latency of every stage.  The general conv kernels spent 10-13 us per stage
+// (19 dependent K steps on 8 workgroups); these kernels are shaped for the problem instead:
+//   * mlp_gemm_kernel: a row-GEMM out[M][N] = A[M][K] * W[N][K]^T on 32 x 16 output tiles (64 workgroups for 128 x 256):
+//     the workgroup loads its WHOLE K extent of both operands in one burst (one memory round trip), its four waves split
+//     K between them (bf16x3 on v_mfma_f32_16x16x32_bf16, fp32 accumulate) and combine through LDS in a fixed order.
+//     Fused around it: the gather of the class-embedding rows + the noise draw (forward 1), bias + LeakyReLU + Dropout
+//     (forward 1), bias + the gather of the sampled real features (forward 2), Dropout-backward * LeakyReLU' (dgrad).
+//   * mlp_wgrad_kernel: both layers' weight gradients dW[co][ci] = sum_r dY[r][co] X[r][ci] (reduction over the 128 rows)
+//     and both bias gradients in ONE launch of 64 x 64 tiles.
+// 16 launches per update become 8.  Arithmetic: every product is the bf16x3 split of common.h (fp32-class accuracy).
+#include "common.h"
+#include "zs3hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f4;
+
+// same counter hash as misc.hip (the masks / noise of a replayed update must not depend on which kernel draws them)
+__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// eight fp32 values -> the bf16 hi / lo fragments of one MFMA operand (bf16x3 split, common.h)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_pair<3>(v[2 * e], v[2 * e + 1], h[e], l[e]);
+  const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+  hi = __builtin_bit_cast(bf16x8, hv);
+  lo = __builtin_bit_cast(bf16x8, lv);
+}
+
+enum { MLP_FWD1 = 1, MLP_FWD2 = 2, MLP_DGRAD = 3 };
+
+struct MlpArgs {
+  const float* a;            // [M][lda] fp32 (FWD2: hd, DGRAD: d(gen)); unused by FWD1
+  const unsigned short* w;   // packed planes of zs3_prep_weight: row n at w + n * kchunks * 64
+  const float* bias;         // [N] or null
+  float* out;                // [M][ldo]: FWD1 h (after LeakyReLU), FWD2 gen, DGRAD d(pre-activation)
+  float* out2;               // FWD1: hd = dropout(h), [M][ldo]
+  int lda, ldo, M, N, K, kchunks;
+  // FWD1: A row r = [emb[pix[r]][0:Ca] | U[0,1)^Cb keyed on key[r] | 0]; the rows are also stored to x_out (wgrad operand)
+  const float* emb;
+  const long* pix;
+  const long* key;           // sampled within-class pixel index: keys the noise (FWD1) and the dropout mask (FWD1, DGRAD)
+  float* x_out;
+  int ld_emb, Ca, Cb, ldx;
+  // FWD2: real_out[r] = real[gidx[r]] (the MMD's real samples), copied by the workgroups of this launch
+  const float* real;
+  const long* gidx;
+  float* real_out;
+  int ld_real;
+  // DGRAD: h of FWD1 (LeakyReLU mask)
+  const float* h;
+  int ldh;
+  float leak, p_drop;
+  unsigned long long seed_noise, seed_drop;
+  const unsigned long long* seed_dev;
+};
+
+constexpr int MLP_BM = 32, MLP_BN = 16, MLP_MAXCH = 20;   // <= 640 reduction elements per call
+
+template <int MODE>
+__global__ __launch_bounds__(256) void mlp_gemm_kernel(const MlpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int kpad = p.kchunks * 32;
+  const int SA = kpad + 4;                    // floats per A row (+16 B: ds_read_b128 of 16 rows hits 16 bank quads)
+  const int SB = p.kchunks * 64 + 8;          // bf16 per W row (+16 B)
+  float* As = reinterpret_cast<float*>(smem);
+  unsigned short* Bs = reinterpret_cast<unsigned short*>(smem + (size_t)MLP_BM * SA * 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = (p.N + MLP_BN - 1) / MLP_BN;
+  const int mb = blockIdx.x / nb, nbk = blockIdx.x - mb * nb;
+  const int m0 = mb * MLP_BM, n0 = nbk * MLP_BN;
+  unsigned long long s_noise = p.seed_noise, s_drop = p.seed_drop;
+  if (p.seed_dev) {
+    s_noise += p.seed_dev[0];
+    s_drop += p.seed_dev[0];
+  }
+
+  // ---- one burst: the whole K extent of this tile's rows of A and of W.  Every global load is issued before the first
+  // LDS write (and before the noise is hashed), so the tile costs ONE memory round trip; <= 20 K chunks (checked by the host)
+  constexpr int MAXA = MLP_BM * (MLP_MAXCH * 8) / 256, MAXB = (MLP_BN * MLP_MAXCH * 8 + 255) / 256;
+  const int a4 = kpad >> 2, na = MLP_BM * a4;
+  const int b16 = p.kchunks * 8, nbp = MLP_BN * b16;   // 16-byte pieces per W row / per tile
+  f4 av[MAXA];
+  u32x4 bv[MAXB];
+#pragma unroll
+  for (int u = 0; u < MAXB; ++u) {
+    const int i = tid + u * 256;
+    bv[u] = u32x4{0u, 0u, 0u, 0u};
+    if (i < nbp) {
+      const int n = i / b16, piece = i - n * b16;
+      if (n0 + n < p.N) bv[u] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(n0 + n) * p.kchunks * 64 + piece * 8);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXA; ++u) {
+    const int i = tid + u * 256;
+    av[u] = f4{0.f, 0.f, 0.f, 0.f};
+    if (i < na) {
+      const int r = i / a4, c = (i - r * a4) * 4, m = m0 + r;
+      if (m < p.M) {
+        if (MODE == MLP_FWD1) {
+          if (c < p.Ca) av[u] = *reinterpret_cast<const f4*>(p.emb + p.pix[m] * p.ld_emb + c);
+        } else if (c < p.K) {
+          av[u] = *reinterpret_cast<const f4*>(p.a + (size_t)m * p.lda + c);
+        }
+      }
+    }
+  }
+  if (MODE == MLP_FWD1) {
+#pragma unroll
+    for (int u = 0; u < MAXA; ++u) {
+      const int i = tid + u * 256;
+      if (i < na) {
+        const int r = i / a4, c = (i - r * a4) * 4, m = m0 + r;
+        if (m < p.M) {
+          if (c >= p.Ca && c < p.Ca + p.Cb) {
+            const unsigned long long base = (unsigned long long)(p.key[m] * p.Cb + (c - p.Ca));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[u][e] = u01(s_noise, base + e);
+          }
+          if (p.x_out && nbk == 0 && c < p.ldx) *reinterpret_cast<f4*>(p.x_out + (size_t)m * p.ldx + c) = av[u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXA; ++u) {
+    const int i = tid + u * 256;
+    if (i < na) {
+      const int r = i / a4, c = (i - r * a4) * 4;
+      *reinterpret_cast<f4*>(As + r * SA + c) = av[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXB; ++u) {
+    const int i = tid + u * 256;
+    if (i < nbp) {
+      const int n = i / b16, piece = i - n * b16;
+      *reinterpret_cast<u32x4*>(Bs + n * SB + piece * 8) = bv[u];
+    }
+  }
+  if (MODE == MLP_FWD2 && p.real_out) {       // the sampled real rows, 16 columns per workgroup
+    for (int i = tid; i < MLP_BM * (MLP_BN / 4); i += 256) {
+      const int r = i / (MLP_BN / 4), c = n0 + (i - r * (MLP_BN / 4)) * 4;
+      const int m = m0 + r;
+      if (m < p.M && c < p.N)
+        *reinterpret_cast<f4*>(p.real_out + (size_t)m * p.N + c) = *reinterpret_cast<const f4*>(p.real + p.gidx[m] * p.ld_real + c);
+    }
+  }
+  __syncthreads();
+
+  // ---- wave w multiplies the K chunks w, w+4, ...: two 16x16 tiles (rows 0-15 / 16-31), bf16x3
+  const int r16 = lane & 15, kg = lane >> 4;
+  f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int ch = wave; ch < p.kchunks; ch += 4) {
+    const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(Bs + r16 * SB + ch * 64 + kg * 8);
+    const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(Bs + r16 * SB + ch * 64 + 32 + kg * 8);
+#pragma unroll
+    for (int rf = 0; rf < 2; ++rf) {
+      const float* src = As + (rf * 16 + r16) * SA + ch * 32 + kg * 8;
+      const f4 v0 = *reinterpret_cast<const f4*>(src), v1 = *reinterpret_cast<const f4*>(src + 4);
+      const float av[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      bf16x8 a_hi, a_lo;
+      split8(av, a_hi, a_lo);
+      acc[rf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc[rf], 0, 0, 0);
+      acc[rf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc[rf], 0, 0, 0);
+      acc[rf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc[rf], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // operands are no longer read: the partial tiles reuse the A region
+  f4* red = reinterpret_cast<f4*>(smem);      // [wave][rf][lane]
+  red[(wave * 2 + 0) * 64 + lane] = acc[0];
+  red[(wave * 2 + 1) * 64 + lane] = acc[1];
+  __syncthreads();
+  if (tid >= 128) return;
+  const int rf = tid >> 6;
+  f4 v = red[(0 * 2 + rf) * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) v += red[(w * 2 + rf) * 64 + lane];   // fixed order: deterministic
+  const int col = n0 + r16;
+  if (col >= p.N) return;
+  const float bias_v = p.bias ? p.bias[col] : 0.f;
+  const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = m0 + rf * 16 + kg * 4 + e;   // C layout of the 16x16 MFMA: row = (lane >> 4) * 4 + e, col = lane & 15
+    if (m >= p.M) continue;
+    float t = v[e] + bias_v;
+    if (MODE == MLP_FWD1) {
+      t = t > 0.f ? t : t * p.leak;
+      p.out[(size_t)m * p.ldo + col] = t;
+      if (p.p_drop > 0.f) t = u01(s_drop, (unsigned long long)(p.key[m] * p.N + col)) >= p.p_drop ? t * inv_keep : 0.f;
+      p.out2[(size_t)m * p.ldo + col] = t;
+    } else if (MODE == MLP_FWD2) {
+      p.out[(size_t)m * p.ldo + col] = t;
+    } else {
+      if (p.p_drop > 0.f) t = u01(s_drop, (unsigned long long)(p.key[m] * p.N + col)) >= p.p_drop ? t * inv_keep : 0.f;
+      p.out[(size_t)m * p.ldo + col] = p.h[(size_t)m * p.ldh + col] > 0.f ? t : t * p.leak;
+    }
+  }
+}
+
+template <int MODE>
+int launch_mlp(const MlpArgs& a, hipStream_t st) {
+  if (a.kchunks < 1 || a.kchunks > MLP_MAXCH) return -2;
+  const size_t lds = (size_t)MLP_BM * (a.kchunks * 32 + 4) * 4 + (size_t)MLP_BN * (a.kchunks * 64 + 8) * 2;
+  static size_t configured = 0;
+  if (lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return -4;
+    configured = lds;
+  }
+  const int blocks = ((a.M + MLP_BM - 1) / MLP_BM) * ((a.N + MLP_BN - 1) / MLP_BN);
+  hipLaunchKernelGGL((mlp_gemm_kernel<MODE>), dim3(blocks), dim3(256), lds, st, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+// ---- both weight gradients and both bias gradients of the MLP in one launch -----------------------------------------
+struct WgProb {
+  const float* dy;   // [R][ldy], co columns
+  const float* x;    // [R][ldx], ci columns
+  float* dw;         // [co][ci] (row stride ci)
+  float* db;         // [co]
+  int ldy, ldx, co, ci, tiles_ci, tile0;   // tile0: first block id of this problem
+};
+struct WgArgs {
+  WgProb pr[2];
+  int R;
+};
+
+constexpr int WG_T = 64, WG_LD = 66;   // 66-float rows: the two 8-row halves of a ds_read_b32 group land 16 banks apart
+
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x 33 KB: above the 64 KB static limit
+  float* Ys = reinterpret_cast<float*>(smem);
+  float* Xs = Ys + 128 * WG_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const WgProb& q = p.pr[blockIdx.x >= p.pr[1].tile0 ? 1 : 0];
+  const int t = blockIdx.x - q.tile0;
+  const int tco = t / q.tiles_ci, tci = t - tco * q.tiles_ci;
+  const int co0 = tco * WG_T, ci0 = tci * WG_T;
+  for (int i = tid; i < 128 * (WG_T / 4); i += 256) {
+    const int r = i / (WG_T / 4), c = (i - r * (WG_T / 4)) * 4;
+    f4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+    if (r < p.R) {
+      if (co0 + c < q.co) vy = *reinterpret_cast<const f4*>(q.dy + (size_t)r * q.ldy + co0 + c);   // co, ci: multiples of 4
+      if (ci0 + c < q.ci) vx = *reinterpret_cast<const f4*>(q.x + (size_t)r * q.ldx + ci0 + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Ys[r * WG_LD + c + e] = vy[e];
+      Xs[r * WG_LD + c + e] = vx[e];
+    }
+  }
+  __syncthreads();
+  const int wi = wave >> 1, wj = wave & 1;
+  const int m16 = lane & 15, kg = lane >> 4;
+  f4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < 4; ++kc) {          // 32 rows of the reduction per MFMA
+    const int k0 = kc * 32 + kg * 8;
+    bf16x8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float ya[8], xb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ya[e] = Ys[(k0 + e) * WG_LD + wi * 32 + f * 16 + m16];
+        xb[e] = Xs[(k0 + e) * WG_LD + wj * 32 + f * 16 + m16];
+      }
+      split8(ya, a_hi[f], a_lo[f]);
+      split8(xb, b_hi[f], b_lo[f]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + wj * 32 + j * 16 + m16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wi * 32 + i * 16 + kg * 4 + e;
+        if (co < q.co && ci < q.ci) q.dw[(size_t)co * q.ci + ci] = acc[i][j][e];
+      }
+    }
+  if (tci == 0 && tid < WG_T && co0 + tid < q.co && q.db) {   // bias gradient: column sums of dy, rows in order
+    float s = 0.f;
+    for (int r = 0; r < p.R; ++r) s += Ys[r * WG_LD + tid];
+    q.db[co0 + tid] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, const long* key, int Ca, int Cb,
+                                 const void* w_pk, int kchunks, const float* bias, float* x_out, int ldx, float* h,
+                                 float* hd, int ldo, int M, int N, float leak, float p_drop, unsigned long long seed_noise,
+                                 unsigned long long seed_drop, const void* seed_dev, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if ((Ca & 3) || (Cb & 3) || (ld_emb & 3) || (ldx & 3) || Ca + Cb > kchunks * 32 || (x_out && ldx > kchunks * 32) || !key || !pix) return -1;
+  MlpArgs a = {};
+  a.w = (const unsigned short*)w_pk; a.bias = bias; a.out = h; a.out2 = hd; a.ldo = ldo; a.M = M; a.N = N; a.K = Ca + Cb;
+  a.kchunks = kchunks; a.emb = emb; a.pix = pix; a.key = key; a.x_out = x_out; a.ld_emb = ld_emb; a.Ca = Ca; a.Cb = Cb;
+  a.ldx = ldx; a.leak = leak; a.p_drop = p_drop; a.seed_noise = seed_noise; a.seed_drop = seed_drop;
+  a.seed_dev = (const unsigned long long*)seed_dev;
+  return launch_mlp<MLP_FWD1>(a, (hipStream_t)stream);
+}
+
+extern "C" int zs3_gmmn_mlp_fwd2(const float* hd, int lda, const void* w_pk, int kchunks, const float* bias, float* gen,
+                                 int ldo, int M, int N, int K, const float* real, int ld_real, const long* gidx,
+                                 float* real_out, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if ((lda & 3) || (K & 3) || K > kchunks * 32 || (real_out && ((N & 3) || (ld_real & 3) || !real || !gidx))) return -1;
+  MlpArgs a = {};
+  a.a = hd; a.lda = lda; a.w = (const unsigned short*)w_pk; a.kchunks = kchunks; a.bias = bias; a.out = gen; a.ldo = ldo;
+  a.M = M; a.N = N; a.K = K; a.real = real; a.ld_real = ld_real; a.gidx = gidx; a.real_out = real_out;
+  return launch_mlp<MLP_FWD2>(a, (hipStream_t)stream);
+}
+
+extern "C" int zs3_gmmn_mlp_dgrad(const float* dgen, int lda, const void* wt_pk, int kchunks, const float* h, int ldh,
+                                  const long* key, float* dpre, int ldo, int M, int N, int K, float leak, float p_drop,
+                                  unsigned long long seed_drop, const void* seed_dev, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if ((lda & 3) || (K & 3) || K > kchunks * 32 || !h || (p_drop > 0.f && !key)) return -1;
+  MlpArgs a = {};
+  a.a = dgen; a.lda = lda; a.w = (const unsigned short*)wt_pk; a.kchunks = kchunks; a.out = dpre; a.ldo = ldo; a.M = M;
+  a.N = N; a.K = K; a.h = h; a.ldh = ldh; a.key = key; a.leak = leak; a.p_drop = p_drop; a.seed_drop = seed_drop;
+  a.seed_dev = (const unsigned long long*)seed_dev;
+  return launch_mlp<MLP_DGRAD>(a, (hipStream_t)stream);
+}
+
+extern "C" int zs3_gmmn_mlp_wgrad(const float* dy2, int ldy2, const float* x2, int ldx2, int co2, int ci2, float* dw2,
+                                  float* db2, const float* dy1, int ldy1, const float* x1, int ldx1, int co1, int ci1,
+                                  float* dw1, float* db1, int R, void* stream) {
+  if (R <= 0 || R > 128) return -1;
+  if ((ldy2 | ldx2 | co2 | ci2 | ldy1 | ldx1 | co1 | ci1) & 3) return -1;
+  WgArgs a;
+  a.R = R;
+  const float* dys[2] = {dy2, dy1};
+  const float* xs[2] = {x2, x1};
+  float* dws[2] = {dw2, dw1};
+  float* dbs[2] = {db2, db1};
+  const int ldys[2] = {ldy2, ldy1}, ldxs[2] = {ldx2, ldx1}, cos_[2] = {co2, co1}, cis[2] = {ci2, ci1};
+  int tiles = 0;
+  for (int i = 0; i < 2; ++i) {
+    WgProb& q = a.pr[i];
+    q.dy = dys[i]; q.x = xs[i]; q.dw = dws[i]; q.db = dbs[i]; q.ldy = ldys[i]; q.ldx = ldxs[i]; q.co = cos_[i]; q.ci = cis[i];
+    q.tiles_ci = (cis[i] + WG_T - 1) / WG_T;
+    q.tile0 = tiles;
+    tiles += q.tiles_ci * ((cos_[i] + WG_T - 1) / WG_T);
+  }
+  constexpr int LDS = 2 * 128 * WG_LD * 4;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return -4;
+    configured = true;
+  }
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles), dim3(256), LDS, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}

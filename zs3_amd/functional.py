@@ -5,6 +5,7 @@ contiguous).  Each Function is one *fused layer* (conv + BatchNorm + residual + 
 training step is ~150 autograd nodes instead of ~700 ATen ops.  Nothing here falls back to torch
 compute: tensors must live on the GPU and libzs3hip.so must be present.
 """
+import os
 import random
 import weakref
 
@@ -23,22 +24,37 @@ WGRAD_SIDE_STREAM = True
 FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
 LAZY_SKIP_GRAD = True      # identity blocks: the skip gradient dA*mask is applied by conv1's dgrad epilogue, never stored
 _lazy_skip = {}            # data_ptr of a block-output gradient -> (tensor, sign bits) it still has to be masked with
+# The layers' weight gradients are independent of each other: with WGRAD_STREAMS > 1 they go round-robin over a small pool
+# of side streams, each launch sized (split-K) for its share of the chip (ZS3_WGRAD_CUS, read by zs3_conv_wgrad_plan) --
+# fewer K splits per layer = less split-K slab traffic, the same number of workgroups in flight.
+WGRAD_STREAMS = max(1, int(os.environ.get("ZS3_WGRAD_STREAMS", "1")))
 _side = {}
+_side_next = {}
 _join_armed = [False]
 
 
-def wgrad_stream(device):
+def wgrad_streams(device):
     key = device.index
     if key not in _side:
-        _side[key] = torch.cuda.Stream(device=device)
+        _side[key] = [torch.cuda.Stream(device=device) for _ in range(WGRAD_STREAMS)]
+        _side_next[key] = 0
     return _side[key]
 
 
+def wgrad_stream(device):
+    """the side stream the next weight-gradient launch goes to (round-robin over the pool)"""
+    pool = wgrad_streams(device)
+    i = _side_next[device.index]
+    _side_next[device.index] = (i + 1) % len(pool)
+    return pool[i]
+
+
 def join_wgrad_stream():
-    """Make the current stream wait for every wgrad launched on the side stream (called at the end of backward)."""
+    """Make the current stream wait for every wgrad launched on the side streams (called at the end of backward)."""
     _join_armed[0] = False
-    for st in _side.values():
-        torch.cuda.current_stream(st.device).wait_stream(st)
+    for pool in _side.values():
+        for st in pool:
+            torch.cuda.current_stream(st.device).wait_stream(st)
 
 
 

@@ -92,10 +92,10 @@ class GCNContextStep(GMMNStep):
         target = torch.cat(self._cluster_labels).float().view(1, k, 1)
         (self.GCN_weight * self.criterion(out, target)).backward()
 
-    def __call__(self, image, target, embedding=None, table=None):
+    def __call__(self, image, target, embedding=None, table=None, next_image=None):
         """-> (generator_loss_batch, generator_GCN_loss_batch, classifier_loss, logits)"""
         self._cluster_feats, self._cluster_labels, self._gcn_losses = [], [], []
-        g_loss, c_loss, out = super().__call__(image, target, embedding=embedding, table=table)
+        g_loss, c_loss, out = super().__call__(image, target, embedding=embedding, table=table, next_image=next_image)
         gcn_loss = float(torch.cat(self._gcn_losses).sum().item()) if self._gcn_losses else 0.0
         self.last_generator_GCN_loss = gcn_loss
         self.last_num_clusters = int(sum(t.shape[0] for t in self._cluster_labels))

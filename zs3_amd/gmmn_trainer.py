@@ -48,7 +48,7 @@ class GMMNStep:
     def __init__(self, model, generator, optimizer, optimizer_generator, criterion, *, seen, unseen, noise_dim=300,
                  embed_dim=300, feature_dim=256, batch_size_generator=128, real_seen_features=True,
                  sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True, group=None, grad_reduce=None,
-                 context_aware=False):
+                 context_aware=False, fused_mlp=True):
         """group: None (single process) | True (default process group) | a torch.distributed group.
         grad_reduce: "sum" when `criterion` already normalises by the global batch / valid-pixel weight
         (SegmentationLosses(group=...)), "mean" when it normalises per rank; default: picked from the criterion.
@@ -79,8 +79,14 @@ class GMMNStep:
         from .optim import Adam
         self.fused_adam = isinstance(optimizer_generator, Adam)
         self.use_graph = use_graph and self.fused_adam
+        # the update's MLP forward / backward on the latency-shaped kernels of csrc/gmmn.hip (8 launches per update instead
+        # of 16); False keeps the general conv kernels (the A/B reference in tests)
+        self.fused_mlp = bool(fused_mlp)
         self._st = None       # static buffers (allocated at first call)
         self._graph = None
+        self._feat_stream = None   # side stream of the pipelined feature pass (prefetch)
+        self._prefetched = None    # (image, features, ready event) of the next batch
+        self.last_updates = 0
         self._sig = (ctypes.c_float * len(self.sigma))(*self.sigma)
 
     # ------------------------------------------------------------------ helpers
@@ -153,34 +159,75 @@ class GMMNStep:
         lin1, lrelu, drop, lin2 = self._layers()
         s, d = self.bsg, self.feature_dim
         width = self.embed_dim + self.noise_dim
-        if self.noise != "cpu" and not self.context_aware:   # noise drawn inside the gather (same stream as zs3_uniform on a [S, noise_dim] tensor)
-            x = ops.gather_cat_noise(st["emb"], st["pix_local"], self.embed_dim, self.noise_dim, width, s, st["seed_base"],
-                                     seed_dev=st["seed_dev"], noise_key=st["ridx"])   # z[random_idx]: duplicates share noise
-        else:
-            x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, width)
-        h = _rows_gemm(x, st["wp1"], lin1.bias, Fz.ACT_LEAKY, lrelu.negative_slope)
         use_drop = training and drop.p > 0
         dseed = st["seed_base"] ^ 0x5DEECE66D
-        hd = ops.dropout(h, drop.p, dseed, row_idx=st["ridx"], seed_dev=st["seed_dev"]) if use_drop else h
-        gen_s = _rows_gemm(hd, st["wp2"], lin2.bias)
-        real_s = ops.gather_rows(st["real"], st["pix_global"])
+        wp1, wp2 = st["wp1"], st["wp2"]
+        device_noise = self.noise != "cpu" and not self.context_aware
+        fused = (self.fused_mlp and s <= 128 and width % 4 == 0 and self.embed_dim % 4 == 0 and wp1.cin_pad <= 640 and
+                 wp2.cin_pad <= 640 and wp2.cout_pad <= 640 and d % 4 == 0 and wp1.cout % 4 == 0)
         t = (2 * s + 31) // 32
-        gmat = torch.empty((2 * s, 2 * s), dtype=torch.float32, device=x.device)
-        tile = torch.empty(2 * t * t, dtype=torch.float64, device=x.device)
+        gmat = torch.empty((2 * s, 2 * s), dtype=torch.float32, device=st["emb"].device)
+        tile = torch.empty(2 * t * t, dtype=torch.float64, device=st["emb"].device)
+        if fused:
+            dev = st["emb"].device
+            hid = wp1.cout
+            x = torch.empty((s, width), dtype=torch.float32, device=dev)
+            h = torch.empty((s, hid), dtype=torch.float32, device=dev)
+            hd = torch.empty((s, hid), dtype=torch.float32, device=dev)
+            gen_s = torch.empty((s, d), dtype=torch.float32, device=dev)
+            real_s = torch.empty((s, d), dtype=torch.float32, device=dev)
+            if device_noise:     # rows gathered and noise drawn inside the first GEMM's operand load
+                check(lib().zs3_gmmn_mlp_fwd1(P(st["emb"]), I(st["emb"].stride(0)), P(st["pix_local"]), P(st["ridx"]),
+                                              I(self.embed_dim), I(self.noise_dim), P(wp1.f_pk), I(wp1.cin_pad // 32),
+                                              P(lin1.bias), P(x), I(width), P(h), P(hd), I(hid), I(s), I(hid),
+                                              F(lrelu.negative_slope), F(drop.p if use_drop else 0.0),
+                                              ctypes.c_ulonglong(st["seed_base"]), ctypes.c_ulonglong(dseed), P(st["seed_dev"]),
+                                              stream()), "zs3_gmmn_mlp_fwd1")
+            else:                # noise from the host (reference RNG stream) / context vector: z sits in st["z"]
+                x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, width)
+                ident = st.setdefault("ident", torch.arange(s, dtype=torch.int64, device=dev))
+                # Cb = 0: the whole row is "embedding" = the already assembled x
+                check(lib().zs3_gmmn_mlp_fwd1(P(x), I(width), P(ident), P(st["ridx"]), I(width), I(0), P(wp1.f_pk),
+                                              I(wp1.cin_pad // 32), P(lin1.bias), P(None), I(width), P(h), P(hd), I(hid), I(s),
+                                              I(hid), F(lrelu.negative_slope), F(drop.p if use_drop else 0.0),
+                                              ctypes.c_ulonglong(0), ctypes.c_ulonglong(dseed), P(st["seed_dev"]), stream()),
+                      "zs3_gmmn_mlp_fwd1")
+            check(lib().zs3_gmmn_mlp_fwd2(P(hd), I(hid), P(wp2.f_pk), I(wp2.cin_pad // 32), P(lin2.bias), P(gen_s), I(d), I(s),
+                                          I(d), I(hid), P(st["real"]), I(st["real"].stride(0)), P(st["pix_global"]), P(real_s),
+                                          stream()), "zs3_gmmn_mlp_fwd2")
+        else:
+            if device_noise:   # noise drawn inside the gather (same stream as zs3_uniform on a [S, noise_dim] tensor)
+                x = ops.gather_cat_noise(st["emb"], st["pix_local"], self.embed_dim, self.noise_dim, width, s, st["seed_base"],
+                                         seed_dev=st["seed_dev"], noise_key=st["ridx"])   # z[random_idx]: duplicates share noise
+            else:
+                x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, width)
+            h = _rows_gemm(x, st["wp1"], lin1.bias, Fz.ACT_LEAKY, lrelu.negative_slope)
+            hd = ops.dropout(h, drop.p, dseed, row_idx=st["ridx"], seed_dev=st["seed_dev"]) if use_drop else h
+            gen_s = _rows_gemm(hd, st["wp2"], lin2.bias)
+            real_s = ops.gather_rows(st["real"], st["pix_global"])
         check(lib().zs3_mmd_fwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), self._sig, I(len(self.sigma)), P(gmat), P(tile),
                                 None, stream()), "zs3_mmd_fwd")          # the loss value is finalised by the update epilogue
         dgen = torch.empty_like(gen_s)
         check(lib().zs3_mmd_bwd_ws(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(tile), P(st["one"]), P(dgen), I(d),
                                    stream()), "zs3_mmd_bwd_ws")
         # generator backward on the sampled rows, gradients into static buffers
-        wp1, wp2 = st["wp1"], st["wp2"]
-        ops.conv2d_wgrad(dgen.view(1, 1, s, -1), hd.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1, out=st["dw2"])
-        ops.colsum(dgen, out=st["db2"])
-        dhd = ops.conv2d_dgrad(dgen.view(1, 1, s, -1), wp2, (1, s)).view(s, -1)
-        dpre = ops.dropout_act_bwd(dhd, h, drop.p if use_drop else 0.0, dseed, lrelu.negative_slope, row_idx=st["ridx"],
-                                   seed_dev=st["seed_dev"])
-        ops.conv2d_wgrad(dpre.view(1, 1, s, -1), x.view(1, 1, s, -1), wp1.cout, wp1.cin, 1, 1, out=st["dw1"])
-        ops.colsum(dpre, out=st["db1"])
+        if fused:
+            dpre = torch.empty((s, wp1.cout), dtype=torch.float32, device=dgen.device)
+            check(lib().zs3_gmmn_mlp_dgrad(P(dgen), I(d), P(wp2.t_pk), I(wp2.cout_pad // 32), P(h), I(h.stride(0)), P(st["ridx"]),
+                                           P(dpre), I(wp1.cout), I(s), I(wp2.cin), I(wp2.cout), F(lrelu.negative_slope),
+                                           F(drop.p if use_drop else 0.0), ctypes.c_ulonglong(dseed), P(st["seed_dev"]),
+                                           stream()), "zs3_gmmn_mlp_dgrad")
+            check(lib().zs3_gmmn_mlp_wgrad(P(dgen), I(d), P(hd), I(hd.stride(0)), I(wp2.cout), I(wp2.cin), P(st["dw2"]),
+                                           P(st["db2"]), P(dpre), I(wp1.cout), P(x), I(width), I(wp1.cout), I(wp1.cin),
+                                           P(st["dw1"]), P(st["db1"]), I(s), stream()), "zs3_gmmn_mlp_wgrad")
+        else:
+            ops.conv2d_wgrad(dgen.view(1, 1, s, -1), hd.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1, out=st["dw2"])
+            ops.colsum(dgen, out=st["db2"])
+            dhd = ops.conv2d_dgrad(dgen.view(1, 1, s, -1), wp2, (1, s)).view(s, -1)
+            dpre = ops.dropout_act_bwd(dhd, h, drop.p if use_drop else 0.0, dseed, lrelu.negative_slope, row_idx=st["ridx"],
+                                       seed_dev=st["seed_dev"])
+            ops.conv2d_wgrad(dpre.view(1, 1, s, -1), x.view(1, 1, s, -1), wp1.cout, wp1.cin, 1, 1, out=st["dw1"])
+            ops.colsum(dpre, out=st["db1"])
         opt = self.optimizer_generator
         multi = st.get("adam_multi")
         if multi is not None:
@@ -280,8 +327,39 @@ class GMMNStep:
         """parameters averaged over the ranks once per step in multi-GPU runs"""
         return list(self.generator.parameters())
 
+    # ------------------------------------------------------------------ frozen-backbone feature pass, pipelined
+    def _features(self, image):
+        with torch.no_grad():
+            return ops.nhwc(self.model.forward_before_class_prediction(image))          # [B, fh, fw, D]
+
+    def prefetch(self, image):
+        """Start the feature pass of the NEXT batch on a side stream.  The backbone is frozen in this step (only `pred_conv`
+        and the generator train, train_pascal_GMMN.py:262-264), so the next batch's features do not depend on anything the
+        current batch's generator loop or classifier update writes: the big convolutions of batch t+1 fill the chip while
+        the latency-bound per-(image, class) update chain of batch t runs.  Batches are still visited in loader order, so
+        the BatchNorm running statistics see the same sequence of updates."""
+        require_gpu(image)
+        dev = image.device
+        if self._feat_stream is None:
+            self._feat_stream = torch.cuda.Stream(device=dev)
+        self._feat_stream.wait_stream(torch.cuda.current_stream(dev))    # the image (and the previous feature pass) are ready
+        with torch.cuda.stream(self._feat_stream):
+            real = self._features(image)
+            done = torch.cuda.Event()
+            done.record()
+        self._prefetched = (image, real, done)
+
+    def _take_features(self, image):
+        pf, self._prefetched = self._prefetched, None
+        if pf is not None and pf[0] is image:
+            main = torch.cuda.current_stream(image.device)
+            main.wait_event(pf[2])
+            pf[1].record_stream(main)
+            return pf[1]
+        return self._features(image)
+
     # ------------------------------------------------------------------ one iteration
-    def __call__(self, image, target, embedding=None, table=None):
+    def __call__(self, image, target, embedding=None, table=None, next_image=None):
         """embedding: the reference's `label_emb` [B, embed_dim, H, W] (zs3/dataloaders/datasets/base.py:45-51), or
         table: the [num_classes, embed_dim] class-embedding table itself -- then the per-pixel embedding rows are looked
         up on the device at feature resolution (embed(nearest(label)) == nearest(embed(label)) exactly),
@@ -291,8 +369,9 @@ class GMMNStep:
         require_gpu(image, target, embedding, table)
         model, dev = self.model, image.device
         b = image.shape[0]
-        with torch.no_grad():
-            real = ops.nhwc(model.forward_before_class_prediction(image))          # [B, fh, fw, D]
+        real = self._take_features(image)
+        if next_image is not None:      # the caller already knows the next batch: overlap its feature pass with this loop
+            self.prefetch(next_image)
         fh, fw, d = real.shape[1], real.shape[2], real.shape[3]
         npix = fh * fw
         if self._st is None or self._st["shape"] != (b, npix):
@@ -449,16 +528,25 @@ class GMMNTrainer:
         train_loss = 0.0
         self.model.train()
         num_img_tr = len(self.train_loader)
-        for i, sample in enumerate(self.train_loader):
+        # one batch of lookahead: the next batch's image goes to the device early so that its (frozen-backbone) feature
+        # pass overlaps this batch's generator loop
+        it = iter(self.train_loader)
+        sample, i, staged = next(it, None), 0, None
+        while sample is not None:
+            following = next(it, None)
             if len(sample["image"]) <= 1:
+                sample, i = following, i + 1
                 continue
-            image, target, embedding = sample["image"].cuda(), sample["label"].cuda(), sample["label_emb"].cuda()
+            image = staged if staged is not None else sample["image"].cuda()
+            target, embedding = sample["label"].cuda(), sample["label_emb"].cuda()
+            staged = following["image"].cuda() if (following is not None and len(following["image"]) > 1) else None
             self.scheduler(self.optimizer, i, epoch, self.best_pred)
-            g_loss, c_loss, _ = self.step_fn(image, target, embedding)
+            g_loss, c_loss, _ = self.step_fn(image, target, embedding, next_image=staged)
+            sample, i_done, i = following, i, i + 1
             train_loss += c_loss
             if self.writer is not None:
-                self.writer.add_scalar("train/total_loss_iter", c_loss, i + num_img_tr * epoch)
-                self.writer.add_scalar("train/generator_loss", g_loss, i + num_img_tr * epoch)
+                self.writer.add_scalar("train/total_loss_iter", c_loss, i_done + num_img_tr * epoch)
+                self.writer.add_scalar("train/generator_loss", g_loss, i_done + num_img_tr * epoch)
         if self.writer is not None:
             self.writer.add_scalar("train/total_loss_epoch", train_loss, epoch)
         return train_loss

@@ -66,8 +66,11 @@ class GradSync:
             return None
         from . import functional as Fz
         if Fz.WGRAD_SIDE_STREAM:
-            side = Fz.wgrad_stream(p.device)
+            pool = Fz.wgrad_streams(p.device)
+            side = pool[0]
             side.wait_stream(torch.cuda.current_stream(p.device))   # gradients produced on the main stream (BN, bias)
+            for other in pool[1:]:                                  # ... and on the other streams of the wgrad pool
+                side.wait_stream(other)
             return side
         return None
 
