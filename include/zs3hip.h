@@ -49,6 +49,16 @@ int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scal
                    int ncols, int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec,
                    int tile_cfg, const void* zero_page, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
+/* tile_cfg 31: wave-specialised 256x128 LDS-DMA kernel, one tile per workgroup.  tile_cfg 32: the same kernel as a stream-K
+ * launch -- 256 persistent workgroups share the (tile, K step) iterations evenly (launches whose tile count is not a
+ * multiple of the 256 CUs: the 138-tile layer-3 convolutions); partial tiles travel through a per-stream workspace that
+ * the host registers once: workspace of zs3_conv_streamk_workspace_bytes() bytes (16-byte aligned) and
+ * zs3_conv_streamk_flag_words() ZEROED 32-bit words; launches on one stream are serialised by the stream, different streams
+ * need their own workspace.  attach(stream, NULL, 0, NULL) forgets the stream.  The last flag word is an error latch
+ * (a workgroup gave up waiting for a partial tile): nonzero means the outputs of that launch are invalid. */
+long zs3_conv_streamk_workspace_bytes(void);
+int zs3_conv_streamk_flag_words(void);
+int zs3_conv_streamk_attach(void* stream, void* workspace, long workspace_bytes, void* flags);
 /* zs3_conv_igemm (no affine / activation) with the two backward-pass epilogue fusions of the residual network:
  * (1) bn_partial != NULL: the epilogue also produces the BatchNorm-backward sums of the layer the output gradient belongs
  *     to: bn_partial[mtiles][2][ncols] = (sum dz, sum dz*xhat) per row tile, with dz = stored value * ReLU mask and
@@ -164,6 +174,13 @@ int zs3_gmmn_update_epilogue(const double* tile_ws, int N, float* loss_ring, voi
  * dgrad: dpre = LeakyReLU'(h) * Dropout'(dgen W2) -- backward of fwd2, the dropout and the activation in one launch.
  * wgrad: dw2 = dy2^T x2 ([co2][ci2]), db2 = column sums of dy2, and the same for layer 1, reduction over R <= 128 rows;
  *        one launch for both layers.  All leading dimensions and channel counts: multiples of 4. */
+/* table-driven update (no host argument per replay): row u = upd_dev[0] of `table` ([S sample indices | order offset | pixel
+ * base], int64, row stride ld_table) selects the (image, class); writes x[j] = [emb[base + order[offset + ridx[j]]] | noise
+ * keyed on ridx[j]], pix_global[j] (row of the real features) and key[j] = ridx[j].  Replaces zs3_sample_rows + the
+ * per-update host-to-device copy of the sample indices + zs3_gather_cat_noise. */
+int zs3_gmmn_prep(const long* table, int ld_table, const void* upd_dev, const long* order, const float* emb, int ld_emb,
+                  int Ca, int Cb, float* x, int ldx, long* pix_global, long* key, int S, unsigned long long seed,
+                  const void* seed_dev, void* stream);
 int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, const long* key, int Ca, int Cb, const void* w_pk,
                       int kchunks, const float* bias, float* x_out, int ldx, float* h, float* hd, int ldo, int M, int N,
                       float leak, float p_drop, unsigned long long seed_noise, unsigned long long seed_drop,

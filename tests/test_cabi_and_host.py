@@ -19,7 +19,7 @@ def libpath():
 
 def test_library_exports_every_declared_symbol(libpath):
     header = open(os.path.join(ROOT, "include", "zs3hip.h")).read()
-    declared = set(re.findall(r"^int\s+(zs3_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|long)\s+(zs3_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 30
     lib = ctypes.CDLL(libpath)
     for name in declared:

@@ -20,6 +20,10 @@
 //
 // Replaces: every nn.Conv2d on the reference hot path (resnet.py:16-28,79,125-131; aspp.py:11-19,86,97;
 // decoder.py:12,16,20,26) and nn.Linear of the GMMN (gmmn.py:18,33) as a 1x1 conv.
+#include <map>
+#include <mutex>
+#include <type_traits>
+
 #include "common.h"
 #include "zs3hip.h"
 
@@ -53,6 +57,11 @@ struct ConvArgs {
   // optional ReLU mask applied to `res` before it is added (sign bytes [M][ncols/4]): the skip gradient of a residual
   // block is (block-output gradient) * mask, taken straight from the block-output gradient instead of a stored copy
   const unsigned char* res_mbits;
+  // stream-K launches of the LDS-DMA kernel (tile_cfg 32): partial-tile slabs [grid][128 KB], one arrival flag per block
+  // (+ one error word), the launch's epoch (flags are compared with it, never reset)
+  float* sk_ws;
+  unsigned* sk_flags;
+  unsigned sk_epoch;
 };
 
 // Rows [0, nrows) of an LDS-staged output tile -> global memory as dwordx4 per lane, with the fused epilogue (affine,
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvArgs p) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <int PREC>
+template <int PREC, bool SK>
 __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   constexpr int BM = 256, BN = 128, TM = 2, TN = 4, NST = 3;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -738,296 +747,128 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
   const int ntn = (p.ncols + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = bid / ntn, nt = bid - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int KT = p.KH * p.KW * (p.cin_pad / 32);
+  const int KT_TILE = p.KH * p.KW * (p.cin_pad / 32);   // K steps of a whole output tile
   const int wm = wave & 3;
 #ifdef ZS3_CONV_TIMING
   const long t_kernel0 = __builtin_readcyclecounter();
   long t_loop0 = 0, t_loop1 = 0;
 #endif
-
-  f32x16 acc[TM][TN];
-
-  if (producer) {
-    const int pw = wave - 4;
-    const int lrow = lane >> 3, slot = lane & 7;
-    constexpr int RA = 8, RB = 4;   // 8-row groups of A / B fetched per producer wave and K step
-    // group g of A holds tile rows 8g..8g+7 (g = 8 pw + i); the swizzle of row r is (r>>1)&7 = ((i&1)<<2) | (lane>>4)
-    const int chunk_even = slot ^ (lane >> 4), chunk_odd = slot ^ (4 | (lane >> 4));
-    const float* xrow[RA];
-    int bh[RA], bw[RA];
-    bool rvalid[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int m = m0 + 64 * pw + 8 * i + lrow;
-      rvalid[i] = m < p.M;
-      int mm = rvalid[i] ? m : 0;
-      int hw = p.Ho * p.Wo;
-      int n = mm / hw, rem = mm - n * hw;
-      int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-      xrow[i] = p.x + (size_t)n * p.H * p.W * p.ldx + ((i & 1) ? chunk_odd : chunk_even) * 4;
-      if (p.dgrad) {
-        bh[i] = oh + p.pad_h;
-        bw[i] = ow + p.pad_w;
-      } else {
-        bh[i] = oh * p.stride - p.pad_h;
-        bw[i] = ow * p.stride - p.pad_w;
-      }
-    }
-    const unsigned short* wrow[RB];
-    int wstep[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      int col = n0 + 32 * pw + 8 * j + lrow;
-      bool ok = col < p.ncols;
-      wrow[j] = ok ? p.w_pk + (size_t)col * (2 * p.ldw) + ((j & 1) ? chunk_odd : chunk_even) * 8
-                   : reinterpret_cast<const unsigned short*>(p.zero);
-      wstep[j] = ok ? 1 : 0;
-    }
-    int kh = 0, kw = 0, c0 = 0, kofs = 0;
-    const float* abase[RA];
-    int astep[RA];
-    auto tap_addresses = [&]() {   // per-row gather base of the current filter tap (called when a tap starts)
-      {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          int hi, wi;
-          bool ok = rvalid[i];
-          if (p.dgrad) {
-            const int th = bh[i] - kh * p.dil, tw = bw[i] - kw * p.dil;
-            const int mask = (1 << p.stride_log2) - 1;
-            hi = th >> p.stride_log2;
-            wi = tw >> p.stride_log2;
-            ok = ok && ((th | tw) >= 0) && (((th | tw) & mask) == 0);
-          } else {
-            hi = bh[i] + kh * p.dil;
-            wi = bw[i] + kw * p.dil;
-            ok = ok && ((hi | wi) >= 0);
-          }
-          ok = ok && hi < p.H && wi < p.W;
-          abase[i] = ok ? xrow[i] + (hi * p.W + wi) * p.ldx : p.zero;
-          astep[i] = ok ? 1 : 0;
-        }
-      }
-    };
-    auto advance = [&]() {
-      kofs += 32;
-      c0 += 32;
-      if (c0 == p.cin_pad) {
-        c0 = 0;
-        if (++kw == p.KW) {
-          kw = 0;
-          ++kh;
-        }
-      }
-    };
-    // (A register-staged producer -- global_load_dwordx4 + ds_write_b128 of the same bytes -- was measured against this
-    // LDS-DMA form: 2700 vs 2100 producer cycles per K step; both sit on the ~35 B/clk/CU the L2 delivers.)
-    auto issue_tile = [&](int stage) {
-      if (c0 == 0) tap_addresses();
-      unsigned char* sA = dsm + stage * STAGE_BYTES + pw * (8 * 1024);
-      unsigned char* sB = dsm + stage * STAGE_BYTES + A_BYTES + pw * (4 * 1024);
-#ifdef ZS3_DMA_ZEROSRC   // probe: every lane re-reads the (L1-resident) zero page -> separates issue cost from L2 bandwidth
-      if (true) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i)
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.zero + (lane & 63) * 4), (lds_void_t*)(sA + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < RB; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.zero + (lane & 63) * 4), (lds_void_t*)(sB + j * 1024), 16, 0, 0);
-        advance();
-        return;
-      }
-#endif
-      if (p.cin_valid == p.cin_pad) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i)
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase[i] + c0 * astep[i]), (lds_void_t*)(sA + i * 1024), 16, 0, 0);
-      } else {   // ragged last channel chunk of a tap: lanes past cin_valid fetch the zero page
-        const int rem = p.cin_valid - c0;
-        const bool ok_even = chunk_even * 4 < rem, ok_odd = chunk_odd * 4 < rem;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          const float* src = ((i & 1) ? ok_odd : ok_even) ? abase[i] + c0 * astep[i] : p.zero;
-          __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sA + i * 1024), 16, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j)
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wrow[j] + 2 * kofs * wstep[j]), (lds_void_t*)(sB + j * 1024), 16, 0,
-                                         0);
-      advance();
-    };
-    issue_tile(0);
-    if (KT > 1) {
-      issue_tile(1);
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  // ---- work of this block.  Plain launch: one output tile, all of its K steps.  Stream-K launch (SK): the grid is
+  // 8 x (gridDim/8) persistent blocks; the tiles are cut into 8 contiguous groups, one per XCD (block b runs on XCD b % 8),
+  // and inside a group the (tile, K step) iterations are dealt out evenly to the group's blocks in order.  A block walks
+  // its iteration range segment by segment; a segment that does not reach its tile's last K step is stored as a raw fp32
+  // partial tile ("slab") and published with an agent-scope release + flag; the block that holds the tile's last K steps
+  // owns the tile: it waits for the earlier segments (always blocks with a lower id on the same XCD, i.e. dispatched
+  // before it), adds their slabs in a fixed order and runs the fused epilogue.  That turns 138 tiles on 256 CUs (54 % of
+  // the chip) into 256 equal shares.
+  long it = 0, it_end = 1;
+  int sk_xcd = 0, sk_slot = 0, sk_per = 1, sk_tile0 = 0;
+  long sk_w = 0;
+  if (SK) {
+    const int T = ((p.M + BM - 1) / BM) * ntn;
+    sk_xcd = blockIdx.x & 7;
+    sk_slot = blockIdx.x >> 3;
+    sk_per = gridDim.x >> 3;
+    sk_tile0 = (int)((long)sk_xcd * T / 8);
+    const int tile1 = (int)((long)(sk_xcd + 1) * T / 8);
+    sk_w = (long)(tile1 - sk_tile0) * KT_TILE;
+    it = (long)sk_slot * sk_w / sk_per;
+    it_end = (long)(sk_slot + 1) * sk_w / sk_per;
+  }
+  int tile = 0, kb = 0, KT = 0, mt = 0, nt = 0, m0 = 0, n0 = 0;
+  auto next_segment = [&]() -> bool {   // KT = K steps of the segment, kb = its first K step inside the tile
+    if (it >= it_end) return false;
+    if (SK) {
+      tile = sk_tile0 + (int)(it / KT_TILE);
+      kb = (int)(it - (long)(tile - sk_tile0) * KT_TILE);
+      const long left = it_end - it;
+      KT = (long)(KT_TILE - kb) < left ? KT_TILE - kb : (int)left;
+      it += KT;
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tile = xcd_remap(blockIdx.x, gridDim.x);
+      kb = 0;
+      KT = KT_TILE;
+      it = it_end;
     }
-    __builtin_amdgcn_s_barrier();  // tile 0 has landed
-    int st2 = 2;                   // ring slot of tile kt + 2
-#ifdef ZS3_CONV_TIMING
-    long t_issue = 0, t_wait = 0, t_bar = 0;
-#define ZS3_T(v) { long t_ = __builtin_readcyclecounter(); v += t_ - t_last; t_last = t_; }
-    long t_last = __builtin_readcyclecounter();
-#else
-#define ZS3_T(v)
-#endif
-    for (int kt = 0; kt < KT; ++kt) {
-      if (kt + 2 < KT) {
-        issue_tile(st2);
-        st2 = st2 == NST - 1 ? 0 : st2 + 1;
-        ZS3_T(t_issue)
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // tile kt+1 has landed, tile kt+2 stays in flight
-      } else {
+    mt = tile / ntn;
+    nt = tile - mt * ntn;
+    m0 = mt * BM;
+    n0 = nt * BN;
+    return true;
+  };
+  // ---- end of a segment: stream-K hand-off of a partial tile, or the tile's fused epilogue.  Runs in both wave roles
+  // with the same barrier sequence; only the consumers hold accumulators (`acc` is a dummy for the producers).
+  auto finish_segment = [&](auto role, auto& acc) {
+    constexpr bool IS_PRODUCER = decltype(role)::value;
+  if (SK) {
+    // slab of block b: [wave 0-3][tile (i, j)][quarter q][lane] f32x4 = 128 KB; reader and writer use the same (wave, lane)
+    constexpr int SLAB_F4 = 4 * 8 * 4 * 64;
+    f32x4* slabs = reinterpret_cast<f32x4*>(p.sk_ws);
+    if (kb + KT < KT_TILE) {   // not the tile's last K steps: publish the partial tile, somebody else owns the epilogue
+      if constexpr (!IS_PRODUCER) {
+        f32x4* dst = slabs + (size_t)blockIdx.x * SLAB_F4 + (size_t)wave * (8 * 4 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+              dst[((i * TN + j) * 4 + q) * 64] = v;
+            }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      ZS3_T(t_wait)
-      __builtin_amdgcn_s_barrier();
-      ZS3_T(t_bar)
+      __syncthreads();   // the LDS ring is refilled by the next segment
+      return;
     }
-#ifdef ZS3_CONV_TIMING
-    if (p.act == 99 && blockIdx.x == 0 && lane == 0) {
-      long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + wave * 3;
-      o[0] = t_issue; o[1] = t_wait; o[2] = t_bar;
-    }
-#endif
-  } else {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lr = lane & 31, sw = (lr >> 1) & 7, jh = lane >> 5;
-    int offA0[2], offA1[2], offBh[2], offBl[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int j4 = jh + 2 * kk;              // which 8-wide K group of the 32-chunk this lane's fragment holds
-      offA0[kk] = ((2 * j4) ^ sw) * 16;        // fp32 chunks 2*j4, 2*j4+1
-      offA1[kk] = ((2 * j4 + 1) ^ sw) * 16;
-      offBh[kk] = (j4 ^ sw) * 16;              // bf16 hi chunk j4, lo chunk 4 + j4
-      offBl[kk] = ((4 + j4) ^ sw) * 16;
-    }
-    const int rowA = (wm * 64 + lr) * 128, rowB = A_BYTES + lr * 128;
-    // One K step = 4 sub-steps (kk, i) of 12 MFMAs each (3 bf16 products x 4 column tiles; the three updates of one
-    // accumulator are 4 MFMAs apart).  The slots between the MFMAs of sub-step s carry the LDS reads of the next raw
-    // fp32 fragment / the next B fragments and the hi/lo split for sub-step s+1 (3 VALU per slot), so the conversion
-    // work sits in the shadow of the 32-cycle MFMAs.  The K-step barrier sits before sub-step 3, which works from
-    // registers only and meanwhile prefetches sub-step 0 of the next tile from the next ring slot.  hipcc's own
-    // schedule hoists all LDS reads and conversions to the top and issues the 48 MFMAs as one clump (no overlap),
-    // so every slot is pinned with sched_barrier(0).
-    bf16x8 b_hi[2][TN], b_lo[2][TN];
-    u32x4 uh[2], ul[2];
-    f32x4 r0, r1;
-    float ha = 0.f, hb = 0.f;
-    const unsigned char* Ab;
-    const unsigned char* Bb;
-    auto set_stage = [&](int stage) {
-      Ab = dsm + stage * STAGE_BYTES + rowA;
-      Bb = dsm + stage * STAGE_BYTES + rowB;
-    };
-    auto read_a = [&](int kk, int i) {
-      r0 = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offA0[kk]);
-      r1 = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offA1[kk]);
-    };
-    auto read_b = [&](int kk, int j) {
-      b_hi[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBh[kk]);
-      if (PREC == 3) b_lo[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBl[kk]);
-    };
-    auto split_half = [&](int buf, int hp) {   // hp = 2*q + phase: values 2q, 2q+1 of the 8-wide fragment
-      const int q = hp >> 1;
-      const float a = q == 0 ? r0[0] : q == 1 ? r0[2] : q == 2 ? r1[0] : r1[2];
-      const float b = q == 0 ? r0[1] : q == 1 ? r0[3] : q == 2 ? r1[1] : r1[3];
-      if ((hp & 1) == 0) {
-        const unsigned h = cvt_pk_bf16(a, b);
-        uh[buf][q] = h;
-        ha = __uint_as_float(h << 16);
-        hb = __uint_as_float(h & 0xFFFF0000u);
-      } else {
-        ul[buf][q] = PREC == 3 ? cvt_pk_bf16(a - ha, b - hb) : 0u;
-      }
-    };
-    // sub-step s4 of the tile in the current ring slot; fillers prepare sub-step s4+1 (s4 == 3: sub-step 0 of the
-    // tile in the slot set_stage() was last pointed at)
-    auto substep = [&](int s4) {
-      const int kk = s4 >> 1, i = s4 & 1, buf = s4 & 1;
-      const int nkk = ((s4 + 1) & 3) >> 1, ni = (s4 + 1) & 1;
-      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, uh[buf]);
-      const bf16x8 a_lo = __builtin_bit_cast(bf16x8, ul[buf]);
-      if (PREC == 3) {
-#pragma unroll
-        for (int g = 0; g < 12; ++g) {
-          const int t = g >> 2, j = g & 3;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? a_lo : a_hi, t == 1 ? b_lo[kk][j] : b_hi[kk][j],
-                                                              acc[i][j], 0, 0, 0);
-#ifndef ZS3_DMA_ABLATE
-#define ZS3_DMA_ABLATE 0
-#endif
-          if (!(ZS3_DMA_ABLATE & 2)) {
-            if (g == 0) read_a(nkk, ni);
-            if ((s4 == 0 || s4 == 3) && g >= 1 && g <= 4) read_b(s4 == 0 ? 1 : 0, g - 1);   // B of the next kk
+    if (kb > 0) {   // owner of a tile whose first K steps were done by earlier blocks of this XCD
+      const long tile_start = (long)(tile - sk_tile0) * KT_TILE;
+      for (int ps = sk_slot - 1; ps >= 0; --ps) {
+        const long ps_beg = (long)ps * sk_w / sk_per, ps_end = (long)(ps + 1) * sk_w / sk_per;
+        if (ps_end <= tile_start) break;
+        if (ps_beg == ps_end) continue;   // a block without work publishes nothing
+        const int pb = ps * 8 + sk_xcd;
+        if (tid == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(p.sk_flags + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 24)) {   // ~ seconds: give up instead of hanging the GPU; the host checks this word
+              __hip_atomic_store(p.sk_flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
           }
-          if (!(ZS3_DMA_ABLATE & 1) && g >= 4) split_half(buf ^ 1, g - 4);
-          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-      } else {
+        __syncthreads();
+        if constexpr (!IS_PRODUCER) {
+          const f32x4* src = slabs + (size_t)pb * SLAB_F4 + (size_t)wave * (8 * 4 * 64) + lane;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[kk][j], acc[i][j], 0, 0, 0);
-          if (j == 0) read_a(nkk, ni);
-          if (s4 == 0 || s4 == 3) read_b(s4 == 0 ? 1 : 0, j);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const f32x4 v = src[((i * TN + j) * 4 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+                if (q == 3) __builtin_amdgcn_sched_barrier(0);   // four loads in flight at a time: the accumulators fill the file
+              }
         }
-#pragma unroll
-        for (int hp = 0; hp < 8; ++hp) split_half(buf ^ 1, hp);
-        __builtin_amdgcn_sched_barrier(0);
+        if (ps_beg <= tile_start) break;
       }
-    };
-    __builtin_amdgcn_s_barrier();  // tile 0 has landed
-    asm volatile("" ::: "memory");
-    int st = 0;
-    set_stage(0);
-    read_a(0, 0);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) read_b(0, j);
-#pragma unroll
-    for (int hp = 0; hp < 8; ++hp) split_half(0, hp);
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef ZS3_CONV_TIMING
-    long t_work = 0, t_bar = 0;
-    long t_last = __builtin_readcyclecounter();
-    t_loop0 = t_last;
-#endif
-    for (int kt = 0; kt < KT; ++kt) {
-      substep(0);
-      substep(1);
-      substep(2);
-      st = st == NST - 1 ? 0 : st + 1;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ZS3_T(t_work)
-      __builtin_amdgcn_s_barrier();  // tile kt+1 has landed; nobody reads tile kt from LDS any more
-      asm volatile("" ::: "memory");
-      ZS3_T(t_bar)
-      set_stage(st);
-      substep(3);                    // after the last tile this prefetches stale (unused) data
     }
-#ifdef ZS3_CONV_TIMING
-    t_loop1 = __builtin_readcyclecounter();
-    if (p.act == 99 && blockIdx.x == 0 && lane == 0) {
-      long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + wave * 3;
-      o[0] = t_work; o[1] = 0; o[2] = t_bar;
-    }
-#endif
   }
 
   // ---- epilogue (consumers hold the accumulators; every DMA has landed and been consumed)
   if (p.stat_partial) {
     float* red = reinterpret_cast<float*>(dsm);
-    if (!producer) {
+    if constexpr (!IS_PRODUCER) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         float s = 0.f, q2 = 0.f;
@@ -1077,7 +918,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
-    if (!producer && (wm >> 1) == half) {
+    if constexpr (!IS_PRODUCER) if ((wm >> 1) == half) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1100,25 +941,343 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
     o[2] = t_loop1 - t_loop0;                         // K loop
   }
 #endif
+    __syncthreads();   // the epilogue's LDS tile is dead: the next segment's DMA may refill the ring
+  };
+  if (producer) {
+    int no_acc = 0;
+    while (next_segment()) {
+    const int pw = wave - 4;
+      const int lrow = lane >> 3, slot = lane & 7;
+      constexpr int RA = 8, RB = 4;   // 8-row groups of A / B fetched per producer wave and K step
+      // group g of A holds tile rows 8g..8g+7 (g = 8 pw + i); the swizzle of row r is (r>>1)&7 = ((i&1)<<2) | (lane>>4)
+      const int chunk_even = slot ^ (lane >> 4), chunk_odd = slot ^ (4 | (lane >> 4));
+      const float* xrow[RA];
+      int bh[RA], bw[RA];
+      bool rvalid[RA];
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        int m = m0 + 64 * pw + 8 * i + lrow;
+        rvalid[i] = m < p.M;
+        int mm = rvalid[i] ? m : 0;
+        int hw = p.Ho * p.Wo;
+        int n = mm / hw, rem = mm - n * hw;
+        int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        xrow[i] = p.x + (size_t)n * p.H * p.W * p.ldx + ((i & 1) ? chunk_odd : chunk_even) * 4;
+        if (p.dgrad) {
+          bh[i] = oh + p.pad_h;
+          bw[i] = ow + p.pad_w;
+        } else {
+          bh[i] = oh * p.stride - p.pad_h;
+          bw[i] = ow * p.stride - p.pad_w;
+        }
+      }
+      const unsigned short* wrow[RB];
+      int wstep[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        int col = n0 + 32 * pw + 8 * j + lrow;
+        bool ok = col < p.ncols;
+        wrow[j] = ok ? p.w_pk + (size_t)col * (2 * p.ldw) + ((j & 1) ? chunk_odd : chunk_even) * 8
+                     : reinterpret_cast<const unsigned short*>(p.zero);
+        wstep[j] = ok ? 1 : 0;
+      }
+      int kh = 0, kw = 0, c0 = 0, kofs = 0;
+      if (SK) {   // the segment starts at K step kb of its tile
+        const int cpt = p.cin_pad >> 5, tap = kb / cpt;
+        c0 = (kb - tap * cpt) * 32;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+        kofs = kb * 32;
+      }
+      const float* abase[RA];
+      int astep[RA];
+      auto tap_addresses = [&]() {   // per-row gather base of the current filter tap (called when a tap starts)
+        {
+#pragma unroll
+          for (int i = 0; i < RA; ++i) {
+            int hi, wi;
+            bool ok = rvalid[i];
+            if (p.dgrad) {
+              const int th = bh[i] - kh * p.dil, tw = bw[i] - kw * p.dil;
+              const int mask = (1 << p.stride_log2) - 1;
+              hi = th >> p.stride_log2;
+              wi = tw >> p.stride_log2;
+              ok = ok && ((th | tw) >= 0) && (((th | tw) & mask) == 0);
+            } else {
+              hi = bh[i] + kh * p.dil;
+              wi = bw[i] + kw * p.dil;
+              ok = ok && ((hi | wi) >= 0);
+            }
+            ok = ok && hi < p.H && wi < p.W;
+            abase[i] = ok ? xrow[i] + (hi * p.W + wi) * p.ldx : p.zero;
+            astep[i] = ok ? 1 : 0;
+          }
+        }
+      };
+      auto advance = [&]() {
+        kofs += 32;
+        c0 += 32;
+        if (c0 == p.cin_pad) {
+          c0 = 0;
+          if (++kw == p.KW) {
+            kw = 0;
+            ++kh;
+          }
+        }
+      };
+      // (A register-staged producer -- global_load_dwordx4 + ds_write_b128 of the same bytes -- was measured against this
+      // LDS-DMA form: 2700 vs 2100 producer cycles per K step; both sit on the ~35 B/clk/CU the L2 delivers.)
+      bool fresh = true;   // first tile of the segment: it may start in the middle of a filter tap
+      auto issue_tile = [&](int stage) {
+        if (c0 == 0 || fresh) tap_addresses();
+        fresh = false;
+        unsigned char* sA = dsm + stage * STAGE_BYTES + pw * (8 * 1024);
+        unsigned char* sB = dsm + stage * STAGE_BYTES + A_BYTES + pw * (4 * 1024);
+#ifdef ZS3_DMA_ZEROSRC   // probe: every lane re-reads the (L1-resident) zero page -> separates issue cost from L2 bandwidth
+        if (true) {
+#pragma unroll
+          for (int i = 0; i < RA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.zero + (lane & 63) * 4), (lds_void_t*)(sA + i * 1024), 16, 0, 0);
+#pragma unroll
+          for (int j = 0; j < RB; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(p.zero + (lane & 63) * 4), (lds_void_t*)(sB + j * 1024), 16, 0, 0);
+          advance();
+          return;
+        }
+#endif
+        if (p.cin_valid == p.cin_pad) {
+#pragma unroll
+          for (int i = 0; i < RA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(abase[i] + c0 * astep[i]), (lds_void_t*)(sA + i * 1024), 16, 0, 0);
+        } else {   // ragged last channel chunk of a tap: lanes past cin_valid fetch the zero page
+          const int rem = p.cin_valid - c0;
+          const bool ok_even = chunk_even * 4 < rem, ok_odd = chunk_odd * 4 < rem;
+#pragma unroll
+          for (int i = 0; i < RA; ++i) {
+            const float* src = ((i & 1) ? ok_odd : ok_even) ? abase[i] + c0 * astep[i] : p.zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(sA + i * 1024), 16, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)(wrow[j] + 2 * kofs * wstep[j]), (lds_void_t*)(sB + j * 1024), 16, 0,
+                                           0);
+        advance();
+      };
+      issue_tile(0);
+      if (KT > 1) {
+        issue_tile(1);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // tile 0 has landed
+      int st2 = 2;                   // ring slot of tile kt + 2
+#ifdef ZS3_CONV_TIMING
+      long t_issue = 0, t_wait = 0, t_bar = 0;
+#define ZS3_T(v) { long t_ = __builtin_readcyclecounter(); v += t_ - t_last; t_last = t_; }
+      long t_last = __builtin_readcyclecounter();
+#else
+#define ZS3_T(v)
+#endif
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 2 < KT) {
+          issue_tile(st2);
+          st2 = st2 == NST - 1 ? 0 : st2 + 1;
+          ZS3_T(t_issue)
+          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // tile kt+1 has landed, tile kt+2 stays in flight
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ZS3_T(t_wait)
+        __builtin_amdgcn_s_barrier();
+        ZS3_T(t_bar)
+      }
+#ifdef ZS3_CONV_TIMING
+      if (p.act == 99 && blockIdx.x == 0 && lane == 0) {
+        long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + wave * 3;
+        o[0] = t_issue; o[1] = t_wait; o[2] = t_bar;
+      }
+#endif
+      finish_segment(std::true_type{}, no_acc);
+    }
+  } else {
+    f32x16 acc[TM][TN];
+    while (next_segment()) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      const int lr = lane & 31, sw = (lr >> 1) & 7, jh = lane >> 5;
+      int offA0[2], offA1[2], offBh[2], offBl[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int j4 = jh + 2 * kk;              // which 8-wide K group of the 32-chunk this lane's fragment holds
+        offA0[kk] = ((2 * j4) ^ sw) * 16;        // fp32 chunks 2*j4, 2*j4+1
+        offA1[kk] = ((2 * j4 + 1) ^ sw) * 16;
+        offBh[kk] = (j4 ^ sw) * 16;              // bf16 hi chunk j4, lo chunk 4 + j4
+        offBl[kk] = ((4 + j4) ^ sw) * 16;
+      }
+      const int rowA = (wm * 64 + lr) * 128, rowB = A_BYTES + lr * 128;
+      // One K step = 4 sub-steps (kk, i) of 12 MFMAs each (3 bf16 products x 4 column tiles; the three updates of one
+      // accumulator are 4 MFMAs apart).  The slots between the MFMAs of sub-step s carry the LDS reads of the next raw
+      // fp32 fragment / the next B fragments and the hi/lo split for sub-step s+1 (3 VALU per slot), so the conversion
+      // work sits in the shadow of the 32-cycle MFMAs.  The K-step barrier sits before sub-step 3, which works from
+      // registers only and meanwhile prefetches sub-step 0 of the next tile from the next ring slot.  hipcc's own
+      // schedule hoists all LDS reads and conversions to the top and issues the 48 MFMAs as one clump (no overlap),
+      // so every slot is pinned with sched_barrier(0).
+      bf16x8 b_hi[2][TN], b_lo[2][TN];
+      u32x4 uh[2], ul[2];
+      f32x4 r0, r1;
+      float ha = 0.f, hb = 0.f;
+      const unsigned char* Ab;
+      const unsigned char* Bb;
+      auto set_stage = [&](int stage) {
+        Ab = dsm + stage * STAGE_BYTES + rowA;
+        Bb = dsm + stage * STAGE_BYTES + rowB;
+      };
+      auto read_a = [&](int kk, int i) {
+        r0 = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offA0[kk]);
+        r1 = *reinterpret_cast<const f32x4*>(Ab + i * 4096 + offA1[kk]);
+      };
+      auto read_b = [&](int kk, int j) {
+        b_hi[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBh[kk]);
+        if (PREC == 3) b_lo[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBl[kk]);
+      };
+      auto split_half = [&](int buf, int hp) {   // hp = 2*q + phase: values 2q, 2q+1 of the 8-wide fragment
+        const int q = hp >> 1;
+        const float a = q == 0 ? r0[0] : q == 1 ? r0[2] : q == 2 ? r1[0] : r1[2];
+        const float b = q == 0 ? r0[1] : q == 1 ? r0[3] : q == 2 ? r1[1] : r1[3];
+        if ((hp & 1) == 0) {
+          const unsigned h = cvt_pk_bf16(a, b);
+          uh[buf][q] = h;
+          ha = __uint_as_float(h << 16);
+          hb = __uint_as_float(h & 0xFFFF0000u);
+        } else {
+          ul[buf][q] = PREC == 3 ? cvt_pk_bf16(a - ha, b - hb) : 0u;
+        }
+      };
+      // sub-step s4 of the tile in the current ring slot; fillers prepare sub-step s4+1 (s4 == 3: sub-step 0 of the
+      // tile in the slot set_stage() was last pointed at)
+      auto substep = [&](int s4) {
+        const int kk = s4 >> 1, i = s4 & 1, buf = s4 & 1;
+        const int nkk = ((s4 + 1) & 3) >> 1, ni = (s4 + 1) & 1;
+        const bf16x8 a_hi = __builtin_bit_cast(bf16x8, uh[buf]);
+        const bf16x8 a_lo = __builtin_bit_cast(bf16x8, ul[buf]);
+        if (PREC == 3) {
+#pragma unroll
+          for (int g = 0; g < 12; ++g) {
+            const int t = g >> 2, j = g & 3;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? a_lo : a_hi, t == 1 ? b_lo[kk][j] : b_hi[kk][j],
+                                                                acc[i][j], 0, 0, 0);
+#ifndef ZS3_DMA_ABLATE
+#define ZS3_DMA_ABLATE 0
+#endif
+            if (!(ZS3_DMA_ABLATE & 2)) {
+              if (g == 0) read_a(nkk, ni);
+              if ((s4 == 0 || s4 == 3) && g >= 1 && g <= 4) read_b(s4 == 0 ? 1 : 0, g - 1);   // B of the next kk
+            }
+            if (!(ZS3_DMA_ABLATE & 1) && g >= 4) split_half(buf ^ 1, g - 4);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[kk][j], acc[i][j], 0, 0, 0);
+            if (j == 0) read_a(nkk, ni);
+            if (s4 == 0 || s4 == 3) read_b(s4 == 0 ? 1 : 0, j);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int hp = 0; hp < 8; ++hp) split_half(buf ^ 1, hp);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      __builtin_amdgcn_s_barrier();  // tile 0 has landed
+      asm volatile("" ::: "memory");
+      int st = 0;
+      set_stage(0);
+      read_a(0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_b(0, j);
+#pragma unroll
+      for (int hp = 0; hp < 8; ++hp) split_half(0, hp);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef ZS3_CONV_TIMING
+      long t_work = 0, t_bar = 0;
+      long t_last = __builtin_readcyclecounter();
+      t_loop0 = t_last;
+#endif
+      for (int kt = 0; kt < KT; ++kt) {
+        substep(0);
+        substep(1);
+        substep(2);
+        st = st == NST - 1 ? 0 : st + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ZS3_T(t_work)
+        __builtin_amdgcn_s_barrier();  // tile kt+1 has landed; nobody reads tile kt from LDS any more
+        asm volatile("" ::: "memory");
+        ZS3_T(t_bar)
+        set_stage(st);
+        substep(3);                    // after the last tile this prefetches stale (unused) data
+      }
+#ifdef ZS3_CONV_TIMING
+      t_loop1 = __builtin_readcyclecounter();
+      if (p.act == 99 && blockIdx.x == 0 && lane == 0) {
+        long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + wave * 3;
+        o[0] = t_work; o[1] = 0; o[2] = t_bar;
+      }
+#endif
+        finish_segment(std::false_type{}, acc);
+    }
+  }
 }
 
-template <int PREC>
-int launch_dma_prec(const ConvArgs& a, hipStream_t st) {
+template <int PREC, bool SK>
+int launch_dma_prec(const ConvArgs& a, int grid, hipStream_t st) {
   constexpr int LDS_BYTES = 3 * (256 + 128) * 128;   // 144 KB of the CU's 160 KB
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<PREC>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<PREC, SK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return -4;
     configured = true;
   }
-  int mt = (a.M + 255) / 256, nt = (a.ncols + 127) / 128;
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<PREC>), dim3(mt * nt), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<PREC, SK>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   return ZS3_LAUNCH_CHECK();
 }
 
 int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
-  return prec == 1 ? launch_dma_prec<1>(a, st) : launch_dma_prec<3>(a, st);
+  const int grid = ((a.M + 255) / 256) * ((a.ncols + 127) / 128);
+  return prec == 1 ? launch_dma_prec<1, false>(a, grid, st) : launch_dma_prec<3, false>(a, grid, st);
+}
+
+// ---- stream-K launches: per-stream workspace registered by the host (zs3_conv_streamk_attach)
+struct SkState {
+  float* ws;
+  unsigned* flags;
+  long ws_bytes;
+  unsigned epoch;
+};
+constexpr int SK_GRID = 256;                       // 8 XCDs x 32 persistent blocks, one per CU
+constexpr long SK_SLAB_BYTES = 256L * 128 * 4;     // one fp32 partial tile
+std::mutex sk_mutex;
+std::map<void*, SkState> sk_states;
+
+int launch_dma_sk(ConvArgs a, int prec, hipStream_t st) {
+  {
+    std::lock_guard<std::mutex> lock(sk_mutex);
+    auto itr = sk_states.find((void*)st);
+    if (itr == sk_states.end() || itr->second.ws_bytes < SK_GRID * SK_SLAB_BYTES) return -5;
+    SkState& sk = itr->second;
+    if (++sk.epoch == 0u) sk.epoch = 1u;   // flags are zero-initialised: 0 never is a valid epoch
+    a.sk_ws = sk.ws;
+    a.sk_flags = sk.flags;
+    a.sk_epoch = sk.epoch;
+  }
+  return prec == 1 ? launch_dma_prec<1, true>(a, SK_GRID, st) : launch_dma_prec<3, true>(a, SK_GRID, st);
 }
 
 int launch_ws(const ConvArgs& a, int prec, hipStream_t st) {
@@ -1144,6 +1303,19 @@ int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
 
 }  // namespace
 
+extern "C" long zs3_conv_streamk_workspace_bytes(void) { return SK_GRID * SK_SLAB_BYTES; }
+extern "C" int zs3_conv_streamk_flag_words(void) { return SK_GRID + 1; }
+extern "C" int zs3_conv_streamk_attach(void* stream, void* workspace, long workspace_bytes, void* flags) {
+  std::lock_guard<std::mutex> lock(sk_mutex);
+  if (!workspace || !flags) {
+    sk_states.erase(stream);
+    return 0;
+  }
+  if (workspace_bytes < SK_GRID * SK_SLAB_BYTES || ((uintptr_t)workspace & 15)) return -1;
+  sk_states[stream] = SkState{(float*)workspace, (unsigned*)flags, workspace_bytes, 0u};
+  return 0;
+}
+
 extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
   int bm = 128;
   if (tile_cfg == 0) {
@@ -1152,7 +1324,7 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
     if (blocks < 512) bm = 64;
   } else {
     int t = tile_cfg % 10;
-    bm = (tile_cfg == 21 || tile_cfg == 31) ? 256 : ((t == 3 || t == 4) ? 64 : 128);
+    bm = (tile_cfg == 21 || tile_cfg == 31 || tile_cfg == 32) ? 256 : ((t == 3 || t == 4) ? 64 : 128);
   }
   return (M + bm - 1) / bm;
 }
@@ -1181,6 +1353,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
   a.zero = (const float*)zero_page;
   a.bs_y = bs_y; a.bs_ldy = bs_ldy; a.bs_mean = bs_mean; a.bs_istd = bs_istd; a.bs_msc = bs_msc; a.bs_msh = bs_msh;
   a.bs_mbits = bs_mbits; a.bs_partial = bs_partial; a.res_mbits = res_mbits;
+  a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0u;
   a.stride_log2 = 0;
   while ((1 << a.stride_log2) < stride) ++a.stride_log2;
   if (a.M <= 0 || ncols <= 0) return 0;
@@ -1203,6 +1376,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 14: return launch_cfg<64, 64, 2>(a, prec, st);
     case 21: return launch_ws(a, prec, st);
     case 31: return launch_dma(a, prec, st);
+    case 32: return launch_dma_sk(a, prec, st);
   }
   return -3;
 }

@@ -485,8 +485,8 @@ static int wgrad_cus() {   // CUs one launch is sized for: 256 / (streams of the
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("ZS3_WGRAD_CUS");
-    v = e ? atoi(e) : 256;
-    if (v < 8 || v > 256) v = 256;
+    v = e ? atoi(e) : 128;   // default: two streams in the pool (functional.WGRAD_STREAMS)
+    if (v < 8 || v > 256) v = 128;
   }
   return v;
 }

@@ -314,7 +314,49 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
   }
 }
 
+// ---- first launch of a table-driven update: everything the update needs from its (image, class) is read from a device table
+// row selected by a device-resident counter, so a captured update replays without any host-side argument.
+// table row u = [ridx[0..S) | order offset | pixel base]: sample j is the ridx[j]-th pixel of the class segment that starts at
+// order[order offset]; x[j] = [emb[base + pixel] | U[0,1)^Cb keyed on ridx[j]]; pix_global[j] = base + pixel (row of the real
+// features), key[j] = ridx[j] (dropout key).  One workgroup per sampled row.
+__global__ __launch_bounds__(256) void gmmn_prep_kernel(const long* table, int ld_table, const long* upd, const long* order,
+                                                        const float* emb, int ld_emb, int Ca, int Cb, float* x, int ldx,
+                                                        long* pix_global, long* key, int S, unsigned long long seed,
+                                                        const unsigned long long* seed_dev) {
+  const long* row = table + upd[0] * ld_table;
+  const int j = blockIdx.x;
+  const long r = row[j], base = row[S + 1];
+  const long pixel = order[row[S] + r];
+  if (threadIdx.x == 0) {
+    pix_global[j] = base + pixel;
+    key[j] = r;
+  }
+  if (seed_dev) seed += seed_dev[0];
+  const float* src = emb + (base + pixel) * ld_emb;
+  for (int c = threadIdx.x * 4; c < Ca + Cb; c += 256 * 4) {
+    f4 v;
+    if (c < Ca) {
+      v = *reinterpret_cast<const f4*>(src + c);
+    } else {
+      const unsigned long long b0 = (unsigned long long)(r * Cb + (c - Ca));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = u01(seed, b0 + e);
+    }
+    *reinterpret_cast<f4*>(x + (size_t)j * ldx + c) = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int zs3_gmmn_prep(const long* table, int ld_table, const void* upd_dev, const long* order, const float* emb,
+                             int ld_emb, int Ca, int Cb, float* x, int ldx, long* pix_global, long* key, int S,
+                             unsigned long long seed, const void* seed_dev, void* stream) {
+  if (S <= 0) return 0;
+  if ((Ca & 3) || (Cb & 3) || (ld_emb & 3) || (ldx & 3) || ld_table < S + 2 || !upd_dev) return -1;
+  hipLaunchKernelGGL(gmmn_prep_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, table, ld_table, (const long*)upd_dev, order,
+                     emb, ld_emb, Ca, Cb, x, ldx, pix_global, key, S, seed, (const unsigned long long*)seed_dev);
+  return ZS3_LAUNCH_CHECK();
+}
 
 extern "C" int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, const long* key, int Ca, int Cb,
                                  const void* w_pk, int kchunks, const float* bias, float* x_out, int ldx, float* h,

@@ -27,7 +27,7 @@ _lazy_skip = {}            # data_ptr of a block-output gradient -> (tensor, sig
 # The layers' weight gradients are independent of each other: with WGRAD_STREAMS > 1 they go round-robin over a small pool
 # of side streams, each launch sized (split-K) for its share of the chip (ZS3_WGRAD_CUS, read by zs3_conv_wgrad_plan) --
 # fewer K splits per layer = less split-K slab traffic, the same number of workgroups in flight.
-WGRAD_STREAMS = max(1, int(os.environ.get("ZS3_WGRAD_STREAMS", "1")))
+WGRAD_STREAMS = max(1, int(os.environ.get("ZS3_WGRAD_STREAMS", "2")))   # same-box A/B: 52.85 -> 51.85 ms per step with 2 (3: no further gain)
 _side = {}
 _side_next = {}
 _join_armed = [False]

@@ -30,6 +30,7 @@ noise="cpu" draws z and the sample indices from the CPU default generator exactl
 (:216,:229) -- bit-parity mode for tests; noise="device" draws z with the counter-based device RNG.
 """
 import ctypes
+import os
 
 import torch
 
@@ -81,9 +82,10 @@ class GMMNStep:
         self.use_graph = use_graph and self.fused_adam
         # the update's MLP forward / backward on the latency-shaped kernels of csrc/gmmn.hip (8 launches per update instead
         # of 16); False keeps the general conv kernels (the A/B reference in tests)
-        self.fused_mlp = bool(fused_mlp)
+        self.fused_mlp = bool(fused_mlp) and os.environ.get("ZS3_GMMN_FUSED", "1") != "0"   # env: same-box A/B runs
         self._st = None       # static buffers (allocated at first call)
         self._graph = None
+        self._graphs = {}     # captured update chains by (mode, chain length)
         self._feat_stream = None   # side stream of the pipelined feature pass (prefetch)
         self._prefetched = None    # (image, features, ready event) of the next batch
         self.last_updates = 0
@@ -108,7 +110,7 @@ class GMMNStep:
         i64 = dict(dtype=torch.int64, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
         st = {
-            "emb": torch.zeros((npix, e), **f32), "real": torch.zeros((b * npix, d), **f32),
+            "emb": torch.zeros((npix, e), **f32), "real": torch.zeros((b * npix, d), **f32), "emb_all": None, "upd_host": None,
             "pix_local": torch.zeros(s, **i64), "pix_global": torch.zeros(s, **i64), "ridx": torch.zeros(s, **i64),
             "z": torch.zeros((s, nz), **f32), "loss": torch.zeros(1, **f32), "one": torch.ones(1, **f32),
             "seed_dev": torch.zeros(1, **i64), "step_dev": torch.zeros(1, **i64),
@@ -176,7 +178,20 @@ class GMMNStep:
             hd = torch.empty((s, hid), dtype=torch.float32, device=dev)
             gen_s = torch.empty((s, d), dtype=torch.float32, device=dev)
             real_s = torch.empty((s, d), dtype=torch.float32, device=dev)
-            if device_noise:     # rows gathered and noise drawn inside the first GEMM's operand load
+            if device_noise and st.get("table_mode"):
+                # table-driven: the update's (image, class) and sample indices come from row slot_dev[0] of the step's
+                # device table (no host argument, nothing to copy per update); x is assembled once, the GEMM reads it plain
+                check(lib().zs3_gmmn_prep(P(st["upd_table"]), I(st["upd_table"].stride(0)), P(st["slot_dev"]), P(st["order_flat"]),
+                                          P(st["emb_all"]), I(st["emb_all"].stride(0)), I(self.embed_dim), I(self.noise_dim), P(x),
+                                          I(width), P(st["pix_global"]), P(st["ridx"]), I(s), ctypes.c_ulonglong(st["seed_base"]),
+                                          P(st["seed_dev"]), stream()), "zs3_gmmn_prep")
+                ident = st.setdefault("ident", torch.arange(s, dtype=torch.int64, device=dev))
+                check(lib().zs3_gmmn_mlp_fwd1(P(x), I(width), P(ident), P(st["ridx"]), I(width), I(0), P(wp1.f_pk),
+                                              I(wp1.cin_pad // 32), P(lin1.bias), P(None), I(width), P(h), P(hd), I(hid), I(s),
+                                              I(hid), F(lrelu.negative_slope), F(drop.p if use_drop else 0.0),
+                                              ctypes.c_ulonglong(0), ctypes.c_ulonglong(dseed), P(st["seed_dev"]), stream()),
+                      "zs3_gmmn_mlp_fwd1")
+            elif device_noise:   # rows gathered and noise drawn inside the first GEMM's operand load
                 check(lib().zs3_gmmn_mlp_fwd1(P(st["emb"]), I(st["emb"].stride(0)), P(st["pix_local"]), P(st["ridx"]),
                                               I(self.embed_dim), I(self.noise_dim), P(wp1.f_pk), I(wp1.cin_pad // 32),
                                               P(lin1.bias), P(x), I(width), P(h), P(hd), I(hid), I(s), I(hid),
@@ -258,24 +273,34 @@ class GMMNStep:
                                              I(st["loss_ring"].numel()), P(st["step_dev"]), P(st["seed_dev"]),
                                              ctypes.c_long(1 << 24), stream()), "zs3_gmmn_update_epilogue")
 
-    def _run_sampled_update(self, training):
+    def _run_sampled_update(self, training, count=1):
+        """`count` consecutive updates.  Table mode: every update reads its own row of the step's device table, so captured
+        chains of 8 / 4 / 2 / 1 updates are replayed back to back with no host work in between; otherwise one update."""
         if not self.use_graph:
-            self._sampled_update(training)
+            for _ in range(count):
+                self._sampled_update(training)
         else:
-            key = (training, self.noise, self.context_aware)
-            if self._graph is None or self._graph[0] != key:
-                g = torch.cuda.CUDAGraph()
-                torch.cuda.synchronize()
-                with torch.cuda.graph(g):
-                    self._sampled_update(training)
-                self._graph = (key, g)
-            self._graph[1].replay()
+            table_mode = bool(self._st.get("table_mode"))
+            left = count
+            for size in ((8, 4, 2, 1) if table_mode else (1,)):
+                while left >= size:
+                    key = (training, self.noise, self.context_aware, table_mode, size)
+                    g = self._graphs.get(key)
+                    if g is None:
+                        g = torch.cuda.CUDAGraph()
+                        torch.cuda.synchronize()
+                        with torch.cuda.graph(g):
+                            for _ in range(size):
+                                self._sampled_update(training)
+                        self._graphs[key] = g
+                    g.replay()
+                    left -= size
         # host-side mirror of the step count (state_dict compatibility with torch.optim.Adam)
         opt = self.optimizer_generator
         for group in opt.param_groups:
             for p in group["params"]:
                 if p in opt.state and "step" in opt.state[p]:
-                    opt.state[p]["step"] += 1
+                    opt.state[p]["step"] += count
         Fz.invalidate_planes(*[p for g_ in opt.param_groups for p in g_["params"]])
 
     # ------------------------------------------------------------------ eager generator pieces (fallback + unseen images)
@@ -377,6 +402,7 @@ class GMMNStep:
         if self._st is None or self._st["shape"] != (b, npix):
             self._alloc(dev, b, npix)
             self._graph = None
+            self._graphs = {}
         st = self._st
         self._resplit()   # the generator may have been changed from outside (load_state_dict, another optimizer)
         real_rows = real.reshape(b, npix, d)
@@ -398,6 +424,45 @@ class GMMNStep:
         mmd_slots, slot = [], 0
         ring_slots, n_ring = [], 0
         st["slot_dev"].zero_()
+        # table mode (device noise, fused kernels): all sample indices of the step are drawn up front in the reference's
+        # order (torch.randint per (image, class), train_pascal_GMMN.py:229) and shipped in ONE copy together with each
+        # update's class segment; the captured update reads its row by a device counter (zs3_gmmn_prep)
+        table_mode = bool(self.noise == "device" and not self.context_aware and self.fused_mlp and self.fused_adam and
+                          self.use_graph and self.real_seen_features and self.bsg <= 128)
+        st["table_mode"] = table_mode
+        if table_mode:
+            rows = []
+            for i in range(b):
+                cls_i = [c for c in range(256) if hist_h[i][c] > 0]
+                if any(c in self.unseen for c in cls_i):
+                    continue
+                off = 0
+                for c in cls_i:
+                    n_c = int(hist_h[i][c])
+                    if c != 255 and c in self.seen:
+                        rows.append((i * npix + off, i * npix, n_c))
+                    off += n_c
+            need = max(len(rows), 1)
+            if st.get("upd_host") is None or st["upd_host"].shape[0] < need:
+                cap = max(need, 256)          # static addresses: the captured updates hold these pointers
+                st["upd_host"] = torch.zeros((cap, self.bsg + 2), dtype=torch.int64).pin_memory()
+                st["upd_table"] = torch.zeros((cap, self.bsg + 2), dtype=torch.int64, device=dev)
+                self._graphs = {}
+            host = st["upd_host"]
+            if rows:    # with replacement, uniform on [0, n_c): floor(U * n_c) with U from the CPU generator, one call per step
+                meta = torch.tensor(rows, dtype=torch.int64)
+                n_c = meta[:, 2:3].double()
+                host[:len(rows), :self.bsg] = torch.minimum((torch.rand((len(rows), self.bsg), dtype=torch.float64) * n_c).long(),
+                                                            meta[:, 2:3] - 1)
+                host[:len(rows), self.bsg:] = meta[:, :2]
+            st["upd_table"][:need].copy_(host[:need], non_blocking=True)
+            if st.get("emb_all") is None:
+                st["emb_all"] = torch.empty((b * npix, self.embed_dim), dtype=torch.float32, device=dev)
+                st["order_flat"] = torch.empty(b * npix, dtype=torch.int64, device=dev)
+            st["order_flat"].copy_(order.reshape(-1))
+            if table is not None:     # one lookup for the whole batch (label 255 -> class 0 like base.py:47-48)
+                check(lib().zs3_gather_rows(P(table_f), I(self.embed_dim), P(tgt_cls), P(st["emb_all"]), I(self.embed_dim),
+                                            ctypes.c_long(b * npix), I(self.embed_dim), stream()), "zs3_gather_rows")
         # pinned staging ring of the sample indices: one row per update of THIS step (the host syncs once, at the end of the
         # step, so a row must not be reused before that); every copy of the previous step completed at its read-back
         if n_mmd > st["ring"].shape[0]:
@@ -407,13 +472,16 @@ class GMMNStep:
             classes = [c for c in range(256) if hist_h[i][c] > 0]
             has_unseen = any(c in self.unseen for c in classes)
             use_real = self.real_seen_features and not has_unseen
+            if table_mode:     # this image's rows of the batch-wide embedding buffer
+                st["emb"] = st["emb_all"][i * npix:(i + 1) * npix]
             if embedding is not None:
                 check(lib().zs3_nearest_rows(P(embedding[i].contiguous()), I(self.embed_dim), I(embedding.shape[2]),
                                              I(embedding.shape[3]), I(fh), I(fw), P(st["emb"]), I(self.embed_dim), stream()),
                       "zs3_nearest_rows")
-            else:  # label 255 -> class 0 like the dataloader (base.py:47-48); those rows are never used
+            elif not table_mode:  # label 255 -> class 0 like the dataloader (base.py:47-48); those rows are never used
                 check(lib().zs3_gather_rows(P(table_f), I(self.embed_dim), P(tgt_cls[i]), P(st["emb"]), I(self.embed_dim),
                                             ctypes.c_long(npix), I(self.embed_dim), stream()), "zs3_gather_rows")
+            pending = 0        # table mode: sampled updates of this image, replayed together after its class loop
             if use_real:
                 fake_rows[i].copy_(real_rows[i])
             else:
@@ -433,6 +501,13 @@ class GMMNStep:
                 do_mmd = c in self.seen and not has_unseen
                 sampled_only = do_mmd and use_real and self.fused_adam
                 z_cpu = torch.rand((n_c, self.noise_dim)) if (self.noise == "cpu" and ctx is None) else None
+                if sampled_only and table_mode:      # indices already drawn into the step's table
+                    pending += 1
+                    ring_slots.append((slot, n_ring))
+                    n_ring += 1
+                    mmd_slots.append((slot, len(classes)))
+                    slot += 1
+                    continue
                 ridx_cpu = torch.randint(low=0, high=n_c, size=(self.bsg,)) if do_mmd else None
                 if sampled_only:
                     ring = st["ring"][st["ring_pos"]]
@@ -475,6 +550,8 @@ class GMMNStep:
                     slot += 1
                 if not use_real:
                     ops.scatter_rows(fake_c, idx_c, fake_rows[i])
+            if pending:
+                self._run_sampled_update(training, pending)
             self._after_image(i, tgt_l[i].view(fh, fw), real_rows[i], has_unseen)
         pg = None if self.group is True else self.group
         if self.group is not None:   # generator replicas -> their average (parameters only; Adam moments stay per rank)

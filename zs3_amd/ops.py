@@ -5,6 +5,7 @@ pixel stride (`ld`) may exceed C (channel-slice views of a wider buffer).  Logic
 channels_last strides are the same memory: `nhwc(t)` / `nchw(t)` convert without copying.
 """
 import ctypes
+import os
 from dataclasses import dataclass
 
 import torch
@@ -14,6 +15,33 @@ from ._lib import F, I, P, check, lib, require_gpu, stream
 PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs
 PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event, tile_cfg) per conv launch
 PROFILE_CFGS = None   # optional set of tile_cfg values to restrict the recording to (event pairs serialise kernel boundaries)
+
+
+_streamk = {}
+
+
+def streamk_ready(device):
+    """Register (once per device and HIP stream) the workspace stream-K launches of the LDS-DMA kernel exchange partial
+    tiles through (zs3_conv_streamk_attach): 32 MB of slabs + one zeroed flag word per persistent workgroup."""
+    st = torch.cuda.current_stream(device)
+    key = (device.index, st.cuda_stream)
+    if key not in _streamk:
+        lib().zs3_conv_streamk_workspace_bytes.restype = ctypes.c_long
+        nbytes = lib().zs3_conv_streamk_workspace_bytes()
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        flags = torch.zeros(lib().zs3_conv_streamk_flag_words(), dtype=torch.int32, device=device)   # zeroed on this stream
+        check(lib().zs3_conv_streamk_attach(ctypes.c_void_p(st.cuda_stream), P(ws), ctypes.c_long(nbytes), P(flags)),
+              "zs3_conv_streamk_attach")
+        _streamk[key] = (ws, flags, st)
+    return _streamk[key]
+
+
+def streamk_errors():
+    """Sum of the stream-K error latches (a workgroup gave up waiting for a partial tile): must be 0."""
+    return int(sum(int(f[-1].item()) for _, f, _ in _streamk.values()))
+
+
+STREAMK = os.environ.get("ZS3_STREAMK", "1") != "0"   # env: same-box A/B runs
 
 
 def pick_tile(m, ncols, k=0):
@@ -29,6 +57,12 @@ def pick_tile(m, ncols, k=0):
     if ncols <= 64:
         return 14
     if m >= 8192 and k >= 512 and ncols >= 256:
+        # stream-K (tile_cfg 32) when whole 256x128 tiles leave > 12 % of the chip idle in the last round (138 tiles of the
+        # layer-3 convolutions: 54 % of 256 CUs; 276 tiles of layer 4: two rounds for 1.08) and there is enough K to share
+        tiles = ((m + 255) // 256) * ((ncols + 127) // 128)
+        rounds = (tiles + 255) // 256
+        if STREAMK and tiles <= 2048 and tiles / (rounds * 256.0) < 0.88 and tiles * (k // 32) >= 2048:
+            return 32
         return 31
     if ncols >= 256 and 128 <= k <= 256:
         return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
@@ -129,6 +163,11 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     m = n * ho * wo
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
+    if tile_cfg == 32:
+        if torch.cuda.is_current_stream_capturing():
+            tile_cfg = 31      # the workspace registration allocates: not inside a graph capture
+        else:
+            streamk_ready(x.device)
     stat = None
     if want_stats or bn_bwd is not None:
         mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
@@ -157,7 +196,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
               "zs3_conv_igemm")
     if prof:
         e1.record()
-        PROFILE.append(("conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
+        PROFILE.append(("conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
 
