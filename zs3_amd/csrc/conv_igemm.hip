@@ -67,10 +67,20 @@ struct ConvArgs {
 // Rows [0, nrows) of an LDS-staged output tile -> global memory as dwordx4 per lane, with the fused epilogue (affine,
 // residual, activation, accumulate).  `c4`/`r0` = this thread's column quad / first row, RPP = rows per pass.  When
 // p.bs_partial is set the thread also accumulates the BN-backward sums of its 4 columns over the rows it stores.
+// Stream-K owner: `sk` lists the partial tiles of the other workgroups that worked on this tile (raw fp32, row-major
+// [256][128] slabs); their rows are added to the staged rows before the fused epilogue, and the BatchNorm forward sums
+// (sum, sum of squares of the completed raw values) are accumulated here instead of from the accumulator registers.
+struct SkParts {
+  const float* part[4];
+  int n;          // number of partial tiles (0: none)
+  int row0;       // first tile row of the staged rows (0 or 128)
+  bool stats;     // accumulate fs_s / fs_q
+};
 template <int RPP>
 __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* ctile, int ldc, int row_base, int nrows,
                                                 int col, int c4, int r0, f32x4 sc, f32x4 sh, bool affine, bool vec,
-                                                f32x4& bs_s, f32x4& bs_q) {
+                                                f32x4& bs_s, f32x4& bs_q, const SkParts* sk = nullptr,
+                                                f32x4* fs_s = nullptr, f32x4* fs_q = nullptr) {
   f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
   const bool bstat = p.bs_partial != nullptr && vec && col < p.ncols;
   if (bstat) {
@@ -85,6 +95,15 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
     const int row = row_base + rr;
     if (row >= p.M || col >= p.ncols) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
+    if (sk) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)   // static indices: the pointers stay in registers
+        if (k < sk->n) v += *reinterpret_cast<const f32x4*>(sk->part[k] + (size_t)(sk->row0 + rr) * 128 + c4 * 4);
+      if (sk->stats) {
+        *fs_s += v;
+        *fs_q += v * v;
+      }
+    }
     if (affine) v = v * sc + sh;
     float* dst = p.y + (size_t)row * p.ldy + col;
     if (vec) {
@@ -140,7 +159,8 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
 // Thread (r0, c4) holds the sums of columns 4*c4..4*c4+3 over its rows; `red` needs 2 * RPP * BN floats of LDS.
 template <int BN, int RPP, int NT>
 __device__ __forceinline__ void finish_bwd_stats(const ConvArgs& p, float* red, int tid, int c4, int r0, int mt, int n0,
-                                                 f32x4 bs_s, f32x4 bs_q) {
+                                                 f32x4 bs_s, f32x4 bs_q, float* dst = nullptr) {
+  if (!dst) dst = p.bs_partial;
   __syncthreads();   // the output tile in LDS is no longer read
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -156,8 +176,8 @@ __device__ __forceinline__ void finish_bwd_stats(const ConvArgs& p, float* red, 
         ts += red[g * BN + c];
         tq += red[(RPP + g) * BN + c];
       }
-      p.bs_partial[((size_t)mt * 2 + 0) * p.ncols + col] = ts;
-      p.bs_partial[((size_t)mt * 2 + 1) * p.ncols + col] = tq;
+      dst[((size_t)mt * 2 + 0) * p.ncols + col] = ts;
+      dst[((size_t)mt * 2 + 1) * p.ncols + col] = tq;
     }
   }
 }
@@ -744,6 +764,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
   const int tid = threadIdx.x, lane = tid & 63;
+  const int tid_outer = tid, lane_outer = lane;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
   const int ntn = (p.ncols + BN - 1) / BN;
@@ -761,6 +782,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   // owns the tile: it waits for the earlier segments (always blocks with a lower id on the same XCD, i.e. dispatched
   // before it), adds their slabs in a fixed order and runs the fused epilogue.  That turns 138 tiles on 256 CUs (54 % of
   // the chip) into 256 equal shares.
+  constexpr int SK_SEGS = SK ? 2 : 1;
   long it = 0, it_end = 1;
   int sk_xcd = 0, sk_slot = 0, sk_per = 1, sk_tile0 = 0;
   long sk_w = 0;
@@ -800,22 +822,45 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   // with the same barrier sequence; only the consumers hold accumulators (`acc` is a dummy for the producers).
   auto finish_segment = [&](auto role, auto& acc) {
     constexpr bool IS_PRODUCER = decltype(role)::value;
+    // the thread index is re-read through an opaque asm: everything the epilogue derives from it (column offsets, scale /
+    // shift vectors, store addresses) would otherwise be hoisted out of the stream-K segment loop and kept alive across the
+    // K loop, where the accumulators already fill the register file (-> scratch spills, and a kernel with scratch pays a
+    // ~1 ms dispatch penalty on this runtime)
+    int tid = tid_outer, lane = lane_outer;
+    asm volatile("" : "+v"(tid), "+v"(lane));
+  constexpr int LDC = BN + 4;
+  static_assert((BM / 2) * LDC * 4 <= NST * STAGE_BYTES, "half output tile must fit in the operand LDS");
+  float* ctile = reinterpret_cast<float*>(dsm);
+  SkParts parts;
+  parts.n = 0;
+  parts.stats = false;
   if (SK) {
-    // slab of block b: [wave 0-3][tile (i, j)][quarter q][lane] f32x4 = 128 KB; reader and writer use the same (wave, lane)
-    constexpr int SLAB_F4 = 4 * 8 * 4 * 64;
-    f32x4* slabs = reinterpret_cast<f32x4*>(p.sk_ws);
+    // a partial tile travels as a raw fp32 row-major [256][128] slab (128 KB per block), written and read through the same
+    // LDS staging as the epilogue: coalesced 512-byte rows by all eight waves, nothing but the accumulators in registers
+    float* slabs = p.sk_ws;
+    constexpr size_t SLAB = (size_t)BM * BN;
     if (kb + KT < KT_TILE) {   // not the tile's last K steps: publish the partial tile, somebody else owns the epilogue
-      if constexpr (!IS_PRODUCER) {
-        f32x4* dst = slabs + (size_t)blockIdx.x * SLAB_F4 + (size_t)wave * (8 * 4 * 64) + lane;
+      float* dst = slabs + (size_t)blockIdx.x * SLAB;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if constexpr (!IS_PRODUCER) if ((wm >> 1) == half) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-              dst[((i * TN + j) * 4 + q) * 64] = v;
-            }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = (wm & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ctile[row * LDC + j * 32 + (lane & 31)] = acc[i][j][r];
+              }
+        }
+        __syncthreads();
+        for (int e = tid; e < (BM / 2) * (BN / 4); e += 512) {
+          const int rr = e / (BN / 4), c4q = e - rr * (BN / 4);
+          *reinterpret_cast<f32x4*>(dst + (size_t)(half * (BM / 2) + rr) * BN + c4q * 4) =
+              *reinterpret_cast<const f32x4*>(ctile + rr * LDC + c4q * 4);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
       __syncthreads();
@@ -827,46 +872,39 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       __syncthreads();   // the LDS ring is refilled by the next segment
       return;
     }
-    if (kb > 0) {   // owner of a tile whose first K steps were done by earlier blocks of this XCD
+    parts.stats = p.stat_partial != nullptr;
+    if (kb > 0) {   // owner of a tile whose first K steps were done by earlier blocks of this XCD (at most 4: tiles >= 64)
+      // the earlier K steps of this tile belong to the slots right below this one (no block of a stream-K launch is
+      // without work: the host requires >= 8 iterations per block), at most 4 of them (tiles >= 64)
       const long tile_start = (long)(tile - sk_tile0) * KT_TILE;
-      for (int ps = sk_slot - 1; ps >= 0; --ps) {
+      bool more = true;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ps = sk_slot - 1 - c;
         const long ps_beg = (long)ps * sk_w / sk_per, ps_end = (long)(ps + 1) * sk_w / sk_per;
-        if (ps_end <= tile_start) break;
-        if (ps_beg == ps_end) continue;   // a block without work publishes nothing
+        const bool use = more && ps >= 0 && ps_end > tile_start;
         const int pb = ps * 8 + sk_xcd;
-        if (tid == 0) {
+        if (use && tid == 0) {
           unsigned spins = 0;
           while (__hip_atomic_load(p.sk_flags + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 24)) {   // ~ seconds: give up instead of hanging the GPU; the host checks this word
+            if (++spins > (1u << 22)) {   // ~ a second: give up instead of hanging the GPU; the host checks this word
               __hip_atomic_store(p.sk_flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               break;
             }
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        __syncthreads();
-        if constexpr (!IS_PRODUCER) {
-          const f32x4* src = slabs + (size_t)pb * SLAB_F4 + (size_t)wave * (8 * 4 * 64) + lane;
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const f32x4 v = src[((i * TN + j) * 4 + q) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
-                if (q == 3) __builtin_amdgcn_sched_barrier(0);   // four loads in flight at a time: the accumulators fill the file
-              }
-        }
-        if (ps_beg <= tile_start) break;
+        parts.part[c] = slabs + (size_t)(use ? pb : 0) * SLAB;
+        if (use) parts.n = c + 1;
+        if (!use || ps_beg <= tile_start) more = false;
       }
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one acquire after the last flag matched
+      __syncthreads();
     }
   }
 
   // ---- epilogue (consumers hold the accumulators; every DMA has landed and been consumed)
-  if (p.stat_partial) {
+  if (!SK && p.stat_partial) {
     float* red = reinterpret_cast<float*>(dsm);
     if constexpr (!IS_PRODUCER) {
 #pragma unroll
@@ -899,9 +937,6 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       }
     }
   }
-  constexpr int LDC = BN + 4;
-  static_assert((BM / 2) * LDC * 4 <= NST * STAGE_BYTES, "half output tile must fit in the operand LDS");
-  float* ctile = reinterpret_cast<float*>(dsm);
   const bool affine = (p.scale != nullptr) || (p.shift != nullptr);
   constexpr int C4 = BN / 4, RPP = 512 / C4;
   const int c4 = tid % C4, r0 = tid / C4;
@@ -915,6 +950,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       if (p.shift) sh[e] = p.shift[col + e];
     }
   f32x4 bs_s = {0.f, 0.f, 0.f, 0.f}, bs_q = {0.f, 0.f, 0.f, 0.f};
+  f32x4 fs_s = {0.f, 0.f, 0.f, 0.f}, fs_q = {0.f, 0.f, 0.f, 0.f};   // stream-K: BatchNorm forward sums of the completed tile
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -930,9 +966,18 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
           }
     }
     __syncthreads();
-    store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
+    if (SK) {
+      parts.row0 = half * (BM / 2);
+      store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q, &parts,
+                           &fs_s, &fs_q);
+    } else {
+      store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
+    }
   }
   if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
+  if (SK && p.stat_partial) {   // same fixed-order block reduction as the BN-backward sums, into the forward partials
+    finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, fs_s, fs_q, p.stat_partial);
+  }
 #ifdef ZS3_CONV_TIMING
   if (p.act == 99 && blockIdx.x == 0 && tid == 0) {
     long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + 24;
@@ -945,9 +990,16 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   };
   if (producer) {
     int no_acc = 0;
-    while (next_segment()) {
+    // at most SK_SEGS segments per block (stream-K launches have no more tiles than blocks: a block's share of the
+    // iterations spans at most two tiles); fully unrolled -- as a real loop the compiler keeps enough per-thread state
+    // alive across the K loop to spill to scratch, and a kernel with scratch pays ~1 ms per dispatch on this runtime
+#pragma unroll
+    for (int seg = 0; seg < SK_SEGS; ++seg) {
+      if (!next_segment()) break;
     const int pw = wave - 4;
-      const int lrow = lane >> 3, slot = lane & 7;
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      const int lrow = lane_s >> 3, slot = lane_s & 7;
       constexpr int RA = 8, RB = 4;   // 8-row groups of A / B fetched per producer wave and K step
       // group g of A holds tile rows 8g..8g+7 (g = 8 pw + i); the swizzle of row r is (r>>1)&7 = ((i&1)<<2) | (lane>>4)
       const int chunk_even = slot ^ (lane >> 4), chunk_odd = slot ^ (4 | (lane >> 4));
@@ -1103,14 +1155,21 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
     }
   } else {
     f32x16 acc[TM][TN];
-    while (next_segment()) {
+    // at most SK_SEGS segments per block (stream-K launches have no more tiles than blocks: a block's share of the
+    // iterations spans at most two tiles); fully unrolled -- as a real loop the compiler keeps enough per-thread state
+    // alive across the K loop to spill to scratch, and a kernel with scratch pays ~1 ms per dispatch on this runtime
+#pragma unroll
+    for (int seg = 0; seg < SK_SEGS; ++seg) {
+      if (!next_segment()) break;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      const int lr = lane & 31, sw = (lr >> 1) & 7, jh = lane >> 5;
+      int lane_s = lane;   // re-read per segment (see finish_segment): keeps the swizzled fragment offsets out of the
+      asm volatile("" : "+v"(lane_s));   // set of values that live across the whole segment loop
+      const int lr = lane_s & 31, sw = (lr >> 1) & 7, jh = lane_s >> 5;
       int offA0[2], offA1[2], offBh[2], offBl[2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -1271,6 +1330,12 @@ int launch_dma_sk(ConvArgs a, int prec, hipStream_t st) {
     std::lock_guard<std::mutex> lock(sk_mutex);
     auto itr = sk_states.find((void*)st);
     if (itr == sk_states.end() || itr->second.ws_bytes < SK_GRID * SK_SLAB_BYTES) return -5;
+    {
+      const long tiles = (long)((a.M + 255) / 256) * ((a.ncols + 127) / 128);
+      const long kt = (long)a.KH * a.KW * (a.cin_pad / 32);
+      // a block's share spans at most two tiles, a tile at most five blocks, every block has work
+      if (tiles > SK_GRID || tiles < 64 || tiles * kt < 8L * SK_GRID) return -7;
+    }
     SkState& sk = itr->second;
     if (++sk.epoch == 0u) sk.epoch = 1u;   // flags are zero-initialised: 0 never is a valid epoch
     a.sk_ws = sk.ws;

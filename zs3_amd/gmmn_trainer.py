@@ -117,7 +117,7 @@ class GMMNStep:
             "loss_ring": torch.zeros(4096, **f32), "slot_dev": torch.zeros(1, **i64),
             "wp1": ops.prep_weight(lin1.weight, need_t=True), "wp2": ops.prep_weight(lin2.weight, need_t=True),
             "ring": torch.zeros((512, s), dtype=torch.int64).pin_memory(), "ring_pos": 0,
-            "seed_base": Fz.next_seed(), "shape": (b, npix),
+            "seed_base": Fz.next_seed(), "shape": (b, npix), "ident": torch.arange(s, **i64),
         }
         self._st = st
         for name, prm in (("dw1", lin1.weight), ("db1", lin1.bias), ("dw2", lin2.weight), ("db2", lin2.bias)):
@@ -185,7 +185,7 @@ class GMMNStep:
                                           P(st["emb_all"]), I(st["emb_all"].stride(0)), I(self.embed_dim), I(self.noise_dim), P(x),
                                           I(width), P(st["pix_global"]), P(st["ridx"]), I(s), ctypes.c_ulonglong(st["seed_base"]),
                                           P(st["seed_dev"]), stream()), "zs3_gmmn_prep")
-                ident = st.setdefault("ident", torch.arange(s, dtype=torch.int64, device=dev))
+                ident = st["ident"]
                 check(lib().zs3_gmmn_mlp_fwd1(P(x), I(width), P(ident), P(st["ridx"]), I(width), I(0), P(wp1.f_pk),
                                               I(wp1.cin_pad // 32), P(lin1.bias), P(None), I(width), P(h), P(hd), I(hid), I(s),
                                               I(hid), F(lrelu.negative_slope), F(drop.p if use_drop else 0.0),
@@ -200,7 +200,7 @@ class GMMNStep:
                                               stream()), "zs3_gmmn_mlp_fwd1")
             else:                # noise from the host (reference RNG stream) / context vector: z sits in st["z"]
                 x = ops.gather_cat(st["emb"], st["pix_local"], self.embed_dim, st["z"], self.noise_dim, width)
-                ident = st.setdefault("ident", torch.arange(s, dtype=torch.int64, device=dev))
+                ident = st["ident"]
                 # Cb = 0: the whole row is "embedding" = the already assembled x
                 check(lib().zs3_gmmn_mlp_fwd1(P(x), I(width), P(ident), P(st["ridx"]), I(width), I(0), P(wp1.f_pk),
                                               I(wp1.cin_pad // 32), P(lin1.bias), P(None), I(width), P(h), P(hd), I(hid), I(s),

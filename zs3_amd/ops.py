@@ -58,10 +58,11 @@ def pick_tile(m, ncols, k=0):
         return 14
     if m >= 8192 and k >= 512 and ncols >= 256:
         # stream-K (tile_cfg 32) when whole 256x128 tiles leave > 12 % of the chip idle in the last round (138 tiles of the
-        # layer-3 convolutions: 54 % of 256 CUs; 276 tiles of layer 4: two rounds for 1.08) and there is enough K to share
+        # layer-3 convolutions and of the ASPP branches: 54 % of 256 CUs) and there is enough K to share; launches with more
+        # tiles than CUs (276 tiles of layer 4) would need more than two segments per workgroup: not built yet
         tiles = ((m + 255) // 256) * ((ncols + 127) // 128)
         rounds = (tiles + 255) // 256
-        if STREAMK and tiles <= 2048 and tiles / (rounds * 256.0) < 0.88 and tiles * (k // 32) >= 2048:
+        if STREAMK and 64 <= tiles <= 256 and tiles / 256.0 < 0.88 and tiles * (k // 32) >= 2048:
             return 32
         return 31
     if ncols >= 256 and 128 <= k <= 256:
