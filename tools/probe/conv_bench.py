@@ -33,7 +33,7 @@ for (cnt, h, ci, co, k, s, d) in SHAPES:
     for c0 in cfgs:
         c = c0
         if c >= 31 and (co if mode == "dgrad" else ci) % 32: c = 21
-        if c == 32 and ops.pick_tile(B * ho * ho if mode == "fwd" else B * h * h, co if mode == "fwd" else ci, (ci if mode == "fwd" else co) * k * k) != 32: c = 31   # stream-K only where the step would use it
+        if c == 32 and ops.pick_tile(B * ho * ho if mode == "fwd" else B * h * h, co if mode == "fwd" else ci, (ci if mode == "fwd" else co) * k * k) not in (31, 32): c = 31
         if mode == "fwd": t = timeit(lambda: ops.conv2d_fwd(x, wp, s, pad, d, tile_cfg=c, want_stats=True))
         elif mode == "dgrad": t = timeit(lambda: ops.conv2d_dgrad(dy, wp, (h, h), s, pad, d, tile_cfg=c))
         else: t = timeit(lambda: ops.conv2d_wgrad(dy, x, co, ci, k, k, s, pad, pad, d))

@@ -801,11 +801,16 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   auto next_segment = [&]() -> bool {   // KT = K steps of the segment, kb = its first K step inside the tile
     if (it >= it_end) return false;
     if (SK) {
-      tile = sk_tile0 + (int)(it / KT_TILE);
-      kb = (int)(it - (long)(tile - sk_tile0) * KT_TILE);
-      const long left = it_end - it;
-      KT = (long)(KT_TILE - kb) < left ? KT_TILE - kb : (int)left;
-      it += KT;
+      // LAST tile of the remaining range first: a block's share is [tail of tile A | head of tile B]; the head of B is a
+      // partial tile that B's owner (the next block) waits for, the tail of A waits for the previous block's head of A.
+      // Heads first = every block publishes before it starts waiting; tails first would chain the waits through all the
+      // blocks of the XCD.
+      tile = sk_tile0 + (int)((it_end - 1) / KT_TILE);
+      const long tile_it0 = (long)(tile - sk_tile0) * KT_TILE;
+      const long seg_it0 = it > tile_it0 ? it : tile_it0;
+      kb = (int)(seg_it0 - tile_it0);
+      KT = (int)(it_end - seg_it0);
+      it_end = seg_it0;
     } else {
       tile = xcd_remap(blockIdx.x, gridDim.x);
       kb = 0;
@@ -1333,8 +1338,9 @@ int launch_dma_sk(ConvArgs a, int prec, hipStream_t st) {
     {
       const long tiles = (long)((a.M + 255) / 256) * ((a.ncols + 127) / 128);
       const long kt = (long)a.KH * a.KW * (a.cin_pad / 32);
-      // a block's share spans at most two tiles, a tile at most five blocks, every block has work
-      if (tiles > SK_GRID || tiles < 64 || tiles * kt < 8L * SK_GRID) return -7;
+      // a block's share spans at most two tiles, a tile at most five blocks, every block has work: anything else runs
+      // as a whole-tile launch
+      if (tiles > SK_GRID || tiles < 64 || tiles * kt < 8L * SK_GRID) return launch_dma(a, prec, st);
     }
     SkState& sk = itr->second;
     if (++sk.epoch == 0u) sk.epoch = 1u;   // flags are zero-initialised: 0 never is a valid epoch

@@ -89,67 +89,53 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const MlpArgs p) {
 
   // ---- one burst: the whole K extent of this tile's rows of A and of W.  Every global load is issued before the first
   // LDS write (and before the noise is hashed), so the tile costs ONE memory round trip; <= 20 K chunks (checked by the host)
-  constexpr int MAXA = MLP_BM * (MLP_MAXCH * 8) / 256, MAXB = (MLP_BN * MLP_MAXCH * 8 + 255) / 256;
-  const int a4 = kpad >> 2, na = MLP_BM * a4;
-  const int b16 = p.kchunks * 8, nbp = MLP_BN * b16;   // 16-byte pieces per W row / per tile
+  // thread t owns row t >> 3 of A (8 threads x 16 B walk a row in 128-byte steps) and row t >> 4 of W (16 threads per
+  // row): no integer division in the address math, every wave instruction reads whole 128-byte lines
+  constexpr int MAXA = (MLP_MAXCH * 8 + 7) / 8, MAXB = (MLP_MAXCH * 8 + 15) / 16;
+  const int a4 = kpad >> 2;                    // float4 per A row
+  const int b16 = p.kchunks * 8;               // 16-byte pieces per W row
+  const int ar = tid >> 3, aq = tid & 7, br = tid >> 4, bq = tid & 15;
+  const int am = m0 + ar;
   f4 av[MAXA];
   u32x4 bv[MAXB];
+  const unsigned short* wrow = p.w + (size_t)(n0 + br) * p.kchunks * 64;
+  const bool wok = n0 + br < p.N;
 #pragma unroll
   for (int u = 0; u < MAXB; ++u) {
-    const int i = tid + u * 256;
+    const int piece = bq + 16 * u;
     bv[u] = u32x4{0u, 0u, 0u, 0u};
-    if (i < nbp) {
-      const int n = i / b16, piece = i - n * b16;
-      if (n0 + n < p.N) bv[u] = *reinterpret_cast<const u32x4*>(p.w + (size_t)(n0 + n) * p.kchunks * 64 + piece * 8);
-    }
+    if (wok && piece < b16) bv[u] = *reinterpret_cast<const u32x4*>(wrow + piece * 8);
   }
+  const float* arow = nullptr;
+  if (am < p.M) arow = MODE == MLP_FWD1 ? p.emb + p.pix[am] * p.ld_emb : p.a + (size_t)am * p.lda;
+  const int alim = MODE == MLP_FWD1 ? p.Ca : p.K;
 #pragma unroll
   for (int u = 0; u < MAXA; ++u) {
-    const int i = tid + u * 256;
+    const int c = (aq + 8 * u) * 4;
     av[u] = f4{0.f, 0.f, 0.f, 0.f};
-    if (i < na) {
-      const int r = i / a4, c = (i - r * a4) * 4, m = m0 + r;
-      if (m < p.M) {
-        if (MODE == MLP_FWD1) {
-          if (c < p.Ca) av[u] = *reinterpret_cast<const f4*>(p.emb + p.pix[m] * p.ld_emb + c);
-        } else if (c < p.K) {
-          av[u] = *reinterpret_cast<const f4*>(p.a + (size_t)m * p.lda + c);
-        }
-      }
-    }
+    if (arow && c < alim) av[u] = *reinterpret_cast<const f4*>(arow + c);
   }
-  if (MODE == MLP_FWD1) {
+  if (MODE == MLP_FWD1 && am < p.M) {
 #pragma unroll
     for (int u = 0; u < MAXA; ++u) {
-      const int i = tid + u * 256;
-      if (i < na) {
-        const int r = i / a4, c = (i - r * a4) * 4, m = m0 + r;
-        if (m < p.M) {
-          if (c >= p.Ca && c < p.Ca + p.Cb) {
-            const unsigned long long base = (unsigned long long)(p.key[m] * p.Cb + (c - p.Ca));
+      const int c = (aq + 8 * u) * 4;
+      if (c >= p.Ca && c < p.Ca + p.Cb) {
+        const unsigned long long base = (unsigned long long)(p.key[am] * p.Cb + (c - p.Ca));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[u][e] = u01(s_noise, base + e);
-          }
-          if (p.x_out && nbk == 0 && c < p.ldx) *reinterpret_cast<f4*>(p.x_out + (size_t)m * p.ldx + c) = av[u];
-        }
+        for (int e = 0; e < 4; ++e) av[u][e] = u01(s_noise, base + e);
       }
+      if (p.x_out && nbk == 0 && c < p.ldx && c < 4 * a4) *reinterpret_cast<f4*>(p.x_out + (size_t)am * p.ldx + c) = av[u];
     }
   }
 #pragma unroll
   for (int u = 0; u < MAXA; ++u) {
-    const int i = tid + u * 256;
-    if (i < na) {
-      const int r = i / a4, c = (i - r * a4) * 4;
-      *reinterpret_cast<f4*>(As + r * SA + c) = av[u];
-    }
+    const int c4i = aq + 8 * u;
+    if (c4i < a4) *reinterpret_cast<f4*>(As + ar * SA + c4i * 4) = av[u];
   }
 #pragma unroll
   for (int u = 0; u < MAXB; ++u) {
-    const int i = tid + u * 256;
-    if (i < nbp) {
-      const int n = i / b16, piece = i - n * b16;
-      *reinterpret_cast<u32x4*>(Bs + n * SB + piece * 8) = bv[u];
-    }
+    const int piece = bq + 16 * u;
+    if (piece < b16) *reinterpret_cast<u32x4*>(Bs + br * SB + piece * 8) = bv[u];
   }
   if (MODE == MLP_FWD2 && p.real_out) {       // the sampled real rows, 16 columns per workgroup
     for (int i = tid; i < MLP_BM * (MLP_BN / 4); i += 256) {

@@ -58,11 +58,13 @@ def pick_tile(m, ncols, k=0):
         return 14
     if m >= 8192 and k >= 512 and ncols >= 256:
         # stream-K (tile_cfg 32) when whole 256x128 tiles leave > 12 % of the chip idle in the last round (138 tiles of the
-        # layer-3 convolutions and of the ASPP branches: 54 % of 256 CUs) and there is enough K to share; launches with more
-        # tiles than CUs (276 tiles of layer 4) would need more than two segments per workgroup: not built yet
+        # layer-3 convolutions and of the ASPP branches: 54 % of 256 CUs) and a tile has >= 72 K steps: every workgroup pays
+        # for ~3 partial-tile transfers of 128 KB (measured: -24 % on the ASPP 3x3 2048->256 with 576 K steps, -7 % on the
+        # 3x3 256->256 with 72, +23 % on the 1x1 1024->256 with 32); launches with more tiles than CUs (276 tiles of layer 4)
+        # would need more than two segments per workgroup: not built yet
         tiles = ((m + 255) // 256) * ((ncols + 127) // 128)
         rounds = (tiles + 255) // 256
-        if STREAMK and 64 <= tiles <= 256 and tiles / 256.0 < 0.88 and tiles * (k // 32) >= 2048:
+        if STREAMK and 64 <= tiles <= 256 and tiles / 256.0 < 0.88 and k // 32 >= 72:
             return 32
         return 31
     if ncols >= 256 and 128 <= k <= 256:
