@@ -106,7 +106,10 @@ def test_fused_update_equals_general_kernels(dev):
         a = next(o for o in out if o[0] and o[1] == noise)
         c = next(o for o in out if not o[0] and o[1] == noise)
         assert a[5] == c[5] > 20
-        # ~50 dependent Adam updates amplify the different fp32 summation order of the two kernel sets
-        assert abs(a[2] - c[2]) < 2e-3 * abs(c[2]) and abs(a[3] - c[3]) < 2e-3 * abs(c[3]), (noise, a[2:4], c[2:4])
-        for pa, pc in zip(a[4], c[4]):
-            assert ((pa - pc).abs().mean() / pc.abs().mean()).item() < 1e-3, noise
+        if noise == "cpu":   # same sample indices, same noise: ~50 dependent Adam updates amplify the summation order only
+            assert abs(a[2] - c[2]) < 2e-3 * abs(c[2]) and abs(a[3] - c[3]) < 2e-3 * abs(c[3]), (noise, a[2:4], c[2:4])
+            for pa, pc in zip(a[4], c[4]):
+                assert ((pa - pc).abs().mean() / pc.abs().mean()).item() < 1e-3, noise
+        else:                # table-driven chained replays draw the sample indices in one call per step: other samples of the
+            # same classes -> the same losses only statistically
+            assert abs(a[2] - c[2]) < 5e-2 * abs(c[2]) and abs(a[3] - c[3]) < 5e-2 * abs(c[3]), (noise, a[2:4], c[2:4])

@@ -121,7 +121,8 @@ template <int W>
 __global__ __launch_bounds__(64 * W) void mmd_tile_kernel(const MmdArgs p) {
   __shared__ float nrm[2][32];
   __shared__ float nrm_part[W > 1 ? W : 1][2][32];
-  __shared__ float acc_part[W > 1 ? W - 1 : 1][16][64];
+  __shared__ float acc_all[W > 1 ? W : 1][16][64];
+  __shared__ double sum_part[W > 1 ? W : 1][2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int T = (2 * p.N + 31) / 32;
   const int ti = blockIdx.x / T, tj = blockIdx.x % T;
@@ -168,22 +169,27 @@ __global__ __launch_bounds__(64 * W) void mmd_tile_kernel(const MmdArgs p) {
   }
   na += __shfl_xor(na, 32, 64);
   nb += __shfl_xor(nb, 32, 64);
+  // W > 1: every wave stores its partial accumulator; then wave w finishes accumulator registers [QW*w, QW*(w+1)) of the
+  // tile (QW = 16 / W): the exp() phase -- 6 bandwidths x 16 entries per lane, the longest part of this latency-bound kernel
+  // when one wave did all of it -- is spread over the W waves.  Partial sums are combined in wave order (deterministic).
+  constexpr int QW = 16 / W;
+  float accq[QW];
   if (W > 1) {
     if (h == 0) {
       nrm_part[w][0][r] = na;
       nrm_part[w][1][r] = nb;
     }
-    if (w > 0) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc_part[w - 1][q][lane] = acc[q];
-    }
+    for (int q = 0; q < 16; ++q) acc_all[w][q][lane] = acc[q];
     __syncthreads();
-    if (w > 0) return;
 #pragma unroll
-    for (int ww = 1; ww < W; ++ww)
+    for (int qq = 0; qq < QW; ++qq) {
+      float t = acc_all[0][QW * w + qq][lane];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] += acc_part[ww - 1][q][lane];
-    if (h == 0) {
+      for (int ww = 1; ww < W; ++ww) t += acc_all[ww][QW * w + qq][lane];
+      accq[qq] = t;
+    }
+    if (w == 0 && h == 0) {
       float sa = nrm_part[0][0][r], sb = nrm_part[0][1][r];
 #pragma unroll
       for (int ww = 1; ww < W; ++ww) {
@@ -193,9 +199,10 @@ __global__ __launch_bounds__(64 * W) void mmd_tile_kernel(const MmdArgs p) {
       nrm[0][r] = sa;
       nrm[1][r] = sb;
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the other lane-half's LDS writes are visible within the wave
+    __syncthreads();
   } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accq[q] = acc[q];
     if (h == 0) {
       nrm[0][r] = na;
       nrm[1][r] = nb;
@@ -207,11 +214,12 @@ __global__ __launch_bounds__(64 * W) void mmd_tile_kernel(const MmdArgs p) {
   const float invN2 = 1.f / ((float)p.N * (float)p.N);
   double pos = 0.0, neg = 0.0;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
+  for (int qq = 0; qq < QW; ++qq) {
+    const int q = QW * w + qq;
     const int il = (q & 3) + 8 * (q >> 2) + 4 * h;
     const int i = ti * 32 + il;
     if (i < 2 * p.N && j < 2 * p.N) {
-      const float e = acc[q] - 0.5f * nrm[0][il] - 0.5f * nj;
+      const float e = accq[qq] - 0.5f * nrm[0][il] - 0.5f * nj;
       float ks = 0.f, kd = 0.f;
       for (int v = 0; v < p.nsig; ++v) {
         const float k = expf(e / p.sig[v]);
@@ -225,7 +233,23 @@ __global__ __launch_bounds__(64 * W) void mmd_tile_kernel(const MmdArgs p) {
   }
   pos = wave_sum_d(pos);
   neg = wave_sum_d(neg);
-  if (lane == 0) {
+  if (W > 1) {
+    if (lane == 0) {
+      sum_part[w][0] = pos;
+      sum_part[w][1] = neg;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tp = sum_part[0][0], tn = sum_part[0][1];
+#pragma unroll
+      for (int ww = 1; ww < W; ++ww) {
+        tp += sum_part[ww][0];
+        tn += sum_part[ww][1];
+      }
+      p.tile[2 * blockIdx.x + 0] = tp;
+      p.tile[2 * blockIdx.x + 1] = tn;
+    }
+  } else if (lane == 0) {
     p.tile[2 * blockIdx.x + 0] = pos;
     p.tile[2 * blockIdx.x + 1] = neg;
   }
