@@ -242,11 +242,21 @@ def main():
             def instrument(i):
                 return i % 5 == 4 or (args.steps < 5 and i == args.steps - 1)
 
-            def sampled_step(i):   # every 5th timed step carries the events (2 of the default 10)
-                ops.PROFILE = timed_prof if instrument(i) else None
+            STRIDE = 4     # ... and in such a step every 4th launch of the dominant kernel, the phase rotating from one
+            nth = [0]      # instrumented step to the next: 127 launches per step, so four instrumented steps cover each
+                           # launch exactly once.  (An event pair is ~50-100 us of host time and a kernel boundary the
+                           # GPU cannot overlap: 127 pairs in a step made that step ~25 ms longer.)
+
+            def sampled_step(i):
+                if instrument(i):
+                    ops.PROFILE = timed_prof
+                    ops.PROFILE_SAMPLE = [STRIDE, nth[0] % STRIDE, -1]
+                    nth[0] += 1
+                else:
+                    ops.PROFILE, ops.PROFILE_SAMPLE = None, None
                 return supervised_step(i)
             dt, last = run(sampled_step, args.steps, 0)
-            prof, ops.PROFILE, ops.PROFILE_CFGS = timed_prof, None, None
+            prof, ops.PROFILE, ops.PROFILE_CFGS, ops.PROFILE_SAMPLE = timed_prof, None, None, None
             instrumented = sum(1 for i in range(args.steps) if instrument(i))
         else:
             dt, last = run(supervised_step, args.steps, args.warmup)
@@ -298,8 +308,8 @@ def main():
             "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TF,
             "traffic": traffic, "traffic_source": traffic_src, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
             "instrumented_timed_steps": instrumented,
-            "note": "achieved = algorithmic 2*M*N*K flops of the launches / HIP-event time (events around every launch of this "
-                    "kernel in every 5th timed step)" + ("; each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation "
+            "note": "achieved = algorithmic 2*M*N*K flops of the sampled launches / their HIP-event time (events around every "
+                    "4th launch of this kernel, rotating phase, in every 5th timed step)" + ("; each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation "
                     "is 3x this fraction" if args.dtype == "bf16x3" else "; one bf16 MFMA per product"),
             "all_conv_igemm_last_warmup_step": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms": 1e3 * v[2]}
                                                 for k, v in warm.items()},

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""MFMA-busy evidence from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE ...; csv).
+usage: pmc_mfma.py <p_counter_collection.csv> <steps> > profiles/rNN_pmc_mfma.md
+
+Per kernel: launches, GRBM_GUI_ACTIVE (GPU-active cycles while the kernel ran), SQ_VALU_MFMA_BUSY_CYCLES summed over the
+chip's 1024 SIMDs, and MFMA-busy = busy / (active * 256 CUs * 4 SIMDs): the fraction of SIMD-cycles in which the matrix
+pipe was issuing (one v_mfma_f32_32x32x16_bf16 = 32 busy cycles, MI355X_MICROARCH.md).  For bf16x3 kernels every algorithmic
+product costs three MFMAs, so MFMA-busy ~ 3 x (achieved TF / 2500 TF) x (2.4 GHz / actual clock)."""
+import collections
+import csv
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"void ", "", name)
+    return re.sub(r"\(.*\)$", "", name)[:80]
+
+
+def main(path, steps):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (r.get("Dispatch_Id"), k)
+        if key not in seen:
+            seen.add(key)
+            cnt[k] += 1
+    names = sorted({c for v in agg.values() for c in v})
+    print(f"counters: {', '.join(names)}; {steps} training steps profiled (PMC collection serialises kernels: durations are not step-time)\n")
+    print("| kernel | launches | GRBM_GUI_ACTIVE (Mcyc) | SQ_VALU_MFMA_BUSY_CYCLES (Mcyc) | MFMA-busy | share of all MFMA-busy cycles |")
+    print("|---|---|---|---|---|---|")
+    tot_busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for v in agg.values()) or 1.0
+    rows = sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))
+    for k, v in rows[:25]:
+        act, busy = v.get("GRBM_GUI_ACTIVE", 0.0), v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        util = busy / (act * 1024.0) if act else float("nan")
+        print(f"| {k} | {cnt[k]} | {act / 1e6:.1f} | {busy / 1e6:.1f} | {100 * util:.1f} % | {100 * busy / tot_busy:.1f} % |")
+    act = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in agg.values())
+    print(f"\nall kernels: MFMA-busy {100 * tot_busy / (act * 1024.0):.1f} % of the GPU-active SIMD-cycles")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]))

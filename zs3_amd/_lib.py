@@ -15,6 +15,35 @@ class Zs3HipError(RuntimeError):
     pass
 
 
+def _declare(handle):
+    """argtypes / restype of every entry point, parsed from include/zs3hip.h: ctypes then converts plain Python ints,
+    floats and None itself (about half the host time of a call that wraps 30 arguments in c_int / c_void_p objects --
+    ~1000 launches per training step), and a call with the wrong number of arguments raises instead of corrupting the stack."""
+    import re
+    header = os.path.join(os.path.dirname(_HERE), "include", "zs3hip.h")
+    if not os.path.exists(header):
+        return
+    text = re.sub(r"/\*.*?\*/", " ", open(header).read(), flags=re.S)
+    scalar = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+              "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint}
+    for ret, name, args in re.findall(r"\b(int|long)\s+(zs3_\w+)\s*\(([^)]*)\)\s*;", text):
+        fn = getattr(handle, name, None)
+        if fn is None:
+            continue
+        types = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            if "*" in a:
+                types.append(ctypes.c_void_p)
+                continue
+            base = re.sub(r"\bconst\b", "", a).split()
+            base = " ".join(base[:-1]) if len(base) > 1 else base[0]     # drop the parameter name
+            types.append(scalar[base])
+        fn.argtypes = types
+        fn.restype = scalar[ret]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -24,18 +53,17 @@ def lib():
                 "zs3_amd has no CPU/eager fallback."
             )
         _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
     return _lib
 
 
 def P(t):
-    """Device pointer of a tensor (or NULL for None)."""
-    if t is None:
-        return ctypes.c_void_p(0)
-    return ctypes.c_void_p(t.data_ptr())
+    """Device pointer of a tensor (or NULL for None) as a plain integer: the declared argtypes do the conversion."""
+    return None if t is None else t.data_ptr()
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def check(rc, what):
@@ -49,5 +77,5 @@ def require_gpu(*tensors):
             raise Zs3HipError("zs3_amd ops run only on MI355X tensors (got a CPU tensor); there is no CPU fallback")
 
 
-F = ctypes.c_float
-I = ctypes.c_int
+F = float    # scalar arguments travel as plain Python numbers (argtypes declared from the header convert them)
+I = int

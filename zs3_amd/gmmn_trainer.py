@@ -85,7 +85,7 @@ class GMMNStep:
         self.fused_mlp = bool(fused_mlp) and os.environ.get("ZS3_GMMN_FUSED", "1") != "0"   # env: same-box A/B runs
         self._st = None       # static buffers (allocated at first call)
         self._graph = None
-        self._graphs = {}     # captured update chains by (mode, chain length)
+        self._update_graphs = {}     # captured update chains by (mode, chain length)
         self._feat_stream = None   # side stream of the pipelined feature pass (prefetch)
         self._prefetched = None    # (image, features, ready event) of the next batch
         self.last_updates = 0
@@ -285,14 +285,14 @@ class GMMNStep:
             for size in ((8, 4, 2, 1) if table_mode else (1,)):
                 while left >= size:
                     key = (training, self.noise, self.context_aware, table_mode, size)
-                    g = self._graphs.get(key)
+                    g = self._update_graphs.get(key)
                     if g is None:
                         g = torch.cuda.CUDAGraph()
                         torch.cuda.synchronize()
                         with torch.cuda.graph(g):
                             for _ in range(size):
                                 self._sampled_update(training)
-                        self._graphs[key] = g
+                        self._update_graphs[key] = g
                     g.replay()
                     left -= size
         # host-side mirror of the step count (state_dict compatibility with torch.optim.Adam)
@@ -402,7 +402,7 @@ class GMMNStep:
         if self._st is None or self._st["shape"] != (b, npix):
             self._alloc(dev, b, npix)
             self._graph = None
-            self._graphs = {}
+            self._update_graphs = {}
         st = self._st
         self._resplit()   # the generator may have been changed from outside (load_state_dict, another optimizer)
         real_rows = real.reshape(b, npix, d)
@@ -447,7 +447,7 @@ class GMMNStep:
                 cap = max(need, 256)          # static addresses: the captured updates hold these pointers
                 st["upd_host"] = torch.zeros((cap, self.bsg + 2), dtype=torch.int64).pin_memory()
                 st["upd_table"] = torch.zeros((cap, self.bsg + 2), dtype=torch.int64, device=dev)
-                self._graphs = {}
+                self._update_graphs = {}
             host = st["upd_host"]
             if rows:    # with replacement, uniform on [0, n_c): floor(U * n_c) with U from the CPU generator, one call per step
                 meta = torch.tensor(rows, dtype=torch.int64)

@@ -15,6 +15,7 @@ from ._lib import F, I, P, check, lib, require_gpu, stream
 PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs
 PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event, tile_cfg) per conv launch
 PROFILE_CFGS = None   # optional set of tile_cfg values to restrict the recording to (event pairs serialise kernel boundaries)
+PROFILE_SAMPLE = None  # optional [stride, phase, counter]: record every stride-th eligible launch (an event pair costs host time)
 
 
 _streamk = {}
@@ -176,6 +177,9 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
         mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
         stat = torch.empty((mt, 2, ncols), dtype=torch.float32, device=x.device)
     prof = PROFILE is not None and (PROFILE_CFGS is None or tile_cfg in PROFILE_CFGS)
+    if prof and PROFILE_SAMPLE is not None:
+        PROFILE_SAMPLE[2] += 1
+        prof = PROFILE_SAMPLE[2] % PROFILE_SAMPLE[0] == PROFILE_SAMPLE[1]
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
