@@ -479,7 +479,9 @@ def test_streamk_launches_match_whole_tile_launches(dev):
     BatchNorm partial sums, fused epilogue, dgrad; repeated launches (flag epochs), two streams at once."""
     from zs3_amd import ops
     shapes = [(16, 33, 1024, 256, 1, 1), (16, 33, 256, 256, 3, 1), (8, 33, 1024, 256, 1, 1), (16, 33, 2048, 256, 3, 12)]
-    assert ops.pick_tile(16 * 33 * 33, 256, 2304) == 32 and ops.pick_tile(16 * 33 * 33, 256, 1024) == 31   # the step's rule
+    old, ops.STREAMK = ops.STREAMK, True
+    assert ops.pick_tile(16 * 33 * 33, 256, 2304) == 32 and ops.pick_tile(16 * 33 * 33, 256, 1024) == 31   # the opt-in rule
+    ops.STREAMK = old
     side = torch.cuda.Stream(device=dev)
     for (n, h, ci, co, k, d) in shapes:
         g = torch.Generator().manual_seed(h + ci + co + k)

@@ -42,7 +42,13 @@ def streamk_errors():
     return int(sum(int(f[-1].item()) for _, f, _ in _streamk.values()))
 
 
-STREAMK = os.environ.get("ZS3_STREAMK", "1") != "0"   # env: same-box A/B runs
+# OFF by default.  Measured on MI355X (tools/probe/conv_bench.py 31,32; same-box A/B of bench.py): in isolation stream-K takes
+# the ASPP 3x3 2048->256 convolutions from 543 to 391-415 us (303 -> 397-439 TF) and the 3x3 256->256 of layer 3 from 96 to
+# 89 us, but inside the training step those launches are not alone -- the three ASPP branches run on three streams and every
+# dgrad runs next to the weight-gradient streams, so the CUs a 138-tile launch leaves idle are already used, and 256
+# persistent workgroups that wait for each other's partial tiles while sharing CUs cost more than they save:
+# 51.2 ms per step without, 51.7 ms with.  ZS3_STREAMK=1 enables the rule below.
+STREAMK = os.environ.get("ZS3_STREAMK", "0") == "1"
 
 
 def pick_tile(m, ncols, k=0):
