@@ -834,10 +834,14 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
     WgradArgs d = a;
     d.ci_write = wd;
     d.ci_read = ci_read < wd ? ci_read : wd;
-    static int use_cv = -1;   // ZS3_WGRAD_CV=0: the per-wave-conversion kernel (A/B runs)
+    // ZS3_WGRAD_CV=1: the shared-conversion kernel.  Parity-green (tests run both), but measured 5-12 % SLOWER than the
+    // per-wave-conversion kernel on every layer (decoder 3x3 256->256: 1795 vs 1575 us; whole step 52.6 vs 52.35 ms): the
+    // conversion VALU work was not what bounds the K loop, and the converted operands' extra LDS round trip + the fragment
+    // reads exposed at the top of every K step cost more than the 3x fewer conversions save.  Kept as the measured experiment.
+    static int use_cv = -1;
     if (use_cv < 0) {
       const char* e = getenv("ZS3_WGRAD_CV");
-      use_cv = e ? atoi(e) : 1;
+      use_cv = e ? atoi(e) : 0;
     }
     if (use_cv)
       rc = prec == 1 ? launch_wgrad_cv_prec<1>(d, taps, splitk, st) : launch_wgrad_cv_prec<3>(d, taps, splitk, st);
