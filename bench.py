@@ -51,9 +51,6 @@ def parse():
                     help="1: the next batch's feature pass overlaps the current batch's generator loop (GMMNStep.prefetch)")
     ap.add_argument("--ddp-selftest", action="store_true",
                     help="1-GPU run with a one-rank RCCL group and the full gradient-sync plumbing (cost of the N>1 code path)")
-    ap.add_argument("--priority-stream", action="store_true",
-                    help="run the steps on a high-priority HIP stream (functional.priority_compute); implies --no-roofline: "
-                         "timing events on that stream are pathologically slow (170 ms per instrumented step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -106,9 +103,6 @@ def main():
     from zs3_amd.utils.synthetic import make_batch
     from zs3_amd.gmmn_trainer import GMMNStep
 
-    if args.priority_stream:
-        Fz.PRIORITY_COMPUTE_STREAM = True
-        args.no_roofline = True
     ops.PREC_DEFAULT = 1 if args.dtype == "bf16" else 3
     unseen = [10, 14]
     seen = [c for c in range(args.classes) if c not in unseen]
@@ -140,10 +134,6 @@ def main():
         return loss
 
     def run(step, steps, warmup):
-        with Fz.priority_compute():      # no-op unless --priority-stream
-            return run_inner(step, steps, warmup)
-
-    def run_inner(step, steps, warmup):
         for i in range(warmup):
             step(i)
         if world > 1:
@@ -326,18 +316,22 @@ def pmc_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/r1_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the
     gfx950 note of MI355X_MICROARCH.md).  PMC collection cannot run inside the timed process, hence the file."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not found:
         return None, None
+    path = found[-1]            # the latest round's passes
     import re
     m = re.match(r"conv_igemm(_ws|_dma)?<(\d+),(\d+),(\d)(?:,pipe(\d))?>", tag)
     if not m:
         return None, None
-    name = f"conv_igemm{m.group(1)}_kernel<{m.group(4)}>" if m.group(1) else f"conv_igemm_kernel<{m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>"
-    k = json.load(open(path))["kernels"].get(name)
+    name = (f"conv_igemm{m.group(1)}_kernel<{m.group(4)}, false>" if m.group(1) == "_dma" else f"conv_igemm{m.group(1)}_kernel<{m.group(4)}>") if m.group(1) else f"conv_igemm_kernel<{m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>"
+    kernels = json.load(open(path))["kernels"]
+    k = kernels.get(name) or kernels.get(name.replace(", false>", ">"))
     if not k:
         return None, None
-    return k["read_bytes_per_launch"] + k["write_bytes_per_launch"], "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    return (k["read_bytes_per_launch"] + k["write_bytes_per_launch"],
+            f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)")
 
 
 def cpu_baseline(args):

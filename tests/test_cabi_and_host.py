@@ -199,21 +199,6 @@ def test_gcn_context_surface(libpath):
         step(torch.zeros(2, 3, 65, 65), torch.zeros(2, 65, 65))      # neither `embedding` nor `table`
 
 
-def test_priority_compute_is_a_noop_without_a_gpu_and_when_disabled():
-    """functional.priority_compute (the training loops and bench.py wrap their steps in it) must not touch CUDA state on a
-    CPU-only host, nor when the switch is off (the default)"""
-    from zs3_amd import functional as Fz
-    assert Fz.PRIORITY_COMPUTE_STREAM is False
-    with Fz.priority_compute() as ctx:
-        assert ctx._ctx is None
-    Fz.PRIORITY_COMPUTE_STREAM = True
-    try:
-        with Fz.priority_compute() as ctx:
-            assert ctx._ctx is None or torch.cuda.is_available()
-    finally:
-        Fz.PRIORITY_COMPUTE_STREAM = False
-
-
 def test_evaluator_seen_unseen_matches_the_reference(golden):
     """zs3/utils/metrics.py:88-196 (imported by eval_pascal.py:14): overall / seen / unseen / per-class score tuples on the
     fixture's four label maps equal the reference's, NaN pattern included (classes absent from the ground truth)."""

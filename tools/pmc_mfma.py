@@ -2,9 +2,12 @@
 """MFMA-busy evidence from one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE ...; csv).
 usage: pmc_mfma.py <p_counter_collection.csv> <steps> > profiles/rNN_pmc_mfma.md
 
-Per kernel: launches, GRBM_GUI_ACTIVE (GPU-active cycles while the kernel ran), SQ_VALU_MFMA_BUSY_CYCLES summed over the
-chip's 1024 SIMDs, and MFMA-busy = busy / (active * 256 CUs * 4 SIMDs): the fraction of SIMD-cycles in which the matrix
-pipe was issuing (one v_mfma_f32_32x32x16_bf16 = 32 busy cycles, MI355X_MICROARCH.md).  For bf16x3 kernels every algorithmic
+Per kernel: launches, GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES, and MFMA-busy = busy / (active * 128): the fraction of
+SIMD-cycles in which the matrix pipe was busy (one v_mfma_f32_32x32x16_bf16 = 32 busy cycles, MI355X_MICROARCH.md).
+Both counters arrive summed over the 8 XCDs: SQ_VALU_MFMA_BUSY_CYCLES over all 1024 SIMDs (checked against the launches'
+MFMA count: 127 LDS-DMA conv launches per step = 4860 GFLOP x 3 products / 32768 flop per MFMA x 32 cycles = 14.2 G busy
+cycles per step), GRBM_GUI_ACTIVE over the 8 per-XCD GRBMs (8 x kernel time x clock), so the SIMD-cycles available are
+(active / 8) * 1024 = active * 128.  For bf16x3 kernels every algorithmic
 product costs three MFMAs, so MFMA-busy ~ 3 x (achieved TF / 2500 TF) x (2.4 GHz / actual clock)."""
 import collections
 import csv
@@ -39,7 +42,7 @@ def main(path, steps):
     rows = sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))
     for k, v in rows[:25]:
         act, busy = v.get("GRBM_GUI_ACTIVE", 0.0), v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
-        util = busy / (act * 1024.0) if act else float("nan")
+        util = busy / (act * 128.0) if act else float("nan")
         wc = v.get("SQ_WAVE_CYCLES", 0.0) or float("nan")
         extra = (f"{100 * v.get('SQ_WAIT_ANY', 0) / wc:.0f} % / {100 * v.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} % / "
                  f"{100 * v.get('SQ_ACTIVE_INST_ANY', 0) / wc:.0f} %")
@@ -47,7 +50,7 @@ def main(path, steps):
         print(f"| {k} | {cnt[k]} | {act / 1e6:.1f} | {busy / 1e6:.1f} | {100 * util:.1f} % | {100 * busy / tot_busy:.1f} % | {extra} | "
               f"{100 * valu:.0f} % | {v.get('SQ_LDS_BANK_CONFLICT', 0) / wc:.3f} |")
     act = sum(v.get("GRBM_GUI_ACTIVE", 0.0) for v in agg.values())
-    print(f"\nall kernels: MFMA-busy {100 * tot_busy / (act * 1024.0):.1f} % of the GPU-active SIMD-cycles")
+    print(f"\nall kernels: MFMA-busy {100 * tot_busy / (act * 128.0):.1f} % of the GPU-active SIMD-cycles")
 
 
 if __name__ == "__main__":

@@ -34,11 +34,6 @@ class BaseTrainer:
 
     # ------------------------------------------------------------------ the reference entry point
     def training(self, epoch):
-        from . import functional as Fz
-        with Fz.priority_compute():      # the step's dependent chain on the high-priority stream (no-op on CPU)
-            return self._training(epoch)
-
-    def _training(self, epoch):
         self.model.train()
         iterator = self.train_loader
         try:

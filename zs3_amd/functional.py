@@ -58,45 +58,6 @@ def join_wgrad_stream():
 
 
 
-# ---------------------------------------------------------------------------------- high-priority stream for the dependent chain
-# The forward / dgrad / BatchNorm chain is the critical path of a step (it is busy for the whole step), the weight-gradient
-# kernels on the side stream only have to be done by the end of backward.  HIP exposes two priority levels through torch and
-# the default stream has the lower one; with the whole training loop inside `priority_compute()` the chain's workgroups go
-# first when both streams have some ready (same-box A/B: 51.3 -> 50.1 ms per step together with the tile rule change).
-# OFF by default: entering / leaving the context once per step instead of once per loop costs 20 ms per step, and HIP
-# timing events recorded on the high-priority stream (bench.py's roofline instrumentation, profilers) turn a step into
-# 170 ms -- both measured, neither understood yet.  bench.py --priority-stream and the trainers honour the switch.
-PRIORITY_COMPUTE_STREAM = False
-_prio = {}
-
-
-class priority_compute:
-    """Context manager: run the enclosed GPU work on this device's high-priority stream (no-op without a GPU, when disabled,
-    or when already inside).  Entering waits for the work queued on the current stream; leaving makes the current stream wait
-    for the enclosed work, so code around the block keeps ordinary stream semantics."""
-
-    def __enter__(self):
-        self._ctx = None
-        if not (PRIORITY_COMPUTE_STREAM and torch.cuda.is_available()):
-            return self
-        dev = torch.cuda.current_device()
-        if dev not in _prio:
-            _prio[dev] = torch.cuda.Stream(device=dev, priority=-1)
-        self._stream, self._outer = _prio[dev], torch.cuda.current_stream(dev)
-        if self._outer == self._stream or torch.cuda.is_current_stream_capturing():
-            return self
-        self._stream.wait_stream(self._outer)
-        self._ctx = torch.cuda.stream(self._stream)
-        self._ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self._ctx is not None:
-            self._ctx.__exit__(*exc)
-            self._outer.wait_stream(self._stream)
-        return False
-
-
 # ---------------------------------------------------------------------------------- weight-plane cache
 _planes = {}
 

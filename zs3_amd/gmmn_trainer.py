@@ -598,10 +598,6 @@ class GMMNTrainer:
                                 real_seen_features=args.real_seen_features, noise=noise)
 
     def training(self, epoch, args=None):
-        with Fz.priority_compute():      # the step's dependent chain on the high-priority stream
-            return self._training(epoch, args)
-
-    def _training(self, epoch, args=None):
         train_loss = 0.0
         self.model.train()
         num_img_tr = len(self.train_loader)
