@@ -366,6 +366,8 @@ class GMMNStep:
         require_gpu(image)
         dev = image.device
         if self._feat_stream is None:
+            # (a CU-masked stream that leaves 16-64 CUs to the generator loop -- hipExtStreamCreateWithCUMask -- was measured:
+            # 61-65 ms per step instead of 38.5: the masked queue slows the convolutions far more than the loop gains)
             self._feat_stream = torch.cuda.Stream(device=dev)
         self._feat_stream.wait_stream(torch.cuda.current_stream(dev))    # the image (and the previous feature pass) are ready
         with torch.cuda.stream(self._feat_stream):
