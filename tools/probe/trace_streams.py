@@ -32,8 +32,11 @@ for q, lst in sorted(byq.items(), key=lambda kv: -len(kv[1])):
     for g, _, _ in gaps:
         hist["<2us" if g < 2000 else "2-10us" if g < 10000 else "10-50us" if g < 50000 else ">50us"] += 1
     print("   gap histogram:", dict(hist))
-    for g, a, b in sorted(gaps, reverse=True)[:6]:
-        print(f"   {g / 1e3:8.1f} us idle between {a} -> {b}")
+    order = sorted(range(len(gaps)), key=lambda i: -gaps[i][0])[:6]
+    for i in order:
+        ctx_before = " > ".join(k[2][:28] for k in lst[max(0, i - 2):i + 1])
+        ctx_after = " > ".join(k[2][:28] for k in lst[i + 1:i + 4])
+        print(f"   {gaps[i][0] / 1e3:8.1f} us idle at +{(lst[i][1] - t0) / 1e6:6.2f} ms:  {ctx_before}  ||  {ctx_after}")
 ev = sorted([(s, 1) for s, e, _, _ in step] + [(e, -1) for s, e, _, _ in step])
 depth, last, union = 0, t0, 0
 for t, d in ev:

@@ -398,7 +398,8 @@ class GMMNStep:
         b = image.shape[0]
         real = self._take_features(image)
         if next_image is not None:      # the caller already knows the next batch: overlap its feature pass with this loop
-            self.prefetch(next_image)
+            self.prefetch(next_image)   # (queued before the loop: 38.5 ms per step; after it: 39.9 ms; with the loop on a
+            # high-priority stream: 101 ms -- HIP priority streams misbehave on this runtime, as in round 1)
         fh, fw, d = real.shape[1], real.shape[2], real.shape[3]
         npix = fh * fw
         if self._st is None or self._st["shape"] != (b, npix):

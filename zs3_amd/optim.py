@@ -22,7 +22,12 @@ class SGD(torch.optim.SGD):
 
     @torch.no_grad()
     def step(self, closure=None):
+        """One multi-tensor launch per (device, momentum, nesterov).  The host side runs at every step boundary, where the
+        GPU has nothing else queued, so it is kept short: the workgroup -> (tensor, chunk) map depends only on the tensor
+        sizes and lives on the device across steps; the record table is assembled with numpy."""
         import struct
+
+        import numpy as np
         loss = closure() if closure is not None else None
         chunk = lib().zs3_sgd_chunk()
         by_cfg = {}
@@ -33,37 +38,45 @@ class SGD(torch.optim.SGD):
             lr, mom, wd, nest = group["lr"], group["momentum"], group["weight_decay"], group["nesterov"]
             packed = struct.unpack("<q", struct.pack("<ff", lr, wd))[0]
             for p in group["params"]:
-                if p.grad is None:
-                    continue
                 g = p.grad
+                if g is None:
+                    continue
                 # parameters are dense in *some* permutation (channels_last conv weights): the update is elementwise,
                 # so p, grad and the buffer only need to share strides
-                if not _same_layout(g, p):
+                if g.stride() != p.stride() and not _same_layout(g, p):
                     g = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(g)
                     keep.append(g)
                 state = self.state[p]
                 first = 0
-                if mom != 0 and state.get("momentum_buffer") is None:
-                    state["momentum_buffer"] = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
-                    first = 1
-                buf = state.get("momentum_buffer") if mom != 0 else None
-                if buf is not None and not _same_layout(buf, p):
-                    # a buffer restored by load_state_dict keeps the strides it was saved with (torch.optim.SGD on the
-                    # reference: NCHW-contiguous); the kernel walks p, grad and buffer by raw pointer, so re-lay it once
-                    buf = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(buf)
-                    state["momentum_buffer"] = buf
+                buf = None
+                if mom != 0:
+                    buf = state.get("momentum_buffer")
+                    if buf is None:
+                        buf = state["momentum_buffer"] = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device)
+                        first = 1
+                    elif buf.stride() != p.stride() and not _same_layout(buf, p):
+                        # a buffer restored by load_state_dict keeps the strides it was saved with (torch.optim.SGD on the
+                        # reference: NCHW-contiguous); the kernel walks p, grad and buffer by raw pointer, so re-lay it once
+                        buf = torch.empty_strided(p.shape, p.stride(), dtype=p.dtype, device=p.device).copy_(buf)
+                        state["momentum_buffer"] = buf
                 rec = by_cfg.setdefault((p.device, float(mom), bool(nest)), [])
                 rec.append((p.data_ptr(), g.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel(), packed, first))
                 touched.append(p)
+        cache = self.__dict__.setdefault("_zs3_blockmaps", {})
         for (dev, mom, nest), recs in by_cfg.items():
-            table = torch.tensor(recs, dtype=torch.int64).pin_memory()
-            bmap = []
-            for e, r in enumerate(recs):
-                bmap.extend((e, c) for c in range((r[3] + chunk - 1) // chunk))
-            blockmap = torch.tensor(bmap, dtype=torch.int32).pin_memory()
-            table_d, map_d = table.to(dev, non_blocking=True), blockmap.to(dev, non_blocking=True)
-            check(lib().zs3_sgd_multi(P(table_d), P(map_d), I(len(bmap)), F(mom), I(int(nest)), stream()), "zs3_sgd_multi")
-            keep.extend((table, blockmap, table_d, map_d))
+            arr = np.asarray(recs, dtype=np.int64)
+            sizes = tuple(arr[:, 3].tolist())
+            hit = cache.get((dev, mom, nest))
+            if hit is None or hit[0] != sizes:
+                nchunks = (arr[:, 3] + chunk - 1) // chunk
+                ent = np.repeat(np.arange(len(recs), dtype=np.int32), nchunks)
+                within = np.concatenate([np.arange(n, dtype=np.int32) for n in nchunks]) if len(recs) else ent
+                hit = (sizes, torch.from_numpy(np.stack((ent, within), 1).copy()).to(dev), int(nchunks.sum()))
+                cache[(dev, mom, nest)] = hit
+            table = torch.from_numpy(arr).pin_memory()
+            table_d = table.to(dev, non_blocking=True)
+            check(lib().zs3_sgd_multi(P(table_d), P(hit[1]), I(hit[2]), F(mom), I(int(nest)), stream()), "zs3_sgd_multi")
+            keep.extend((table, table_d))
         self._keepalive = keep   # pinned staging buffers must outlive the asynchronous copies
         Fz.refresh_planes(*touched)   # one launch re-splits every updated conv weight into its bf16 hi/lo planes
         return loss
