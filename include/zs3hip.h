@@ -158,9 +158,11 @@ int zs3_mmd_fwd(const float* gen, int ldg, const float* real, int ldr, int N, in
                 float* G, double* tile_ws, float* loss, void* stream);
 int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G, const float* loss,
                 const float* gout, float* dgen, int ldo, void* stream);
-/* zs3_mmd_bwd that takes the loss from zs3_mmd_fwd's tile_ws (zs3_mmd_fwd may then be called with loss = NULL) */
+/* zs3_mmd_bwd that takes the loss from zs3_mmd_fwd's tile_ws (zs3_mmd_fwd may then be called with loss = NULL); with
+   loss_ring != NULL it also stores the loss value to loss_ring[slot_dev[0]] (slot_dev: device int64, < ring_len) */
 int zs3_mmd_bwd_ws(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
-                   const double* tile_ws, const float* gout, float* dgen, int ldo, void* stream);
+                   const double* tile_ws, const float* gout, float* dgen, int ldo, float* loss_ring, const void* slot_dev,
+                   int ring_len, void* stream);
 /* end of one generator update: loss_ring[slot_dev[0]++] = MMD loss from tile_ws; step_dev[0] += 1; seed_dev[0] += seed_inc */
 int zs3_gmmn_update_epilogue(const double* tile_ws, int N, float* loss_ring, void* slot_dev, int ring_len, void* step_dev,
                              void* seed_dev, long seed_inc, void* stream);
@@ -193,6 +195,16 @@ int zs3_gmmn_mlp_dgrad(const float* dgen, int lda, const void* wt_pk, int kchunk
 int zs3_gmmn_mlp_wgrad(const float* dy2, int ldy2, const float* x2, int ldx2, int co2, int ci2, float* dw2, float* db2,
                        const float* dy1, int ldy1, const float* x1, int ldx1, int co1, int ci1, float* dw1, float* db1, int R,
                        void* stream);
+/* wgrad + torch.optim.Adam (train_pascal_GMMN.py:65-67,240) + end-of-update bookkeeping in one launch: every 64x64 tile of a
+ * weight gradient is consumed where it is produced -- Adam moments and weight updated, the weight's bf16 hi/lo operand planes
+ * rewritten -- and the last workgroup to finish advances the device-resident counters of the captured update: slot_dev += 1,
+ * step_dev += 1, seed_dev += seed_inc.  state2 / state1: 8 device pointers per layer (HOST arrays): {weight, exp_avg,
+ * exp_avg_sq, bias, bias exp_avg, bias exp_avg_sq, f_pk, t_pk}; done_dev: a zeroed uint32 arrival counter (left zero). */
+int zs3_gmmn_mlp_wgrad_adam(const float* dy2, int ldy2, const float* x2, int ldx2, int co2, int ci2, const float* dy1,
+                            int ldy1, const float* x1, int ldx1, int co1, int ci1, int R, const void* const* state2,
+                            const void* const* state1, int cin_pad2, int cout_pad2, int cin_pad1, int cout_pad1, float lr,
+                            float b1, float b2, float eps, float wd, void* slot_dev, void* step_dev, void* seed_dev,
+                            long seed_inc, void* done_dev, void* stream);
 
 /* ---- GMMN step helpers and optimisers (misc.hip) ---------------------------------------------- */
 /* nn.Dropout (aspp.py:100, decoder.py:19,23, gmmn.py:20): y = keep ? x/(1-p) : 0 with a counter-based mask

@@ -113,3 +113,47 @@ def test_fused_update_equals_general_kernels(dev):
         else:                # table-driven chained replays draw the sample indices in one call per step: other samples of the
             # same classes -> the same losses only statistically
             assert abs(a[2] - c[2]) < 5e-2 * abs(c[2]) and abs(a[3] - c[3]) < 5e-2 * abs(c[3]), (noise, a[2:4], c[2:4])
+
+
+def test_generator_optimizer_state_reload_between_steps(dev):
+    """the captured update holds raw pointers to the Adam moments and mirrors the step count on the device.
+    optimizer_generator.load_state_dict() between two steps replaces those tensors: the step must notice and rebuild, and
+    the second step must equal the one of a run without the reload."""
+    import copy
+    import zs3_oracle as zo
+    from zs3_amd.gmmn_trainer import GMMNStep
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.modeling.gmmn import GMMNnetwork
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    seen = [c for c in range(21) if c not in (10, 14)]
+    b = zo.make_synthetic_batch(3, 65, seed=5, with_label_emb=False)
+    results = []
+    for reload in (False, True):
+        torch.manual_seed(1)
+        m = DeepLab(num_classes=21, pretrained=False).to(dev).train()
+        gen = GMMNnetwork(300, 300, 256, 256)
+        gen.model[2].p = 0.0
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        gen = gen.to(dev).train()
+        groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+        opt_g = Adam(gen.parameters(), lr=2e-4)
+        step = GMMNStep(m, gen, SGD(groups, momentum=0.9, weight_decay=5e-4), opt_g,
+                        SegmentationLosses(cuda=True).build_loss("ce"), seen=seen, unseen=[10, 14], noise="cpu")
+        out = []
+        for it in range(2):
+            torch.manual_seed(40 + it)
+            out.append(step(b["image"].to(dev), b["label"].to(dev), table=b["table"].to(dev))[:2])
+            if reload and it == 0:
+                old_ptr = opt_g.state[gen.model[0].weight]["exp_avg"].data_ptr()
+                opt_g.load_state_dict(copy.deepcopy(opt_g.state_dict()))
+                assert opt_g.state[gen.model[0].weight]["exp_avg"].data_ptr() != old_ptr
+        results.append((out, [p.detach().clone() for p in gen.parameters()],
+                        int(opt_g.state[gen.model[0].weight]["step"])))
+    (o0, p0, s0), (o1, p1, s1) = results
+    assert s0 == s1 == 2 * step.last_updates
+    assert o0 == o1
+    for a, c in zip(p0, p1):
+        assert torch.equal(a, c)

@@ -19,7 +19,7 @@ for n, b in busy.most_common(40):
     print(f"{n:62s} {cnt[n]:6d} {b/1e3:9.1f} {b/1e3/cnt[n]:7.2f} {gap[n]/1e3:9.1f} {gap[n]/1e3/cnt[n]:7.2f}")
 print("total busy ms", sum(busy.values())/1e6, "total gap ms", sum(gap.values())/1e6, "span ms", (ks[-1][1]-ks[0][0])/1e6)
 # one update: find the last occurrence of the epilogue kernel and print the 30 launches before it
-idx = [i for i, k in enumerate(ks) if "gmmn_update_epilogue" in k[2]]
+idx = [i for i, k in enumerate(ks) if "gmmn_update_epilogue" in k[2] or "mlp_wgrad_kernel<true>" in k[2]]
 if len(idx) > 10:
     i1, i0 = idx[-5], idx[-6]
     print("\none generator update (launch-by-launch): start_us dur_us gap_us name")

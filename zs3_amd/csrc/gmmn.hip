@@ -221,14 +221,39 @@ struct WgProb {
   float* dw;         // [co][ci] (row stride ci)
   float* db;         // [co]
   int ldy, ldx, co, ci, tiles_ci, tile0;   // tile0: first block id of this problem
+  // fused Adam (mlp_wgrad_kernel<true>): the layer's weight [co][ci] and bias [co] with their moments, and the bf16 hi/lo
+  // operand planes of zs3_prep_weight that the next forward / dgrad read (f_pk rows = co, t_pk rows = ci)
+  float *w, *wm, *wv, *b, *bm, *bv;
+  unsigned short *f_pk, *t_pk;
+  int cin_pad, cout_pad;
 };
 struct WgArgs {
   WgProb pr[2];
   int R;
+  // fused Adam + end-of-update bookkeeping
+  float lr, b1, b2, eps, wd;
+  const long* step;        // Adam step count before this update
+  long* counters[3];       // slot (update index of the step), step, seed: advanced by the last workgroup to finish
+  long seed_inc;
+  unsigned* done;          // arrival counter (zero between launches)
 };
+
+__device__ __forceinline__ long packed_index(long row, long k, long ktot, int half) {   // layout of zs3_prep_weight, 1 tap
+  return ((row * (ktot >> 5) + (k >> 5)) * 2 + half) * 32 + (k & 31);
+}
+__device__ __forceinline__ float adam_update(float g, float& p, float& m, float& v, float lr, float b1, float b2, float eps,
+                                             float wd, float bc1, float bc2_sqrt) {   // torch.optim.Adam, as zs3_adam_multi
+  const float gi = g + wd * p;
+  m = m + (1.f - b1) * (gi - m);
+  v = b2 * v + (1.f - b2) * gi * gi;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - (lr / bc1) * (m / denom);
+  return p;
+}
 
 constexpr int WG_T = 64, WG_LD = 66;   // 66-float rows: the two 8-row halves of a ds_read_b32 group land 16 banks apart
 
+template <bool ADAM>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x 33 KB: above the 64 KB static limit
   float* Ys = reinterpret_cast<float*>(smem);
@@ -282,6 +307,12 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
       }
   }
+  float bc1 = 1.f, bc2_sqrt = 1.f;
+  if (ADAM) {
+    const double st = (double)(p.step[0] + 1);
+    bc1 = (float)(1.0 - pow((double)p.b1, st));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)p.b2, st));
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -290,13 +321,54 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int co = co0 + wi * 32 + i * 16 + kg * 4 + e;
-        if (co < q.co && ci < q.ci) q.dw[(size_t)co * q.ci + ci] = acc[i][j][e];
+        if (co < q.co && ci < q.ci) {
+          const size_t idx = (size_t)co * q.ci + ci;
+          if (!ADAM) {
+            q.dw[idx] = acc[i][j][e];
+          } else {   // the tile's gradient never leaves the registers: Adam + the bf16 hi/lo planes of the new weight
+            float w = q.w[idx], m = q.wm[idx], v = q.wv[idx];
+            adam_update(acc[i][j][e], w, m, v, p.lr, p.b1, p.b2, p.eps, p.wd, bc1, bc2_sqrt);
+            q.w[idx] = w;
+            q.wm[idx] = m;
+            q.wv[idx] = v;
+            const unsigned short h = f32_to_bf16_rne(w);
+            const unsigned short l = f32_to_bf16_rne(w - bf16_bits_to_f32(h));
+            q.f_pk[packed_index(co, ci, q.cin_pad, 0)] = h;
+            q.f_pk[packed_index(co, ci, q.cin_pad, 1)] = l;
+            if (q.t_pk) {
+              q.t_pk[packed_index(ci, co, q.cout_pad, 0)] = h;
+              q.t_pk[packed_index(ci, co, q.cout_pad, 1)] = l;
+            }
+          }
+        }
       }
     }
-  if (tci == 0 && tid < WG_T && co0 + tid < q.co && q.db) {   // bias gradient: column sums of dy, rows in order
+  if (tci == 0 && tid < WG_T && co0 + tid < q.co) {   // bias gradient: column sums of dy, rows in order
     float s = 0.f;
     for (int r = 0; r < p.R; ++r) s += Ys[r * WG_LD + tid];
-    q.db[co0 + tid] = s;
+    if (!ADAM) {
+      if (q.db) q.db[co0 + tid] = s;
+    } else if (q.b) {
+      float w = q.b[co0 + tid], m = q.bm[co0 + tid], v = q.bv[co0 + tid];
+      adam_update(s, w, m, v, p.lr, p.b1, p.b2, p.eps, p.wd, bc1, bc2_sqrt);
+      q.b[co0 + tid] = w;
+      q.bm[co0 + tid] = m;
+      q.bv[co0 + tid] = v;
+    }
+  }
+  if (ADAM) {
+    // end of the update: the LAST workgroup to get here advances the device-resident counters (every workgroup has read
+    // the step count by then; the readers of slot and seed are other launches, ordered by the stream)
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned n = __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n == gridDim.x - 1) {
+        __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.counters[0][0] += 1;
+        p.counters[1][0] += 1;
+        p.counters[2][0] += p.seed_inc;
+      }
+    }
   }
 }
 
@@ -386,7 +458,7 @@ extern "C" int zs3_gmmn_mlp_wgrad(const float* dy2, int ldy2, const float* x2, i
                                   float* dw1, float* db1, int R, void* stream) {
   if (R <= 0 || R > 128) return -1;
   if ((ldy2 | ldx2 | co2 | ci2 | ldy1 | ldx1 | co1 | ci1) & 3) return -1;
-  WgArgs a;
+  WgArgs a = {};
   a.R = R;
   const float* dys[2] = {dy2, dy1};
   const float* xs[2] = {x2, x1};
@@ -404,11 +476,59 @@ extern "C" int zs3_gmmn_mlp_wgrad(const float* dy2, int ldy2, const float* x2, i
   constexpr int LDS = 2 * 128 * WG_LD * 4;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess)
       return -4;
     configured = true;
   }
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles), dim3(256), LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(tiles), dim3(256), LDS, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+/* zs3_gmmn_mlp_wgrad + Adam in one launch: state[l] = {w, exp_avg, exp_avg_sq, bias, bias exp_avg, bias exp_avg_sq, f_pk,
+ * t_pk} (8 device pointers per layer, layer 2 first), dims[l] = {cin_pad, cout_pad}.  The last workgroup to finish
+ * advances slot_dev, step_dev (+1 each) and seed_dev (+seed_inc); done_dev is a zeroed 32-bit arrival counter. */
+extern "C" int zs3_gmmn_mlp_wgrad_adam(const float* dy2, int ldy2, const float* x2, int ldx2, int co2, int ci2,
+                                       const float* dy1, int ldy1, const float* x1, int ldx1, int co1, int ci1, int R,
+                                       const void* const* state2, const void* const* state1, int cin_pad2, int cout_pad2,
+                                       int cin_pad1, int cout_pad1, float lr, float b1, float b2, float eps, float wd,
+                                       void* slot_dev, void* step_dev, void* seed_dev, long seed_inc, void* done_dev,
+                                       void* stream) {
+  if (R <= 0 || R > 128 || !state2 || !state1 || !slot_dev || !step_dev || !seed_dev || !done_dev) return -1;
+  if ((ldy2 | ldx2 | co2 | ci2 | ldy1 | ldx1 | co1 | ci1) & 3) return -1;
+  WgArgs a = {};
+  a.R = R;
+  const float* dys[2] = {dy2, dy1};
+  const float* xs[2] = {x2, x1};
+  const void* const* sts[2] = {state2, state1};
+  const int ldys[2] = {ldy2, ldy1}, ldxs[2] = {ldx2, ldx1}, cos_[2] = {co2, co1}, cis[2] = {ci2, ci1};
+  const int cips[2] = {cin_pad2, cin_pad1}, cops[2] = {cout_pad2, cout_pad1};
+  int tiles = 0;
+  for (int i = 0; i < 2; ++i) {
+    WgProb& q = a.pr[i];
+    q.dy = dys[i]; q.x = xs[i]; q.ldy = ldys[i]; q.ldx = ldxs[i]; q.co = cos_[i]; q.ci = cis[i];
+    q.w = (float*)sts[i][0]; q.wm = (float*)sts[i][1]; q.wv = (float*)sts[i][2];
+    q.b = (float*)sts[i][3]; q.bm = (float*)sts[i][4]; q.bv = (float*)sts[i][5];
+    q.f_pk = (unsigned short*)sts[i][6]; q.t_pk = (unsigned short*)sts[i][7];
+    if (!q.w || !q.wm || !q.wv || !q.f_pk) return -1;
+    q.cin_pad = cips[i]; q.cout_pad = cops[i];
+    q.tiles_ci = (cis[i] + WG_T - 1) / WG_T;
+    q.tile0 = tiles;
+    tiles += q.tiles_ci * ((cos_[i] + WG_T - 1) / WG_T);
+  }
+  a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
+  a.step = (const long*)step_dev;
+  a.counters[0] = (long*)slot_dev; a.counters[1] = (long*)step_dev; a.counters[2] = (long*)seed_dev;
+  a.seed_inc = seed_inc;
+  a.done = (unsigned*)done_dev;
+  constexpr int LDS = 2 * 128 * WG_LD * 4;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        hipSuccess)
+      return -4;
+    configured = true;
+  }
+  hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(tiles), dim3(256), LDS, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }

@@ -271,7 +271,8 @@ __global__ void mmd_finalize_kernel(const double* tile, int ntiles, int N, float
 // owning a slice of the reduction over j (see mmd_tile_kernel).
 template <int W>
 __global__ __launch_bounds__(64 * W) void mmd_bwd_kernel(const MmdArgs p, const float* loss, const float* gout, float* dgen,
-                                                        int ldo, const double* tile_ws, int ntiles) {
+                                                        int ldo, const double* tile_ws, int ntiles, float* loss_ring,
+                                                        const long* slot, int ring_len) {
   __shared__ float rs[32];
   __shared__ float rs_part[W > 1 ? W : 1][32];
   __shared__ float acc_part[W > 1 ? W - 1 : 1][16][64];
@@ -285,6 +286,10 @@ __global__ __launch_bounds__(64 * W) void mmd_bwd_kernel(const MmdArgs p, const 
         neg += tile_ws[2 * k + 1];
       }
       loss_sh = sqrtf((float)((pos - neg) / ((double)p.N * (double)p.N)));
+      if (loss_ring && blockIdx.x == 0) {   // the update's loss value for the host (read back once per training step)
+        const long sl = slot[0];
+        if (sl < ring_len) loss_ring[sl] = loss_sh;
+      }
     }
   }
   const int TD = (p.D + 31) / 32;
@@ -419,17 +424,18 @@ extern "C" int zs3_mmd_fwd(const float* gen, int ldg, const float* real, int ldr
 }
 
 static int mmd_bwd_impl(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
-                        const float* loss, const double* tile_ws, const float* gout, float* dgen, int ldo, void* stream) {
+                        const float* loss, const double* tile_ws, const float* gout, float* dgen, int ldo, void* stream,
+                        float* loss_ring = nullptr, const long* slot = nullptr, int ring_len = 0) {
   MmdArgs a;
   float one = 1.f;
   if (mmd_fill(a, gen, ldg, real, ldr, N, D, &one, 1, (float*)G, nullptr)) return -1;
   const int TK = (N + 31) / 32, TD = (D + 31) / 32, T = (2 * N + 31) / 32;
   if (N % 128 == 0)
     hipLaunchKernelGGL(mmd_bwd_kernel<4>, dim3(TK * TD), dim3(256), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo, tile_ws,
-                       T * T);
+                       T * T, loss_ring, slot, ring_len);
   else
     hipLaunchKernelGGL(mmd_bwd_kernel<1>, dim3(TK * TD), dim3(64), 0, (hipStream_t)stream, a, loss, gout, dgen, ldo, tile_ws,
-                       T * T);
+                       T * T, loss_ring, slot, ring_len);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -440,9 +446,11 @@ extern "C" int zs3_mmd_bwd(const float* gen, int ldg, const float* real, int ldr
 }
 
 extern "C" int zs3_mmd_bwd_ws(const float* gen, int ldg, const float* real, int ldr, int N, int D, const float* G,
-                              const double* tile_ws, const float* gout, float* dgen, int ldo, void* stream) {
-  if (!tile_ws) return -1;
-  return mmd_bwd_impl(gen, ldg, real, ldr, N, D, G, nullptr, tile_ws, gout, dgen, ldo, stream);
+                              const double* tile_ws, const float* gout, float* dgen, int ldo, float* loss_ring,
+                              const void* slot_dev, int ring_len, void* stream) {
+  if (!tile_ws || (loss_ring && !slot_dev)) return -1;
+  return mmd_bwd_impl(gen, ldg, real, ldr, N, D, G, nullptr, tile_ws, gout, dgen, ldo, stream, loss_ring, (const long*)slot_dev,
+                      ring_len);
 }
 
 // End of one captured generator update: the MMD loss value from the tile sums into loss_ring[slot++], Adam step count

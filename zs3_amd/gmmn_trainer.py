@@ -152,6 +152,29 @@ class GMMNStep:
                     bmap.extend((e, c) for c in range((p.numel() + chunk - 1) // chunk))
                 st["adam_multi"] = (torch.tensor(recs, dtype=torch.int64).to(dev),
                                     torch.tensor(bmap, dtype=torch.int32).to(dev), len(bmap), groups[0])
+                # the same update fused into the weight-gradient launch (zs3_gmmn_mlp_wgrad_adam): per layer
+                # {weight, exp_avg, exp_avg_sq, bias, bias exp_avg, bias exp_avg_sq, f_pk, t_pk}; layer 1's transposed planes
+                # are never read (the generator's input needs no gradient) and are not maintained
+                def _state(lin, wp, with_t):
+                    sw, sb = opt.state[lin.weight], opt.state[lin.bias]
+                    ptrs = [lin.weight, sw["exp_avg"], sw["exp_avg_sq"], lin.bias, sb["exp_avg"], sb["exp_avg_sq"], wp.f_pk,
+                            wp.t_pk if with_t else None]
+                    return (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in ptrs])
+                st["adam_state2"], st["adam_state1"] = _state(lin2, st["wp2"], True), _state(lin1, st["wp1"], False)
+                st["done"] = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def _adam_signature(self):
+        """identity of everything the captured update holds raw pointers to / mirrors on the device"""
+        if not self.fused_adam:
+            return None
+        opt = self.optimizer_generator
+        sig = []
+        for group in opt.param_groups:
+            for p in group["params"]:
+                stt = opt.state.get(p, {})
+                sig.append((p.data_ptr(), stt["exp_avg"].data_ptr() if "exp_avg" in stt else 0,
+                            stt["exp_avg_sq"].data_ptr() if "exp_avg_sq" in stt else 0, int(stt["step"]) if "step" in stt else -1))
+        return tuple(sig)
 
     # ------------------------------------------------------------------ the fixed-shape sampled-row update
     def _sampled_update(self, training):
@@ -223,8 +246,11 @@ class GMMNStep:
         check(lib().zs3_mmd_fwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), self._sig, I(len(self.sigma)), P(gmat), P(tile),
                                 None, stream()), "zs3_mmd_fwd")          # the loss value is finalised by the update epilogue
         dgen = torch.empty_like(gen_s)
+        fused_adam = fused and st.get("adam_multi") is not None and st.get("adam_state2") is not None
+        # fused_adam: the loss value goes to loss_ring[slot] here, the counters are advanced by the wgrad + Adam launch
         check(lib().zs3_mmd_bwd_ws(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(tile), P(st["one"]), P(dgen), I(d),
-                                   stream()), "zs3_mmd_bwd_ws")
+                                   P(st["loss_ring"]) if fused_adam else None, P(st["slot_dev"]) if fused_adam else None,
+                                   I(st["loss_ring"].numel()), stream()), "zs3_mmd_bwd_ws")
         # generator backward on the sampled rows, gradients into static buffers
         if fused:
             dpre = torch.empty((s, wp1.cout), dtype=torch.float32, device=dgen.device)
@@ -232,6 +258,17 @@ class GMMNStep:
                                            P(dpre), I(wp1.cout), I(s), I(wp2.cin), I(wp2.cout), F(lrelu.negative_slope),
                                            F(drop.p if use_drop else 0.0), ctypes.c_ulonglong(dseed), P(st["seed_dev"]),
                                            stream()), "zs3_gmmn_mlp_dgrad")
+            if fused_adam:   # gradients consumed tile by tile: Adam, the new weights' bf16 planes and the update's counters
+                group = st["adam_multi"][3]
+                b1, b2 = group["betas"]
+                check(lib().zs3_gmmn_mlp_wgrad_adam(P(dgen), I(d), P(hd), I(hd.stride(0)), I(wp2.cout), I(wp2.cin), P(dpre),
+                                                    I(wp1.cout), P(x), I(width), I(wp1.cout), I(wp1.cin), I(s),
+                                                    st["adam_state2"], st["adam_state1"], I(wp2.cin_pad), I(wp2.cout_pad),
+                                                    I(wp1.cin_pad), I(wp1.cout_pad), F(group["lr"]), F(b1), F(b2),
+                                                    F(group["eps"]), F(group["weight_decay"]), P(st["slot_dev"]),
+                                                    P(st["step_dev"]), P(st["seed_dev"]), ctypes.c_long(1 << 24), P(st["done"]),
+                                                    stream()), "zs3_gmmn_mlp_wgrad_adam")
+                return
             check(lib().zs3_gmmn_mlp_wgrad(P(dgen), I(d), P(hd), I(hd.stride(0)), I(wp2.cout), I(wp2.cin), P(st["dw2"]),
                                            P(st["db2"]), P(dpre), I(wp1.cout), P(x), I(width), I(wp1.cout), I(wp1.cin),
                                            P(st["dw1"]), P(st["db1"]), I(s), stream()), "zs3_gmmn_mlp_wgrad")
@@ -302,6 +339,7 @@ class GMMNStep:
                 if p in opt.state and "step" in opt.state[p]:
                     opt.state[p]["step"] += count
         Fz.invalidate_planes(*[p for g_ in opt.param_groups for p in g_["params"]])
+        self._st["adam_sig"] = self._adam_signature()
 
     # ------------------------------------------------------------------ eager generator pieces (fallback + unseen images)
     def _generator_forward(self, x, training):
@@ -402,10 +440,13 @@ class GMMNStep:
             # high-priority stream: 101 ms -- HIP priority streams misbehave on this runtime, as in round 1)
         fh, fw, d = real.shape[1], real.shape[2], real.shape[3]
         npix = fh * fw
-        if self._st is None or self._st["shape"] != (b, npix):
+        if self._st is None or self._st["shape"] != (b, npix) or self._st.get("adam_sig") != self._adam_signature():
+            # (re)build the static buffers, pointer tables and captured updates: first call, another batch shape, or the
+            # generator's optimizer state was replaced behind our back (load_state_dict: new moment tensors, another step count)
             self._alloc(dev, b, npix)
             self._graph = None
             self._update_graphs = {}
+            self._st["adam_sig"] = self._adam_signature()
         st = self._st
         self._resplit()   # the generator may have been changed from outside (load_state_dict, another optimizer)
         real_rows = real.reshape(b, npix, d)
