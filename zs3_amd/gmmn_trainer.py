@@ -312,14 +312,14 @@ class GMMNStep:
 
     def _run_sampled_update(self, training, count=1):
         """`count` consecutive updates.  Table mode: every update reads its own row of the step's device table, so captured
-        chains of 8 / 4 / 2 / 1 updates are replayed back to back with no host work in between; otherwise one update."""
+        chains of 32 ... 1 updates are replayed back to back with no host work in between; otherwise one update."""
         if not self.use_graph:
             for _ in range(count):
                 self._sampled_update(training)
         else:
             table_mode = bool(self._st.get("table_mode"))
             left = count
-            for size in ((8, 4, 2, 1) if table_mode else (1,)):
+            for size in ((32, 16, 8, 4, 2, 1) if table_mode else (1,)):
                 while left >= size:
                     key = (training, self.noise, self.context_aware, table_mode, size)
                     g = self._update_graphs.get(key)
@@ -512,6 +512,8 @@ class GMMNStep:
         if n_mmd > st["ring"].shape[0]:
             st["ring"] = torch.zeros((n_mmd, self.bsg), dtype=torch.int64).pin_memory()
         st["ring_pos"] = 0
+        pending = 0        # table mode: sampled updates queued but not yet replayed
+        per_image_hook = type(self)._after_image is not GMMNStep._after_image
         for i in range(b):
             classes = [c for c in range(256) if hist_h[i][c] > 0]
             has_unseen = any(c in self.unseen for c in classes)
@@ -525,7 +527,9 @@ class GMMNStep:
             elif not table_mode:  # label 255 -> class 0 like the dataloader (base.py:47-48); those rows are never used
                 check(lib().zs3_gather_rows(P(table_f), I(self.embed_dim), P(tgt_cls[i]), P(st["emb"]), I(self.embed_dim),
                                             ctypes.c_long(npix), I(self.embed_dim), stream()), "zs3_gather_rows")
-            pending = 0        # table mode: sampled updates of this image, replayed together after its class loop
+            if has_unseen and pending:   # the eager generator calls below read the weights: every queued update first
+                self._run_sampled_update(training, pending)
+                pending = 0
             if use_real:
                 fake_rows[i].copy_(real_rows[i])
             else:
@@ -594,8 +598,11 @@ class GMMNStep:
                     slot += 1
                 if not use_real:
                     ops.scatter_rows(fake_c, idx_c, fake_rows[i])
-            if pending:
+            # table mode: the sampled updates of consecutive images are replayed together (a replay costs ~100 us of launch
+            # latency on top of its kernels: 48 replays per step became ~12), unless a subclass hooks in after every image
+            if pending and (per_image_hook or i == b - 1):
                 self._run_sampled_update(training, pending)
+                pending = 0
             self._after_image(i, tgt_l[i].view(fh, fw), real_rows[i], has_unseen)
         pg = None if self.group is True else self.group
         if self.group is not None:   # generator replicas -> their average (parameters only; Adam moments stay per rank)
