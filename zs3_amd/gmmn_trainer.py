@@ -539,6 +539,26 @@ class GMMNStep:
                 n_valid = npix - int(hist_h[i][255])
                 ctx = ops.colsum(ops.gather_rows(st["emb"], order[i, :n_valid])) / max(n_valid, 1)
                 st["z"].copy_(ctx.view(1, -1).expand(self.bsg, -1))
+            if has_unseen and self.fused_adam:
+                # No class of an image that contains an unseen class trains the generator (:224); all that is left of its
+                # class loop is "generate features for every labelled pixel" (:242).  Rows of the MLP are independent and
+                # `order` lists the pixels class by class, so ONE generator call over all labelled pixels replaces one per
+                # class (6 launches per image instead of 6 per class).  The CPU noise stream is drawn class by class in the
+                # reference's order.
+                n_valid = npix - int(hist_h[i][255])
+                if n_valid > 0:
+                    idx_all = order[i, :n_valid]
+                    if ctx is not None:
+                        z = ctx.view(1, -1).expand(n_valid, -1).contiguous()
+                    elif self.noise == "cpu":
+                        z = torch.cat([torch.rand((int(hist_h[i][c]), self.noise_dim)) for c in classes if c != 255]).to(dev)
+                    else:
+                        z = ops.uniform((n_valid, self.noise_dim), Fz.next_seed(), dev)
+                    x = ops.gather_cat(st["emb"], idx_all, self.embed_dim, z, self.noise_dim, self.embed_dim + self.noise_dim)
+                    fake_all, _, _, _ = self._generator_forward(x, training)
+                    if not use_real:
+                        ops.scatter_rows(fake_all, idx_all, fake_rows[i])
+                classes = []      # nothing left for the per-class loop below
             off = 0
             for c in classes:
                 n_c = int(hist_h[i][c])
