@@ -508,3 +508,34 @@ def test_streamk_launches_match_whole_tile_launches(dev):
         dx32 = ops.conv2d_dgrad(dy, wp, (h, h), 1, pad, d, tile_cfg=32)   # runs as whole tiles where stream-K does not apply
         assert rel(dx32, dx31) < 5e-6
     assert ops.streamk_errors() == 0
+
+
+@pytest.mark.parametrize("chunks,c", [(69, 256), (1057, 64), (4161, 64), (16513, 72), (2048, 8)])
+def test_bn_finalize_short_and_tall_partial_buffers(dev, chunks, c):
+    """zs3_bn_fwd_finalize / zs3_bn_bwd_finalize combine [chunks][2][C] fp32 partial sums in fp64; buffers of >= 2048 rows
+    (stem, layer1) take the 8-channel x 128-row-group kernel, the others 32 x 8.  Both against fp64 sums on the host
+    (batch_norm semantics of nn.BatchNorm2d in train mode: biased variance for the output, unbiased for running_var)."""
+    from zs3_amd import ops
+    g = torch.Generator().manual_seed(chunks + c)
+    part = torch.randn(chunks, 2, c, generator=g)
+    part[:, 1] = part[:, 1].abs() * 50 + 40          # sums of squares: keep the variance positive
+    count = float(chunks * 64)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    out = ops.bn_fwd_finalize(part.to(dev), count, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm_d, rv_d, nbt)
+    s, q = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    mean = s / count
+    var = (q / count - mean * mean).clamp_min(0)
+    istd = 1.0 / torch.sqrt(var + 1e-5)
+    for got, want in ((out[0], mean), (out[1], istd), (out[2], gamma.double() * istd), (out[3], beta.double() - mean * gamma.double() * istd)):
+        assert torch.allclose(got.double().cpu(), want, rtol=2e-6, atol=1e-6)
+    assert torch.allclose(rm_d.double().cpu(), 0.9 * rm.double() + 0.1 * mean, rtol=2e-6, atol=1e-6)
+    assert torch.allclose(rv_d.double().cpu(), 0.9 * rv.double() + 0.1 * var * count / (count - 1), rtol=2e-6, atol=1e-6)
+    assert int(nbt) == 1
+    dgamma, dbeta, c1, c2 = ops.bn_bwd_finalize(part.to(dev), count, True)
+    assert torch.allclose(dbeta.double().cpu(), s, rtol=2e-6, atol=1e-5)
+    assert torch.allclose(dgamma.double().cpu(), q, rtol=2e-6, atol=1e-5)
+    assert torch.allclose(c1.double().cpu(), s / count, rtol=2e-6, atol=1e-7)
+    assert torch.allclose(c2.double().cpu(), q / count, rtol=2e-6, atol=1e-7)

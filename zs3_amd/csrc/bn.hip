@@ -11,6 +11,7 @@
 // Replaces native_batch_norm fwd/bwd + relu_/threshold_backward + residual add_ at resnet.py:33-53,
 // aspp.py:25-29,111-116, decoder.py:30-32,15-24 (113 BN layers; numerics of F.batch_norm, i.e.
 // invstd = 1/sqrt(var_biased + eps), running_var uses the unbiased variance).
+#include <cstdlib>
 #include "common.h"
 #include "zs3hip.h"
 
@@ -108,18 +109,28 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
   }
 }
 
-// 32 channels per 256-thread block: thread (ty, tx) sums the partial rows ty, ty+8, ... of channel c0 + tx in fp64 (a
-// half-wave reads 128 contiguous bytes of a partial row), the eight row groups are combined through LDS in a fixed order
-// (deterministic); the result is valid in the threads with ty == 0.  (The previous one-wave-per-channel form read one
-// 4-byte value per lane with stride C: ~10 us per call, 226 calls on the step's dependent chain.)
-constexpr int FIN_CH = 32, FIN_GROUPS = 8;
+// FIN_CH channels x FIN_GROUPS row groups per block: thread (ty, tx) sums the partial rows ty, ty + FIN_GROUPS, ... of channel
+// c0 + tx in fp64, the row groups are combined through LDS in a fixed order (deterministic); the result is valid in the threads
+// with ty == 0.  Two shapes: 32 x 8 (256 threads; a half-wave reads 128 contiguous bytes of a partial row) for the usual short
+// partial buffers (69-1057 rows), and 8 x 128 (1024 threads) for the tall ones of the stem and layer1, whose conv kernels write
+// one partial row per 64 output rows (4161 / 16513 rows x 64-256 channels: with 32 x 8 that was 2-8 workgroups walking 520-2064
+// rows per thread -- 35-240 us per call, 1.6 ms of the step's dependent chain for 11 of the 113 BN layers).
+// (The first, one-wave-per-channel form read one 4-byte value per lane with stride C: ~10 us per call, 226 calls per step.)
+static int fin_tall_rows() {   // ZS3_BN_FIN_TALL=<rows> moves the switch (A/B runs); default 2048
+  static const int v = [] {
+    const char* e = getenv("ZS3_BN_FIN_TALL");
+    return e && atoi(e) > 0 ? atoi(e) : 2048;
+  }();
+  return v;
+}
+template <int FIN_CH, int FIN_GROUPS>
 __device__ __forceinline__ bool combine_partials(const float* partial, int chunks, int C, int& c, double& s, double& q) {
   __shared__ double red[2][FIN_GROUPS][FIN_CH];
   const int tx = threadIdx.x & (FIN_CH - 1), ty = threadIdx.x / FIN_CH;
   c = blockIdx.x * FIN_CH + tx;
   double ls = 0.0, lq = 0.0;
   if (c < C) {
-#pragma unroll 4
+#pragma unroll 8
     for (int k = ty; k < chunks; k += FIN_GROUPS) {
       ls += (double)partial[((size_t)k * 2 + 0) * C + c];
       lq += (double)partial[((size_t)k * 2 + 1) * C + c];
@@ -139,7 +150,8 @@ __device__ __forceinline__ bool combine_partials(const float* partial, int chunk
   return true;
 }
 
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* partial, int chunks, int C, double count,
+template <int FIN_CH, int FIN_GROUPS>
+__global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_fwd_finalize_kernel(const float* partial, int chunks, int C, double count,
                                                              const double* count_dev, const float* gamma, const float* beta, float eps,
                                                              float momentum, float* running_mean, float* running_var,
                                                              float* mean_out, float* invstd_out, float* scale_out,
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* parti
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   int c;
   double s, q;
-  const bool owner = combine_partials(partial, chunks, C, c, s, q);
+  const bool owner = combine_partials<FIN_CH, FIN_GROUPS>(partial, chunks, C, c, s, q);
   if (count_dev) count = *count_dev;  // cross-rank sample count produced on the device by the SyncBN all-reduce
   if (owner) {
     double mean = s / count;
@@ -181,12 +193,13 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
   shift_out[c] = b - rm[c] * g * invstd;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int chunks, int C, double count,
+template <int FIN_CH, int FIN_GROUPS>
+__global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_bwd_finalize_kernel(const float* partial, int chunks, int C, double count,
                                                              const double* count_dev, float* dgamma, float* dbeta, float* c1, float* c2,
                                                              int use_batch_stats) {
   int c;
   double s, q;
-  const bool owner = combine_partials(partial, chunks, C, c, s, q);
+  const bool owner = combine_partials<FIN_CH, FIN_GROUPS>(partial, chunks, C, c, s, q);
   if (count_dev) count = *count_dev;
   if (owner) {
     if (dbeta) dbeta[c] = (float)s;
@@ -373,9 +386,14 @@ extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, doub
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_out, float* invstd_out, float* scale_out,
                                    float* shift_out, long* num_batches_tracked, void* stream) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
-                     count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
-                     shift_out, num_batches_tracked);
+  if (chunks >= fin_tall_rows())
+    hipLaunchKernelGGL((bn_fwd_finalize_kernel<8, 128>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, chunks, C,
+                       count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
+                       shift_out, num_batches_tracked);
+  else
+    hipLaunchKernelGGL((bn_fwd_finalize_kernel<32, 8>), dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+                       count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
+                       shift_out, num_batches_tracked);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -390,8 +408,12 @@ extern "C" int zs3_bn_eval_affine(const float* gamma, const float* beta, const f
 extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
                                    float* dgamma, float* dbeta,
                                    float* c1, float* c2, int use_batch_stats, void* stream) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
-                     count, count_dev, dgamma, dbeta, c1, c2, use_batch_stats);
+  if (chunks >= fin_tall_rows())
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, 128>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, chunks, C,
+                       count, count_dev, dgamma, dbeta, c1, c2, use_batch_stats);
+  else
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<32, 8>), dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+                       count, count_dev, dgamma, dbeta, c1, c2, use_batch_stats);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -263,22 +263,52 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
   const int t = blockIdx.x - q.tile0;
   const int tco = t / q.tiles_ci, tci = t - tco * q.tiles_ci;
   const int co0 = tco * WG_T, ci0 = tci * WG_T;
-  for (int i = tid; i < 128 * (WG_T / 4); i += 256) {
-    const int r = i / (WG_T / 4), c = (i - r * (WG_T / 4)) * 4;
-    f4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-    if (r < p.R) {
-      if (co0 + c < q.co) vy = *reinterpret_cast<const f4*>(q.dy + (size_t)r * q.ldy + co0 + c);   // co, ci: multiples of 4
-      if (ci0 + c < q.ci) vx = *reinterpret_cast<const f4*>(q.x + (size_t)r * q.ldx + ci0 + c);
+  {
+    // one burst: all 16 loads of the thread are in flight before the first LDS store (a load -> store loop would pay the
+    // HBM/L2 latency 8 times over; this kernel's whole budget is a few of those)
+    const int c = (tid & 15) * 4, r0 = tid >> 4;      // 16 threads per row, 16 rows per pass
+    f4 vy[8], vx[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = r0 + it * 16;
+      vy[it] = f4{0.f, 0.f, 0.f, 0.f};
+      vx[it] = f4{0.f, 0.f, 0.f, 0.f};
+      if (r < p.R) {
+        if (co0 + c < q.co) vy[it] = *reinterpret_cast<const f4*>(q.dy + (size_t)r * q.ldy + co0 + c);   // co, ci: multiples of 4
+        if (ci0 + c < q.ci) vx[it] = *reinterpret_cast<const f4*>(q.x + (size_t)r * q.ldx + ci0 + c);
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      Ys[r * WG_LD + c + e] = vy[e];
-      Xs[r * WG_LD + c + e] = vx[e];
+    for (int it = 0; it < 8; ++it) {
+      const int r = r0 + it * 16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Ys[r * WG_LD + c + e] = vy[it][e];
+        Xs[r * WG_LD + c + e] = vx[it][e];
+      }
     }
   }
-  __syncthreads();
   const int wi = wave >> 1, wj = wave & 1;
   const int m16 = lane & 15, kg = lane >> 4;
+  // fused Adam: the thread's 4 x 4 weights and moments are requested now, so that their L2 / HBM round trip runs under the
+  // staging and the MFMAs instead of in front of the epilogue (the loads below cannot be hoisted by the compiler: the
+  // epilogue's stores may alias them)
+  f4 w_old[2][2], m_old[2][2], v_old[2][2];
+  if (ADAM) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wi * 32 + i * 16 + m16, ci = ci0 + wj * 32 + j * 16 + kg * 4;
+        if (co < q.co && ci < q.ci) {
+          const size_t idx = (size_t)co * q.ci + ci;
+          w_old[i][j] = *reinterpret_cast<const f4*>(q.w + idx);
+          m_old[i][j] = *reinterpret_cast<const f4*>(q.wm + idx);
+          v_old[i][j] = *reinterpret_cast<const f4*>(q.wv + idx);
+        }
+      }
+  }
+  __syncthreads();
   f4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -298,13 +328,15 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
       split8(ya, a_hi[f], a_lo[f]);
       split8(xb, b_hi[f], b_lo[f]);
     }
+    // the x fragment is the MFMA's row operand: a lane then holds FOUR CONSECUTIVE ci of one co (C layout: row =
+    // (lane >> 4) * 4 + e, col = lane & 15), i.e. 16 contiguous bytes of dw / weight / moment rows and 8 of the f_pk plane
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_lo[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
       }
   }
   float bc1 = 1.f, bc2_sqrt = 1.f;
@@ -317,34 +349,43 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int ci = ci0 + wj * 32 + j * 16 + m16;
+      const int co = co0 + wi * 32 + i * 16 + m16;
+      const int ci = ci0 + wj * 32 + j * 16 + kg * 4;   // ci .. ci + 3 (channel counts are multiples of 4)
+      if (co >= q.co || ci >= q.ci) continue;
+      const size_t idx = (size_t)co * q.ci + ci;
+      if (!ADAM) {
+        *reinterpret_cast<f4*>(q.dw + idx) = acc[i][j];
+        continue;
+      }
+      // the tile's gradient never leaves the registers: Adam on four weights, then their bf16 hi/lo planes
+      f4 w = w_old[i][j], m = m_old[i][j], v = v_old[i][j];
+      unsigned short h[4], l[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int co = co0 + wi * 32 + i * 16 + kg * 4 + e;
-        if (co < q.co && ci < q.ci) {
-          const size_t idx = (size_t)co * q.ci + ci;
-          if (!ADAM) {
-            q.dw[idx] = acc[i][j][e];
-          } else {   // the tile's gradient never leaves the registers: Adam + the bf16 hi/lo planes of the new weight
-            float w = q.w[idx], m = q.wm[idx], v = q.wv[idx];
-            adam_update(acc[i][j][e], w, m, v, p.lr, p.b1, p.b2, p.eps, p.wd, bc1, bc2_sqrt);
-            q.w[idx] = w;
-            q.wm[idx] = m;
-            q.wv[idx] = v;
-            const unsigned short h = f32_to_bf16_rne(w);
-            const unsigned short l = f32_to_bf16_rne(w - bf16_bits_to_f32(h));
-            q.f_pk[packed_index(co, ci, q.cin_pad, 0)] = h;
-            q.f_pk[packed_index(co, ci, q.cin_pad, 1)] = l;
-            if (q.t_pk) {
-              q.t_pk[packed_index(ci, co, q.cout_pad, 0)] = h;
-              q.t_pk[packed_index(ci, co, q.cout_pad, 1)] = l;
-            }
-          }
+        float we = w[e], me = m[e], ve = v[e];
+        adam_update(acc[i][j][e], we, me, ve, p.lr, p.b1, p.b2, p.eps, p.wd, bc1, bc2_sqrt);
+        w[e] = we; m[e] = me; v[e] = ve;
+        h[e] = f32_to_bf16_rne(we);
+        l[e] = f32_to_bf16_rne(we - bf16_bits_to_f32(h[e]));
+      }
+      *reinterpret_cast<f4*>(q.w + idx) = w;
+      *reinterpret_cast<f4*>(q.wm + idx) = m;
+      *reinterpret_cast<f4*>(q.wv + idx) = v;
+      const u32x2 hp = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+      const u32x2 lp = {(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+      *reinterpret_cast<u32x2*>(q.f_pk + packed_index(co, ci, q.cin_pad, 0)) = hp;   // 4 consecutive k of one 32-chunk
+      *reinterpret_cast<u32x2*>(q.f_pk + packed_index(co, ci, q.cin_pad, 1)) = lp;
+      if (q.t_pk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          q.t_pk[packed_index(ci + e, co, q.cout_pad, 0)] = h[e];
+          q.t_pk[packed_index(ci + e, co, q.cout_pad, 1)] = l[e];
         }
       }
     }
   if (tci == 0 && tid < WG_T && co0 + tid < q.co) {   // bias gradient: column sums of dy, rows in order
-    float s = 0.f;
+    float s = 0.f;   // rows in order (one chain: the order is part of the result)
+#pragma unroll 16
     for (int r = 0; r < p.R; ++r) s += Ys[r * WG_LD + tid];
     if (!ADAM) {
       if (q.db) q.db[co0 + tid] = s;

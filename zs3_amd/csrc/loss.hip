@@ -279,16 +279,32 @@ __global__ __launch_bounds__(64 * W) void mmd_bwd_kernel(const MmdArgs p, const 
   __shared__ float loss_sh;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   if (tile_ws) {   // loss from the tile partial sums (same serial order as mmd_finalize_kernel): saves a launch in the chain
-    if (threadIdx.x == 0) {
+    // The LAST wave does it while the others already stream their operands; its lanes fetch 64 tiles' sums in one burst
+    // (a one-thread loop over global memory costs a dependent L2 round trip every few tiles: ~8 us of this kernel's 13),
+    // and lane 0 adds them from LDS in the serial order.
+    __shared__ double tsum[2][64];
+    if (w == W - 1) {
       double pos = 0.0, neg = 0.0;
-      for (int k = 0; k < ntiles; ++k) {
-        pos += tile_ws[2 * k];
-        neg += tile_ws[2 * k + 1];
+      for (int base = 0; base < ntiles; base += 64) {
+        const int kt = base + lane;
+        tsum[0][lane] = kt < ntiles ? tile_ws[2 * kt] : 0.0;
+        tsum[1][lane] = kt < ntiles ? tile_ws[2 * kt + 1] : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          const int n = ntiles - base < 64 ? ntiles - base : 64;
+          for (int kk = 0; kk < n; ++kk) {
+            pos += tsum[0][kk];
+            neg += tsum[1][kk];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      loss_sh = sqrtf((float)((pos - neg) / ((double)p.N * (double)p.N)));
-      if (loss_ring && blockIdx.x == 0) {   // the update's loss value for the host (read back once per training step)
-        const long sl = slot[0];
-        if (sl < ring_len) loss_ring[sl] = loss_sh;
+      if (lane == 0) {
+        loss_sh = sqrtf((float)((pos - neg) / ((double)p.N * (double)p.N)));
+        if (loss_ring && blockIdx.x == 0) {   // the update's loss value for the host (read back once per training step)
+          const long sl = slot[0];
+          if (sl < ring_len) loss_ring[sl] = loss_sh;
+        }
       }
     }
   }
