@@ -134,6 +134,14 @@ int zs3_bilinear_fwd(const float* x, int ldx, float* out, int ldo, int N, int H,
                      void* stream);
 int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int H, int W, int Ho, int Wo, int C,
                      int accumulate, void* stream);
+/* The end of the training step fused (deeplab.py:44,55 upsample + loss.py:31-46 CE, backward): d(loss)/d(lr) for
+ * loss = CE(bilinear(lr -> Ho x Wo, align_corners=True), target) without the full-resolution gradient ever existing.  One
+ * thread per low-resolution pixel re-samples the scores of the <= 7x7 output pixels it contributes to (the arithmetic of
+ * zs3_bilinear_fwd), takes their softmax and accumulates in zs3_bilinear_bwd's order.  lr: [N,H,W,C] (C <= 64), target:
+ * float32 or int64 [N,Ho,Wo], loss_ws / gout / batch / ignore_index as for zs3_ce_bwd, dlr: [N,H,W,C] with row stride ldo. */
+int zs3_ce_bilinear_bwd(const float* lr, int ldx, const void* target, int target_is_i64, const float* weight, int N, int H,
+                        int W, int Ho, int Wo, int C, int ignore_index, int batch, const float* loss_ws, const float* gout,
+                        float* dlr, int ldo, void* stream);
 /* Validation without shipping logits to the host (train_pascal.py:130-134, Evaluator._generate_matrix metrics.py:73-79):
  * conf[gt*C + pred] += 1 for every target pixel with 0 <= gt < C, pred = first argmax over the C channels of x
  * [N,H,W,C] bilinearly resized (align_corners=True, same arithmetic as zs3_bilinear_fwd) to Ho x Wo -- pass the
@@ -179,10 +187,11 @@ int zs3_gmmn_update_epilogue(const double* tile_ws, int N, float* loss_ring, voi
 /* table-driven update (no host argument per replay): row u = upd_dev[0] of `table` ([S sample indices | order offset | pixel
  * base], int64, row stride ld_table) selects the (image, class); writes x[j] = [emb[base + order[offset + ridx[j]]] | noise
  * keyed on ridx[j]], pix_global[j] (row of the real features) and key[j] = ridx[j].  Replaces zs3_sample_rows + the
- * per-update host-to-device copy of the sample indices + zs3_gather_cat_noise. */
+ * per-update host-to-device copy of the sample indices + zs3_gather_cat_noise.  adam_bc (optional): receives Adam's bias
+ * corrections {1 - b1^t, sqrt(1 - b2^t)}, t = adam_step_dev[0] + 1, of this update for zs3_gmmn_mlp_wgrad_adam. */
 int zs3_gmmn_prep(const long* table, int ld_table, const void* upd_dev, const long* order, const float* emb, int ld_emb,
                   int Ca, int Cb, float* x, int ldx, long* pix_global, long* key, int S, unsigned long long seed,
-                  const void* seed_dev, void* stream);
+                  const void* seed_dev, const void* adam_step_dev, float b1, float b2, float* adam_bc, void* stream);
 int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, const long* key, int Ca, int Cb, const void* w_pk,
                       int kchunks, const float* bias, float* x_out, int ldx, float* h, float* hd, int ldo, int M, int N,
                       float leak, float p_drop, unsigned long long seed_noise, unsigned long long seed_drop,
@@ -199,12 +208,13 @@ int zs3_gmmn_mlp_wgrad(const float* dy2, int ldy2, const float* x2, int ldx2, in
  * weight gradient is consumed where it is produced -- Adam moments and weight updated, the weight's bf16 hi/lo operand planes
  * rewritten -- and the last workgroup to finish advances the device-resident counters of the captured update: slot_dev += 1,
  * step_dev += 1, seed_dev += seed_inc.  state2 / state1: 8 device pointers per layer (HOST arrays): {weight, exp_avg,
- * exp_avg_sq, bias, bias exp_avg, bias exp_avg_sq, f_pk, t_pk}; done_dev: a zeroed uint32 arrival counter (left zero). */
+ * exp_avg_sq, bias, bias exp_avg, bias exp_avg_sq, f_pk, t_pk}; done_dev: a zeroed uint32 arrival counter (left zero);
+ * adam_bc: the two bias corrections written by zs3_gmmn_prep for this update, or NULL (then every thread computes them). */
 int zs3_gmmn_mlp_wgrad_adam(const float* dy2, int ldy2, const float* x2, int ldx2, int co2, int ci2, const float* dy1,
                             int ldy1, const float* x1, int ldx1, int co1, int ci1, int R, const void* const* state2,
                             const void* const* state1, int cin_pad2, int cout_pad2, int cin_pad1, int cout_pad1, float lr,
                             float b1, float b2, float eps, float wd, void* slot_dev, void* step_dev, void* seed_dev,
-                            long seed_inc, void* done_dev, void* stream);
+                            long seed_inc, void* done_dev, const float* adam_bc, void* stream);
 
 /* ---- GMMN step helpers and optimisers (misc.hip) ---------------------------------------------- */
 /* nn.Dropout (aspp.py:100, decoder.py:19,23, gmmn.py:20): y = keep ? x/(1-p) : 0 with a counter-based mask
@@ -238,6 +248,13 @@ int zs3_counter_add2(void* c0, long v0, void* c1, long v1, void* stream);
 /* pix_local[j] = order[ridx[j]], pix_global[j] = pix_local[j] + base (the sampled rows of train_pascal_GMMN.py:229-231) */
 int zs3_sample_rows(const long* order, const long* ridx, long base, long* pix_local, long* pix_global, int s,
                     void* stream);
+/* The label bookkeeping at the head of a GMMN step in one launch (train_pascal_GMMN.py:175-180 nearest resize of the label
+ * maps, :183 unique classes, :226 per-class pixel lists): target [B][H][W] float32 or int64 -> tgt_l [B][ho*wo] int64 (values
+ * outside 0..255 become 255), tgt_cls (255 -> 0, the dataloader's embedding class, datasets/base.py:47-48), hist [B][256]
+ * int64 class histogram, order [B][ho*wo] int64 = the pixels of every image grouped by class in ascending pixel order (a stable
+ * argsort of tgt_l). */
+int zs3_label_order(const void* target, int target_is_i64, int B, int H, int W, int ho, int wo, long* tgt_l, long* tgt_cls,
+                    long* hist, long* order, void* stream);
 /* F.interpolate(mode="nearest") of one [C][H][W] image into pixel rows [ho*wo][ldo] (train_pascal_GMMN.py:175-195) */
 int zs3_nearest_rows(const float* src, int C, int H, int W, int ho, int wo, float* rows, int ldo, void* stream);
 /* out[r] = [a[idx[r]][0:Ca] | b[r][0:Cb] | 0...]: torch.cat((embd, noise), 1) of gmmn.py:44 fused with the class mask */

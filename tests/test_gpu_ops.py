@@ -272,6 +272,15 @@ def test_dropout_statistics_and_backward(dev):
     Fz.manual_seed(123)
     y2 = Fz.dropout(x, 0.5, True)
     assert torch.equal(y2, y)  # the mask is a pure function of the seed
+    # the float4 kernel (C % 4 == 0, 16-byte aligned rows) draws the mask of the scalar kernel: same data at a 4-byte offset
+    from zs3_amd import ops
+    g = torch.Generator().manual_seed(4)
+    src = torch.randn(1000, 256, generator=g).to(dev)
+    shifted = torch.empty(1000 * 256 + 1, device=dev)[1:].view(1000, 256)
+    shifted.copy_(src)
+    rows = torch.randint(0, 5000, (1000,), generator=g).to(dev)
+    for kw in ({}, {"row_idx": rows}):
+        assert torch.equal(ops.dropout(src, 0.3, 777, **kw), ops.dropout(shifted, 0.3, 777, **kw))
 
 
 @pytest.mark.parametrize("classes,hw,HW", [(21, (33, 33), (129, 129)), (60, (17, 19), (65, 73)), (21, (40, 40), (40, 40))])
@@ -539,3 +548,70 @@ def test_bn_finalize_short_and_tall_partial_buffers(dev, chunks, c):
     assert torch.allclose(dgamma.double().cpu(), q, rtol=2e-6, atol=1e-5)
     assert torch.allclose(c1.double().cpu(), s / count, rtol=2e-6, atol=1e-7)
     assert torch.allclose(c2.double().cpu(), q / count, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("classes,tdtype,padded", [(21, torch.float32, True), (60, torch.int64, True), (5, torch.int64, False),
+                                                   (21, torch.int64, False)])
+def test_fused_ce_upsample_backward(dev, classes, tdtype, padded):
+    """zs3_ce_bilinear_bwd (CE backward + align_corners upsample backward in one launch, taken when the criterion receives the
+    tensor DeepLab tagged with its low-resolution scores) against the two-kernel path and against fp64 torch on the host
+    (deeplab.py:44,55 + loss.py:31-46)."""
+    import torch.nn.functional as F
+    from zs3_amd import functional as Fz
+    from zs3_amd import ops
+    from zs3_amd.utils import loss as L
+    g = torch.Generator().manual_seed(classes)
+    n, h, w, H, W = 2, 17, 19, 65, 73
+    cp = (classes + 7) // 8 * 8 if padded else classes
+    base = (torch.randn(n, h, w, cp, generator=g) * 3).to(dev)
+    target = torch.randint(0, classes, (n, H, W), generator=g)
+    target[0, :5] = 255
+    target[1, 10:20, 30:] = 255
+    weight = torch.rand(classes, generator=g) + 0.5
+    weight[3] = 100.0
+    grads, losses = [], []
+    for fuse in (True, False):
+        lr = base.clone()[..., :classes].requires_grad_()
+        out = ops.nchw(Fz.bilinear(lr, (H, W)))
+        if fuse:
+            out._zs3_lowres = lr
+        loss = L.cross_entropy_2d(out, target.to(dev).to(tdtype), weight.to(dev))
+        loss.backward()
+        assert lr.grad is not None and lr.grad.shape == lr.shape
+        grads.append(lr.grad.detach().clone())
+        losses.append(loss.item())
+    assert losses[0] == losses[1]
+    scale = grads[1].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() < 2e-6 * scale       # same arithmetic, fused
+    ref = base[..., :classes].double().cpu().permute(0, 3, 1, 2).requires_grad_()
+    up = F.interpolate(ref, size=(H, W), mode="bilinear", align_corners=True)
+    lref = F.cross_entropy(up, target, weight=weight.double(), ignore_index=255, reduction="mean") / n
+    lref.backward()
+    assert abs(losses[0] - lref.item()) < 1e-5 * abs(lref.item())
+    gref = ref.grad.permute(0, 2, 3, 1)
+    assert (grads[0].double().cpu() - gref).abs().max().item() < 1e-4 * gref.abs().max().item()
+    # the tag does not survive a view: that takes the two-kernel path (and still gives the same gradient)
+    lr = base.clone()[..., :classes].requires_grad_()
+    out = ops.nchw(Fz.bilinear(lr, (H, W)))
+    out._zs3_lowres = lr
+    L.cross_entropy_2d(out[:, :, :, :], target.to(dev).to(tdtype), weight.to(dev)).backward()
+    assert (lr.grad - grads[1]).abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("shape,size,tdtype", [((3, 513, 513), (129, 129), torch.float32), ((2, 65, 73), (17, 19), torch.int64),
+                                               ((1, 40, 40), (40, 40), torch.float32), ((2, 30, 50), (33, 35), torch.float32)])
+def test_label_order_matches_torch_sequence(dev, shape, size, tdtype):
+    """zs3_label_order = nearest resize of the label maps + class histogram + stable argsort by class (the head of
+    train_pascal_GMMN.py's step: :175-183, :226) -- exact integer results against the torch ops it replaces."""
+    import torch.nn.functional as F
+    from zs3_amd import ops
+    g = torch.Generator().manual_seed(shape[1])
+    target = torch.randint(0, 21, shape, generator=g)
+    target[torch.rand(shape, generator=g) < 0.1] = 255
+    target[0, : shape[1] // 3] = 7                     # long runs of one class (whole waves with a single label)
+    tgt_l, tgt_cls, hist, order = ops.label_order(target.to(dev).to(tdtype), size)
+    want = F.interpolate(target[:, None].float(), size=size, mode="nearest")[:, 0].long().reshape(shape[0], -1)
+    assert torch.equal(tgt_l.cpu(), want)
+    assert torch.equal(tgt_cls.cpu(), torch.where(want == 255, torch.zeros_like(want), want))
+    assert torch.equal(hist.cpu(), torch.stack([torch.bincount(r, minlength=256) for r in want]))
+    assert torch.equal(order.cpu(), torch.argsort(want, dim=1, stable=True))

@@ -310,19 +310,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
 }
 
 // out[g][c] = scale * sum_{r<R} x[(g*R + r)][c]     (global average pool, pooled-branch backward)
+// (64 channel quads per block left the ASPP pool -- 16 images x 2048 channels x 1089 pixels, 143 MB -- with 128 workgroups of
+// 272-row serial chains: 154 us; 16 quads per block = 512 workgroups, 68 rows per thread.)
+constexpr int GCS_TX = 16;
 __global__ __launch_bounds__(256) void group_colsum_kernel(const float* x, int ldx, int R, int C, float scale, float* out,
                                                           int ldo) {
   __shared__ float red[256 * 4];
   const int c4n = C >> 2;
-  const int tx_n = c4n < 64 ? c4n : 64;
+  const int tx_n = c4n < GCS_TX ? c4n : GCS_TX;   // 16 lanes x 16 B = 256 contiguous bytes of a row; 16 row groups per block
   const int ty_n = 256 / tx_n;
   const int tid = threadIdx.x, tx = tid % tx_n, ty = tid / tx_n;
   const int g = blockIdx.y;
   const int cq = blockIdx.x * tx_n + tx;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   const bool ok = ty < ty_n && cq < c4n;
-  if (ok)
+  if (ok) {
+#pragma unroll 8
     for (int r = ty; r < R; r += ty_n) s += *reinterpret_cast<const f32x4*>(x + ((size_t)g * R + r) * ldx + cq * 4);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) red[tid * 4 + k] = ok ? s[k] : 0.f;
   __syncthreads();
@@ -450,7 +455,7 @@ extern "C" int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, fl
   if (C % 4 || ldx % 4 || ldo % 4) return -1;
   if (G <= 0) return 0;
   int c4n = C / 4;
-  int tx_n = c4n < 64 ? c4n : 64;
+  int tx_n = c4n < GCS_TX ? c4n : GCS_TX;
   dim3 grid((c4n + tx_n - 1) / tx_n, G);
   hipLaunchKernelGGL(group_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, scale, out, ldo);
   return ZS3_LAUNCH_CHECK();

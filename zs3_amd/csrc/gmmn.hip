@@ -233,6 +233,7 @@ struct WgArgs {
   // fused Adam + end-of-update bookkeeping
   float lr, b1, b2, eps, wd;
   const long* step;        // Adam step count before this update
+  const float* bc;         // {1 - b1^t, sqrt(1 - b2^t)} of this update from zs3_gmmn_prep, or null (computed here)
   long* counters[3];       // slot (update index of the step), step, seed: advanced by the last workgroup to finish
   long seed_inc;
   unsigned* done;          // arrival counter (zero between launches)
@@ -263,36 +264,24 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
   const int t = blockIdx.x - q.tile0;
   const int tco = t / q.tiles_ci, tci = t - tco * q.tiles_ci;
   const int co0 = tco * WG_T, ci0 = tci * WG_T;
-  {
-    // one burst: all 16 loads of the thread are in flight before the first LDS store (a load -> store loop would pay the
-    // HBM/L2 latency 8 times over; this kernel's whole budget is a few of those)
-    const int c = (tid & 15) * 4, r0 = tid >> 4;      // 16 threads per row, 16 rows per pass
-    f4 vy[8], vx[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = r0 + it * 16;
-      vy[it] = f4{0.f, 0.f, 0.f, 0.f};
-      vx[it] = f4{0.f, 0.f, 0.f, 0.f};
-      if (r < p.R) {
-        if (co0 + c < q.co) vy[it] = *reinterpret_cast<const f4*>(q.dy + (size_t)r * q.ldy + co0 + c);   // co, ci: multiples of 4
-        if (ci0 + c < q.ci) vx[it] = *reinterpret_cast<const f4*>(q.x + (size_t)r * q.ldx + ci0 + c);
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = r0 + it * 16;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Ys[r * WG_LD + c + e] = vy[it][e];
-        Xs[r * WG_LD + c + e] = vx[it][e];
-      }
-    }
-  }
   const int wi = wave >> 1, wj = wave & 1;
   const int m16 = lane & 15, kg = lane >> 4;
-  // fused Adam: the thread's 4 x 4 weights and moments are requested now, so that their L2 / HBM round trip runs under the
-  // staging and the MFMAs instead of in front of the epilogue (the loads below cannot be hoisted by the compiler: the
-  // epilogue's stores may alias them)
+  // ONE burst of independent loads: the 16 staging loads of the thread and (fused Adam) its 4 x 4 weights and moments are all
+  // in flight before the first LDS store.  Branch-free on purpose: out-of-range rows / columns read row 0 / column 0 and are
+  // zeroed by a select afterwards -- with the loads under `if`s the compiler waited for each one before issuing the next
+  // (16 dependent L2 round trips: 10 of this kernel's 18 us).
+  const int c = (tid & 15) * 4, r0 = tid >> 4;      // 16 threads per row, 16 rows per pass
+  const bool cy_ok = co0 + c < q.co, cx_ok = ci0 + c < q.ci;   // co, ci: multiples of 4
+  const float* ybase = q.dy + (cy_ok ? co0 + c : 0);
+  const float* xbase = q.x + (cx_ok ? ci0 + c : 0);
+  f4 vy[8], vx[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = r0 + it * 16;
+    const size_t rr = r < p.R ? (size_t)r : 0;
+    vy[it] = *reinterpret_cast<const f4*>(ybase + rr * q.ldy);
+    vx[it] = *reinterpret_cast<const f4*>(xbase + rr * q.ldx);
+  }
   f4 w_old[2][2], m_old[2][2], v_old[2][2];
   if (ADAM) {
 #pragma unroll
@@ -300,13 +289,21 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int co = co0 + wi * 32 + i * 16 + m16, ci = ci0 + wj * 32 + j * 16 + kg * 4;
-        if (co < q.co && ci < q.ci) {
-          const size_t idx = (size_t)co * q.ci + ci;
-          w_old[i][j] = *reinterpret_cast<const f4*>(q.w + idx);
-          m_old[i][j] = *reinterpret_cast<const f4*>(q.wm + idx);
-          v_old[i][j] = *reinterpret_cast<const f4*>(q.wv + idx);
-        }
+        const size_t idx = (co < q.co && ci < q.ci) ? (size_t)co * q.ci + ci : 0;   // out of range: element 0, never used
+        w_old[i][j] = *reinterpret_cast<const f4*>(q.w + idx);
+        m_old[i][j] = *reinterpret_cast<const f4*>(q.wm + idx);
+        v_old[i][j] = *reinterpret_cast<const f4*>(q.wv + idx);
       }
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = r0 + it * 16;
+    const bool r_ok = r < p.R;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Ys[r * WG_LD + c + e] = (r_ok && cy_ok) ? vy[it][e] : 0.f;
+      Xs[r * WG_LD + c + e] = (r_ok && cx_ok) ? vx[it][e] : 0.f;
+    }
   }
   __syncthreads();
   f4 acc[2][2];
@@ -341,9 +338,14 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
   }
   float bc1 = 1.f, bc2_sqrt = 1.f;
   if (ADAM) {
-    const double st = (double)(p.step[0] + 1);
-    bc1 = (float)(1.0 - pow((double)p.b1, st));
-    bc2_sqrt = (float)sqrt(1.0 - pow((double)p.b2, st));
+    if (p.bc) {           // computed once per update by zs3_gmmn_prep
+      bc1 = p.bc[0];
+      bc2_sqrt = p.bc[1];
+    } else {
+      const double st = (double)(p.step[0] + 1);
+      bc1 = (float)(1.0 - pow((double)p.b1, st));
+      bc2_sqrt = (float)sqrt(1.0 - pow((double)p.b2, st));
+    }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -421,7 +423,16 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const WgArgs p) {
 __global__ __launch_bounds__(256) void gmmn_prep_kernel(const long* table, int ld_table, const long* upd, const long* order,
                                                         const float* emb, int ld_emb, int Ca, int Cb, float* x, int ldx,
                                                         long* pix_global, long* key, int S, unsigned long long seed,
-                                                        const unsigned long long* seed_dev) {
+                                                        const unsigned long long* seed_dev, const long* adam_step, float b1,
+                                                        float b2, float* adam_bc) {
+  // Adam's bias corrections of THIS update (torch: 1 - beta ** step in Python doubles): one thread of this latency-bound
+  // launch computes them for the 14 k threads of the weight-gradient launch, where the two double-precision pow() calls per
+  // thread were 10 % of the instruction stream
+  if (adam_bc && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double st = (double)(adam_step[0] + 1);
+    adam_bc[0] = (float)(1.0 - pow((double)b1, st));
+    adam_bc[1] = (float)sqrt(1.0 - pow((double)b2, st));
+  }
   const long* row = table + upd[0] * ld_table;
   const int j = blockIdx.x;
   const long r = row[j], base = row[S + 1];
@@ -449,11 +460,13 @@ __global__ __launch_bounds__(256) void gmmn_prep_kernel(const long* table, int l
 
 extern "C" int zs3_gmmn_prep(const long* table, int ld_table, const void* upd_dev, const long* order, const float* emb,
                              int ld_emb, int Ca, int Cb, float* x, int ldx, long* pix_global, long* key, int S,
-                             unsigned long long seed, const void* seed_dev, void* stream) {
+                             unsigned long long seed, const void* seed_dev, const void* adam_step_dev, float b1, float b2,
+                             float* adam_bc, void* stream) {
   if (S <= 0) return 0;
-  if ((Ca & 3) || (Cb & 3) || (ld_emb & 3) || (ldx & 3) || ld_table < S + 2 || !upd_dev) return -1;
+  if ((Ca & 3) || (Cb & 3) || (ld_emb & 3) || (ldx & 3) || ld_table < S + 2 || !upd_dev || (adam_bc && !adam_step_dev)) return -1;
   hipLaunchKernelGGL(gmmn_prep_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, table, ld_table, (const long*)upd_dev, order,
-                     emb, ld_emb, Ca, Cb, x, ldx, pix_global, key, S, seed, (const unsigned long long*)seed_dev);
+                     emb, ld_emb, Ca, Cb, x, ldx, pix_global, key, S, seed, (const unsigned long long*)seed_dev,
+                     (const long*)adam_step_dev, b1, b2, adam_bc);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -534,7 +547,7 @@ extern "C" int zs3_gmmn_mlp_wgrad_adam(const float* dy2, int ldy2, const float* 
                                        const void* const* state2, const void* const* state1, int cin_pad2, int cout_pad2,
                                        int cin_pad1, int cout_pad1, float lr, float b1, float b2, float eps, float wd,
                                        void* slot_dev, void* step_dev, void* seed_dev, long seed_inc, void* done_dev,
-                                       void* stream) {
+                                       const float* adam_bc, void* stream) {
   if (R <= 0 || R > 128 || !state2 || !state1 || !slot_dev || !step_dev || !seed_dev || !done_dev) return -1;
   if ((ldy2 | ldx2 | co2 | ci2 | ldy1 | ldx1 | co1 | ci1) & 3) return -1;
   WgArgs a = {};
@@ -559,6 +572,7 @@ extern "C" int zs3_gmmn_mlp_wgrad_adam(const float* dy2, int ldy2, const float* 
   }
   a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
   a.step = (const long*)step_dev;
+  a.bc = adam_bc;
   a.counters[0] = (long*)slot_dev; a.counters[1] = (long*)step_dev; a.counters[2] = (long*)seed_dev;
   a.seed_inc = seed_inc;
   a.done = (unsigned*)done_dev;

@@ -1,6 +1,7 @@
 // Small HBM/latency-bound kernels of the GMMN step and the optimisers: counter-based dropout, uniform
 // noise, nearest-neighbour down-sampling into pixel rows, row gather / scatter / deterministic
 // index-add, fused SGD(momentum, weight decay) and Adam updates.
+#include <cstdint>
 #include "common.h"
 #include "zs3hip.h"
 
@@ -33,6 +34,29 @@ __global__ void dropout_kernel(const float* x, int ldx, float* y, int ldy, long 
     const float v = x[m * ldx + c];
     const unsigned long long e = row_idx ? (unsigned long long)(row_idx[m] * C + c) : (unsigned long long)i;
     y[m * ldy + c] = u01(seed, e) >= p ? v * inv_keep : 0.f;
+  }
+}
+
+// float4 form of the above for C % 4 == 0 and 16-byte aligned rows (every dropout of the network: 256 channels): one row
+// division per four elements and 16-byte accesses; the mask of element (m, c) is the same u01(seed, m*C + c).  (The scalar
+// kernel moved the decoder's 272 MB activations at 2.4 TB/s.)
+__global__ __launch_bounds__(256) void dropout4_kernel(const float* x, int ldx, float* y, int ldy, long M, int C, float p,
+                                                       float inv_keep, unsigned long long seed, const long* row_idx,
+                                                       const unsigned long long* seed_dev) {
+  if (seed_dev) seed += seed_dev[0];
+  const int c4 = C >> 2;
+  const long total = M * c4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / c4;
+    const int c = (int)(i - m * c4) << 2;
+    const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + c);
+    const unsigned long long e = (unsigned long long)((row_idx ? row_idx[m] : m) * C + c);
+    float4 o;
+    o.x = u01(seed, e) >= p ? v.x * inv_keep : 0.f;
+    o.y = u01(seed, e + 1) >= p ? v.y * inv_keep : 0.f;
+    o.z = u01(seed, e + 2) >= p ? v.z * inv_keep : 0.f;
+    o.w = u01(seed, e + 3) >= p ? v.w * inv_keep : 0.f;
+    *reinterpret_cast<float4*>(y + m * ldy + c) = o;
   }
 }
 
@@ -284,13 +308,98 @@ __global__ void counter_add2_kernel(long* c0, long v0, long* c1, long v1) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------- label maps of the GMMN step
+// One workgroup per image: the label map at feature resolution (F.interpolate(mode="nearest") of train_pascal_GMMN.py:175-180,
+// the index arithmetic of nearest_rows_kernel), its class histogram, and the pixels grouped by class in ascending pixel order
+// (= a stable argsort of the labels; a counting sort, since labels are bytes).  Replaces ~20 small library launches per step
+// (float cast, transpose, scatter_add histogram, a 12-kernel segmented merge sort, where/zeros: 1.2 ms per B=16 step).
+// Pass 1: labels + LDS histogram.  Pass 2, 1024 pixels at a time: a lane's rank among the equal labels of its wave comes from
+// ballots, the wave's count per label goes through LDS, position = class base + counts of earlier waves + rank; the class
+// bases then advance by the chunk's counts.  Integer arithmetic only: exact and deterministic.
+template <typename TT>
+__global__ __launch_bounds__(1024) void label_order_kernel(const TT* target, int H, int W, int ho, int wo, float sh, float sw,
+                                                           long* tgt_l, long* tgt_cls, long* hist, long* order) {
+  __shared__ int cnt[256];
+  __shared__ int base[256];
+  __shared__ unsigned short wave_cnt[16][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npix = ho * wo;
+  const TT* src = target + (long)blockIdx.x * H * W;
+  long* lab_out = tgt_l + (long)blockIdx.x * npix;
+  long* cls_out = tgt_cls + (long)blockIdx.x * npix;
+  long* ord_out = order + (long)blockIdx.x * npix;
+  if (tid < 256) cnt[tid] = 0;
+  __syncthreads();
+  for (int p = tid; p < npix; p += 1024) {
+    const int oh = p / wo, ow = p - oh * wo;
+    int ih = (int)floorf((float)oh * sh), iw = (int)floorf((float)ow * sw);
+    ih = ih < H - 1 ? ih : H - 1;
+    iw = iw < W - 1 ? iw : W - 1;
+    long v = (long)src[(long)ih * W + iw];
+    if (v < 0 || v > 255) v = 255;            // not a class id: treated like the ignore label
+    lab_out[p] = v;
+    cls_out[p] = v == 255 ? 0 : v;            // the dataloader's embedding lookup maps 255 to class 0 (base.py:47-48)
+    atomicAdd(&cnt[(int)v], 1);
+  }
+  __syncthreads();
+  if (tid < 256) hist[(long)blockIdx.x * 256 + tid] = cnt[tid];
+  if (tid == 0) {
+    int run = 0;
+    for (int c = 0; c < 256; ++c) {
+      base[c] = run;
+      run += cnt[c];
+    }
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < npix; c0 += 1024) {
+    for (int e = tid; e < 16 * 256; e += 1024) (&wave_cnt[0][0])[e] = 0;
+    __syncthreads();
+    const int p = c0 + tid;
+    const bool valid = p < npix;
+    const int lab = valid ? (int)lab_out[p] : -1;
+    int rank = 0;
+    bool todo = valid;
+    unsigned long long pending = __ballot(todo);
+    while (pending) {
+      const int first = __ffsll((long long)pending) - 1;
+      const int c = __shfl(lab, first, 64);
+      const unsigned long long same = __ballot(todo && lab == c);
+      if (todo && lab == c) {
+        rank = __popcll(same & ((1ull << lane) - 1ull));
+        todo = false;
+      }
+      if (lane == first) wave_cnt[wave][c] = (unsigned short)__popcll(same);
+      pending &= ~same;
+    }
+    __syncthreads();
+    if (valid) {
+      int off = base[lab] + rank;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w][lab];
+      ord_out[off] = p;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      int add = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) add += wave_cnt[w][tid];
+      base[tid] += add;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
                            const long* row_idx, const void* seed_dev, void* stream) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, p,
-                     1.f / (1.f - p), seed, row_idx, (const unsigned long long*)seed_dev);
+  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL(dropout4_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C,
+                       p, 1.f / (1.f - p), seed, row_idx, (const unsigned long long*)seed_dev);
+  else
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, p,
+                       1.f / (1.f - p), seed, row_idx, (const unsigned long long*)seed_dev);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -298,6 +407,21 @@ extern "C" int zs3_uniform(float* out, long n, unsigned long long seed, const vo
   if (n <= 0) return 0;
   hipLaunchKernelGGL(uniform_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, out, n, seed,
                      (const unsigned long long*)seed_dev);
+  return ZS3_LAUNCH_CHECK();
+}
+
+/* target: [B][H][W] float32 or int64 label maps -> tgt_l [B][ho*wo] (nearest resize, values outside 0..255 become 255),
+ * tgt_cls (255 -> 0), hist [B][256], order [B][ho*wo] = stable argsort of tgt_l along the pixels; all int64. */
+extern "C" int zs3_label_order(const void* target, int target_is_i64, int B, int H, int W, int ho, int wo, long* tgt_l,
+                               long* tgt_cls, long* hist, long* order, void* stream) {
+  if (B < 1 || ho < 1 || wo < 1) return -1;
+  const float sh = (float)H / (float)ho, sw = (float)W / (float)wo;
+  if (target_is_i64)
+    hipLaunchKernelGGL(label_order_kernel<long>, dim3(B), dim3(1024), 0, (hipStream_t)stream, (const long*)target, H, W, ho, wo,
+                       sh, sw, tgt_l, tgt_cls, hist, order);
+  else
+    hipLaunchKernelGGL(label_order_kernel<float>, dim3(B), dim3(1024), 0, (hipStream_t)stream, (const float*)target, H, W, ho,
+                       wo, sh, sw, tgt_l, tgt_cls, hist, order);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -2,6 +2,7 @@
 // decoder.py:34-36, deeplab.py:44,55) on NHWC fp32, forward and backward.  HBM-bound; float4 over
 // channels; backward passes are written in gather form (one thread owns an input element), so they
 // need no atomics and are deterministic.
+#include <cstdint>
 #include "common.h"
 #include "zs3hip.h"
 
@@ -308,4 +309,117 @@ extern "C" int zs3_argmax_confusion(const float* x, int ldx, int N, int H, int W
     hipLaunchKernelGGL(argmax_confusion_kernel<float>, dim3((int)blocks), dim3(256), lds, (hipStream_t)stream, a,
                        (const float*)target, (unsigned long long*)conf);
   return ZS3_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------- fused CE backward + upsample backward
+// The training step ends in  logits [N,H,W,C] --bilinear, align_corners--> [N,Ho,Wo,C] --weighted CE--> loss
+// (deeplab.py:44,55 + loss.py:31-46).  Unfused, the backward writes the full-resolution gradient (354 MB at B=16, 513^2, 21
+// classes) and gathers it back to H x W.  Here one thread owns one LOW-resolution pixel: for every output pixel whose bilinear
+// footprint contains it (<= 7 x 7 at the 4x upsample) it re-samples the C scores from the four taps (the arithmetic of
+// bilinear_fwd_kernel), takes the softmax, and accumulates  wt * w[t] * coef * (p_c - [c == t])  in the candidate order of
+// bilinear_bwd_kernel.  25 MB of low-resolution logits and the label map are all it reads; the full-resolution gradient never
+// exists.  CPAD >= C is the compile-time register footprint (24 for the 21 VOC classes, 64 for the 60 of Pascal-Context).
+template <typename TT, int CPAD, bool VEC>
+__global__ __launch_bounds__(128) void ce_bilinear_bwd_kernel(const ResizeArgs p, const TT* target, const float* weight,
+                                                             int ignore_index, const float* loss_ws, const float* gout,
+                                                             float inv_batch) {
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= (long)p.N * p.H * p.W) return;
+  const int w = (int)(m % p.W);
+  const long r = m / p.W;
+  const int h = (int)(r % p.H), n = (int)(r / p.H);
+  const float coef = gout[0] * inv_batch / loss_ws[1];
+  int olo, ohi, wlo, whi;
+  cand_range(h, p.sh, p.Ho, olo, ohi);
+  cand_range(w, p.sw, p.Wo, wlo, whi);
+  float acc[CPAD];
+#pragma unroll
+  for (int c = 0; c < CPAD; ++c) acc[c] = 0.f;
+  const float* b = p.x + (long)n * p.H * p.W * p.ldx;
+  const TT* tg = target + (long)n * p.Ho * p.Wo;
+  for (int oh = olo; oh <= ohi; ++oh) {
+    int h0, h1;
+    float lh;
+    src_index(oh, p.sh, p.H, h0, h1, lh);
+    const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+    if (wh == 0.f) continue;
+    for (int ow = wlo; ow <= whi; ++ow) {
+      int w0, w1;
+      float lw;
+      src_index(ow, p.sw, p.W, w0, w1, lw);
+      const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+      if (ww == 0.f) continue;
+      const int t = (int)(long)tg[(long)oh * p.Wo + ow];
+      if (t == ignore_index || t < 0 || t >= p.C) continue;   // ignored pixels carry no gradient
+      const float wt = wh * ww;
+      const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
+      const float* q00 = b + ((long)h0 * p.W + w0) * p.ldx;
+      const float* q01 = b + ((long)h0 * p.W + w1) * p.ldx;
+      const float* q10 = b + ((long)h1 * p.W + w0) * p.ldx;
+      const float* q11 = b + ((long)h1 * p.W + w1) * p.ldx;
+      float z[CPAD];
+      if (VEC) {   // ldx >= CPAD, 16-byte aligned rows: whole float4s (lanes past C are never used)
+#pragma unroll
+        for (int c = 0; c < CPAD; c += 4) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(q00 + c), bb = *reinterpret_cast<const f32x4*>(q01 + c),
+                      cc = *reinterpret_cast<const f32x4*>(q10 + c), d = *reinterpret_cast<const f32x4*>(q11 + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[c + e] = bilerp(w00, w01, w10, w11, a[e], bb[e], cc[e], d[e]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPAD; ++c) z[c] = c < p.C ? bilerp(w00, w01, w10, w11, q00[c], q01[c], q10[c], q11[c]) : 0.f;
+      }
+      float mx = z[0];
+#pragma unroll
+      for (int c = 1; c < CPAD; ++c)
+        if (c < p.C) mx = fmaxf(mx, z[c]);
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPAD; ++c)
+        if (c < p.C) {
+          z[c] = expf(z[c] - mx);
+          se += z[c];
+        }
+      const float inv = 1.f / se, wc = (weight ? weight[t] : 1.f) * coef;
+#pragma unroll
+      for (int c = 0; c < CPAD; ++c)
+        if (c < p.C) acc[c] += wt * (wc * (z[c] * inv - (c == t ? 1.f : 0.f)));
+    }
+  }
+  float* dst = p.out + m * p.ldo;
+#pragma unroll
+  for (int c = 0; c < CPAD; ++c)
+    if (c < p.C) dst[c] = acc[c];
+}
+
+template <typename TT>
+static int launch_ce_bilinear_bwd(const ResizeArgs& a, const void* target, const float* weight, int ignore_index,
+                                  const float* loss_ws, const float* gout, float inv_batch, hipStream_t st) {
+  const long total = (long)a.N * a.H * a.W;
+  const dim3 grid((unsigned)((total + 127) / 128)), block(128);
+  const bool vec24 = a.ldx % 4 == 0 && a.ldx >= 24 && ((uintptr_t)a.x & 15) == 0;
+  const bool vec64 = a.ldx % 4 == 0 && a.ldx >= 64 && ((uintptr_t)a.x & 15) == 0;
+  const TT* t = (const TT*)target;
+  if (a.C <= 24) {
+    if (vec24) hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 24, true>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
+    else hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 24, false>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
+  } else {
+    if (vec64) hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 64, true>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
+    else hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 64, false>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
+  }
+  return ZS3_LAUNCH_CHECK();
+}
+
+/* d(loss)/d(lr) for  loss = CE(bilinear(lr -> Ho x Wo), target)  in one launch.  lr: [N,H,W,C] low-resolution class scores,
+ * loss_ws / gout as for zs3_ce_bwd (loss_ws[1] = sum of the class weights over the valid pixels, written by zs3_ce_fwd on the
+ * upsampled scores), dlr: [N,H,W,C] with row stride ldo (every one of the C channels of every pixel is written). */
+extern "C" int zs3_ce_bilinear_bwd(const float* lr, int ldx, const void* target, int target_is_i64, const float* weight,
+                                   int N, int H, int W, int Ho, int Wo, int C, int ignore_index, int batch,
+                                   const float* loss_ws, const float* gout, float* dlr, int ldo, void* stream) {
+  if (C < 1 || C > 64 || N < 1) return -1;
+  const ResizeArgs a = make_resize(lr, ldx, dlr, ldo, N, H, W, Ho, Wo, C, 0);
+  const float inv_batch = batch > 0 ? 1.f / (float)batch : 1.f;
+  return target_is_i64 ? launch_ce_bilinear_bwd<long>(a, target, weight, ignore_index, loss_ws, gout, inv_batch, (hipStream_t)stream)
+                       : launch_ce_bilinear_bwd<float>(a, target, weight, ignore_index, loss_ws, gout, inv_batch, (hipStream_t)stream);
 }

@@ -162,6 +162,7 @@ class GMMNStep:
                     return (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in ptrs])
                 st["adam_state2"], st["adam_state1"] = _state(lin2, st["wp2"], True), _state(lin1, st["wp1"], False)
                 st["done"] = torch.zeros(1, dtype=torch.int32, device=dev)
+                st["adam_bc"] = torch.ones(2, dtype=torch.float32, device=dev)   # bias corrections of the running update
 
     def _adam_signature(self):
         """identity of everything the captured update holds raw pointers to / mirrors on the device"""
@@ -193,6 +194,9 @@ class GMMNStep:
         t = (2 * s + 31) // 32
         gmat = torch.empty((2 * s, 2 * s), dtype=torch.float32, device=st["emb"].device)
         tile = torch.empty(2 * t * t, dtype=torch.float64, device=st["emb"].device)
+        fused_adam = fused and st.get("adam_multi") is not None and st.get("adam_state2") is not None
+        adam_b1, adam_b2 = st["adam_multi"][3]["betas"] if fused_adam else (0.9, 0.999)
+        bc_ready = False     # Adam's bias corrections of this update already on the device (written by zs3_gmmn_prep)
         if fused:
             dev = st["emb"].device
             hid = wp1.cout
@@ -207,7 +211,9 @@ class GMMNStep:
                 check(lib().zs3_gmmn_prep(P(st["upd_table"]), I(st["upd_table"].stride(0)), P(st["slot_dev"]), P(st["order_flat"]),
                                           P(st["emb_all"]), I(st["emb_all"].stride(0)), I(self.embed_dim), I(self.noise_dim), P(x),
                                           I(width), P(st["pix_global"]), P(st["ridx"]), I(s), ctypes.c_ulonglong(st["seed_base"]),
-                                          P(st["seed_dev"]), stream()), "zs3_gmmn_prep")
+                                          P(st["seed_dev"]), P(st["step_dev"] if fused_adam else None), F(adam_b1), F(adam_b2),
+                                          P(st["adam_bc"] if fused_adam else None), stream()), "zs3_gmmn_prep")
+                bc_ready = fused_adam
                 ident = st["ident"]
                 check(lib().zs3_gmmn_mlp_fwd1(P(x), I(width), P(ident), P(st["ridx"]), I(width), I(0), P(wp1.f_pk),
                                               I(wp1.cin_pad // 32), P(lin1.bias), P(None), I(width), P(h), P(hd), I(hid), I(s),
@@ -246,7 +252,6 @@ class GMMNStep:
         check(lib().zs3_mmd_fwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), self._sig, I(len(self.sigma)), P(gmat), P(tile),
                                 None, stream()), "zs3_mmd_fwd")          # the loss value is finalised by the update epilogue
         dgen = torch.empty_like(gen_s)
-        fused_adam = fused and st.get("adam_multi") is not None and st.get("adam_state2") is not None
         # fused_adam: the loss value goes to loss_ring[slot] here, the counters are advanced by the wgrad + Adam launch
         check(lib().zs3_mmd_bwd_ws(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(tile), P(st["one"]), P(dgen), I(d),
                                    P(st["loss_ring"]) if fused_adam else None, P(st["slot_dev"]) if fused_adam else None,
@@ -267,7 +272,7 @@ class GMMNStep:
                                                     I(wp1.cin_pad), I(wp1.cout_pad), F(group["lr"]), F(b1), F(b2),
                                                     F(group["eps"]), F(group["weight_decay"]), P(st["slot_dev"]),
                                                     P(st["step_dev"]), P(st["seed_dev"]), ctypes.c_long(1 << 24), P(st["done"]),
-                                                    stream()), "zs3_gmmn_mlp_wgrad_adam")
+                                                    P(st["adam_bc"] if bc_ready else None), stream()), "zs3_gmmn_mlp_wgrad_adam")
                 return
             check(lib().zs3_gmmn_mlp_wgrad(P(dgen), I(d), P(hd), I(hd.stride(0)), I(wp2.cout), I(wp2.cin), P(st["dw2"]),
                                            P(st["db2"]), P(dpre), I(wp1.cout), P(x), I(width), I(wp1.cout), I(wp1.cin),
@@ -453,15 +458,13 @@ class GMMNStep:
         st["real"].copy_(real_rows.reshape(b * npix, d))
         fake = torch.empty((b, fh, fw, d), dtype=torch.float32, device=dev)
         fake_rows = fake.view(b, npix, d)
-        # labels at feature resolution (nearest), per-image class histogram: one host sync per step
-        tgt_l = ops.nearest_rows(target.contiguous().float(), (fh, fw)).t().contiguous().long()      # [B, npix]
-        hist = torch.zeros((b, 256), dtype=torch.int64, device=dev).scatter_add_(1, tgt_l, torch.ones_like(tgt_l))
-        order = torch.argsort(tgt_l, dim=1, stable=True)                                          # pixels grouped by class
+        # labels at feature resolution (nearest), per-image class histogram, pixels grouped by class: one launch, then the one
+        # host sync of the step's head
+        tgt_l, tgt_cls, hist, order = ops.label_order(target, (fh, fw))                           # [B, npix] int64 each
         self._before_images(tgt_l.view(b, fh, fw))
         hist_h = hist.cpu().tolist()
         if table is not None:
             table_f = table.contiguous().float()
-            tgt_cls = torch.where(tgt_l == 255, torch.zeros_like(tgt_l), tgt_l).contiguous()
         training = self.generator.training
         n_mmd = int(sum(1 for i in range(b) for c in range(255) if hist_h[i][c] > 0))
         mmd_losses = torch.zeros(max(n_mmd, 1), dtype=torch.float32, device=dev)

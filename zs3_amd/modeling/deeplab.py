@@ -37,7 +37,9 @@ class DeepLab(nn.Module):
         return self.aspp.forward_nhwc(top), low
 
     def _logits_to_image(self, logits_nhwc, size):
-        return ops.nchw(Fz.bilinear(logits_nhwc, size))   # align_corners=True resize of deeplab.py:44,55
+        out = ops.nchw(Fz.bilinear(logits_nhwc, size))   # align_corners=True resize of deeplab.py:44,55
+        out._zs3_lowres = logits_nhwc   # lets the criterion fuse its backward with the resize's (utils/loss.py)
+        return out
 
     # ------------------------------------------------------------------ the reference's forward variants
     def forward(self, input):

@@ -470,6 +470,22 @@ def nearest_rows(src_chw, size, ld=None):
     return rows
 
 
+def label_order(target, size):
+    """target: [B,H,W] float32 / int64 label maps -> (tgt_l [B,npix], tgt_cls [B,npix], hist [B,256], order [B,npix]), int64:
+    nearest resize to `size`, 255 -> class 0, class histogram, stable argsort by class -- one launch (zs3_label_order)."""
+    require_gpu(target)
+    if target.dtype not in (torch.float32, torch.int64):
+        target = target.float()
+    target = target.contiguous()
+    b, h, w_ = target.shape
+    ho, wo = size
+    out = torch.empty((3, b, ho * wo), dtype=torch.int64, device=target.device)
+    hist = torch.empty((b, 256), dtype=torch.int64, device=target.device)
+    check(lib().zs3_label_order(P(target), I(int(target.dtype == torch.int64)), I(b), I(h), I(w_), I(ho), I(wo), P(out[0]),
+                                P(out[1]), P(hist), P(out[2]), stream()), "zs3_label_order")
+    return out[0], out[1], hist, out[2]
+
+
 def gather_cat(a, idx, ca, b, cb, ldo):
     n = b.shape[0]
     out = torch.empty((n, ldo), dtype=torch.float32, device=a.device)
