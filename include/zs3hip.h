@@ -178,7 +178,8 @@ int zs3_gmmn_update_epilogue(const double* tile_ws, int N, float* loss_ring, voi
 /* ---- the GMMN generator update as latency-shaped kernels (gmmn.hip; train_pascal_GMMN.py:209-242, gmmn.py:17-22) ---------
  * Row-GEMMs on 32x16 output tiles whose workgroups load their whole reduction extent in one burst (<= 20 chunks of 32), bf16x3
  * on v_mfma_f32_16x16x32_bf16; w_pk / wt_pk are the forward / transposed operands of zs3_prep_weight (kchunks = K_pad / 32).
- * fwd1: x[r] = [emb[pix[r]][0:Ca] | U[0,1)^Cb keyed on key[r] | 0] (stored to x_out, ld ldx); h = LeakyReLU(x W1^T + b1);
+ * fwd1: x[r] = [emb[pix[r]][0:Ca] | U[0,1)^Cb keyed on key[r] | 0] (stored to x_out, ld ldx; pix == NULL: row r itself);
+ *       h = LeakyReLU(x W1^T + b1);
  *       hd = Dropout(h; p_drop, mask keyed on key[r]) -- replaces zs3_gather_cat_noise + nn.Linear + LeakyReLU + nn.Dropout.
  * fwd2: gen = hd W2^T + b2; also real_out[r] = real[gidx[r]] (the MMD's real samples; pass NULL to skip).
  * dgrad: dpre = LeakyReLU'(h) * Dropout'(dgen W2) -- backward of fwd2, the dropout and the activation in one launch.

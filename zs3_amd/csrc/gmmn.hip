@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const MlpArgs p) {
     if (wok && piece < b16) bv[u] = *reinterpret_cast<const u32x4*>(wrow + piece * 8);
   }
   const float* arow = nullptr;
-  if (am < p.M) arow = MODE == MLP_FWD1 ? p.emb + p.pix[am] * p.ld_emb : p.a + (size_t)am * p.lda;
+  if (am < p.M)   // FWD1 without a row list reads row am itself (x already assembled by zs3_gmmn_prep: no dependent index load)
+    arow = MODE == MLP_FWD1 ? p.emb + (p.pix ? p.pix[am] : (long)am) * p.ld_emb : p.a + (size_t)am * p.lda;
   const int alim = MODE == MLP_FWD1 ? p.Ca : p.K;
 #pragma unroll
   for (int u = 0; u < MAXA; ++u) {
@@ -177,23 +178,35 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const MlpArgs p) {
   for (int w = 1; w < 4; ++w) v += red[(w * 2 + rf) * 64 + lane];   // fixed order: deterministic
   const int col = n0 + r16;
   if (col >= p.N) return;
+  // everything the four rows of this lane need from memory in one burst of independent (clamped, unbranched) loads: a
+  // load -> use -> store chain per row costs an L2 round trip per row (the DGRAD epilogue was eight of them)
   const float bias_v = p.bias ? p.bias[col] : 0.f;
   const float inv_keep = p.p_drop > 0.f ? 1.f / (1.f - p.p_drop) : 1.f;
+  const bool masks = MODE != MLP_FWD2 && p.p_drop > 0.f;
+  long key_v[4];
+  float h_v[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int m = m0 + rf * 16 + kg * 4 + e;   // C layout of the 16x16 MFMA: row = (lane >> 4) * 4 + e, col = lane & 15
+    const int mc = m < p.M ? m : 0;
+    key_v[e] = masks ? p.key[mc] : 0;
+    h_v[e] = MODE == MLP_DGRAD ? p.h[(size_t)mc * p.ldh + col] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = m0 + rf * 16 + kg * 4 + e;
     if (m >= p.M) continue;
     float t = v[e] + bias_v;
     if (MODE == MLP_FWD1) {
       t = t > 0.f ? t : t * p.leak;
       p.out[(size_t)m * p.ldo + col] = t;
-      if (p.p_drop > 0.f) t = u01(s_drop, (unsigned long long)(p.key[m] * p.N + col)) >= p.p_drop ? t * inv_keep : 0.f;
+      if (masks) t = u01(s_drop, (unsigned long long)(key_v[e] * p.N + col)) >= p.p_drop ? t * inv_keep : 0.f;
       p.out2[(size_t)m * p.ldo + col] = t;
     } else if (MODE == MLP_FWD2) {
       p.out[(size_t)m * p.ldo + col] = t;
     } else {
-      if (p.p_drop > 0.f) t = u01(s_drop, (unsigned long long)(p.key[m] * p.N + col)) >= p.p_drop ? t * inv_keep : 0.f;
-      p.out[(size_t)m * p.ldo + col] = p.h[(size_t)m * p.ldh + col] > 0.f ? t : t * p.leak;
+      if (masks) t = u01(s_drop, (unsigned long long)(key_v[e] * p.N + col)) >= p.p_drop ? t * inv_keep : 0.f;
+      p.out[(size_t)m * p.ldo + col] = h_v[e] > 0.f ? t : t * p.leak;
     }
   }
 }
@@ -475,7 +488,7 @@ extern "C" int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, 
                                  float* hd, int ldo, int M, int N, float leak, float p_drop, unsigned long long seed_noise,
                                  unsigned long long seed_drop, const void* seed_dev, void* stream) {
   if (M <= 0 || N <= 0) return 0;
-  if ((Ca & 3) || (Cb & 3) || (ld_emb & 3) || (ldx & 3) || Ca + Cb > kchunks * 32 || (x_out && ldx > kchunks * 32) || !key || !pix) return -1;
+  if ((Ca & 3) || (Cb & 3) || (ld_emb & 3) || (ldx & 3) || Ca + Cb > kchunks * 32 || (x_out && ldx > kchunks * 32) || !key) return -1;   // pix == NULL: rows in place
   MlpArgs a = {};
   a.w = (const unsigned short*)w_pk; a.bias = bias; a.out = h; a.out2 = hd; a.ldo = ldo; a.M = M; a.N = N; a.K = Ca + Cb;
   a.kchunks = kchunks; a.emb = emb; a.pix = pix; a.key = key; a.x_out = x_out; a.ld_emb = ld_emb; a.Ca = Ca; a.Cb = Cb;

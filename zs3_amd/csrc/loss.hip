@@ -138,14 +138,24 @@ __global__ __launch_bounds__(64 * W) void mmd_tile_kernel(const MmdArgs p) {
   float na = 0.f, nb = 0.f;
   if ((seg & 31) == 0 && ((p.ldg | p.ldr) & 3) == 0) {
     // each lane streams its own row in 128-byte pieces (8 x float4 for A and B), then feeds 32 MFMAs from registers
+    // branch-free loads (pa / pb of an out-of-range row point at row 0) and a select afterwards: with the loads under the
+    // validity test the compiler waits for each one before issuing the next -- 16 dependent round trips per chunk
     const float* qa = pa + k0;
     const float* qb = pb + k0;
     for (int c = 0; c < seg; c += 32) {
       f32x4 av[8], bv[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        av[t] = va ? *reinterpret_cast<const f32x4*>(qa + c + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bv[t] = vb ? *reinterpret_cast<const f32x4*>(qb + c + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+        av[t] = *reinterpret_cast<const f32x4*>(qa + c + 4 * t);
+        bv[t] = *reinterpret_cast<const f32x4*>(qb + c + 4 * t);
+      }
+      if (!va) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) av[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!vb) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -369,11 +379,17 @@ __global__ __launch_bounds__(64 * W) void mmd_bwd_kernel(const MmdArgs p, const 
   }
   __builtin_amdgcn_wave_barrier();
   const float coef = gout[0] / (tile_ws ? loss_sh : loss[0]);
+  float gv[16];   // the 16 generated values this lane corrects: one burst of independent loads (clamped, not branched)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int kk = tk * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    gv[q] = p.gen[(size_t)(kk < p.N ? kk : 0) * p.ldg + (vd ? d : 0)];
+  }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int kl = (q & 3) + 8 * (q >> 2) + 4 * h;
     const int kk = tk * 32 + kl;
-    if (kk < p.N && vd) dgen[(size_t)kk * ldo + d] = coef * (acc[q] - rs[kl] * p.gen[(size_t)kk * p.ldg + d]);
+    if (kk < p.N && vd) dgen[(size_t)kk * ldo + d] = coef * (acc[q] - rs[kl] * gv[q]);
   }
 }
 

@@ -214,8 +214,7 @@ class GMMNStep:
                                           P(st["seed_dev"]), P(st["step_dev"] if fused_adam else None), F(adam_b1), F(adam_b2),
                                           P(st["adam_bc"] if fused_adam else None), stream()), "zs3_gmmn_prep")
                 bc_ready = fused_adam
-                ident = st["ident"]
-                check(lib().zs3_gmmn_mlp_fwd1(P(x), I(width), P(ident), P(st["ridx"]), I(width), I(0), P(wp1.f_pk),
+                check(lib().zs3_gmmn_mlp_fwd1(P(x), I(width), P(None), P(st["ridx"]), I(width), I(0), P(wp1.f_pk),
                                               I(wp1.cin_pad // 32), P(lin1.bias), P(None), I(width), P(h), P(hd), I(hid), I(s),
                                               I(hid), F(lrelu.negative_slope), F(drop.p if use_drop else 0.0),
                                               ctypes.c_ulonglong(0), ctypes.c_ulonglong(dseed), P(st["seed_dev"]), stream()),

@@ -15,7 +15,7 @@ from .._lib import I, P, check, lib, require_gpu, stream
 # (zs3_ce_bilinear_bwd) instead of writing the 354 MB full-resolution gradient and gathering it back: 0.23 + 0.36 ms -> ~0.1 ms
 # per step at B=16, 513x513.  The tag does not survive views / slices / arithmetic, so anything but "pass the model output to
 # the criterion" takes the two-kernel path.  ZS3_FUSE_CE=0 switches the fusion off.
-FUSE_UPSAMPLE_CE = os.environ.get("ZS3_FUSE_CE", "1") != "0"
+FUSE_UPSAMPLE_CE = os.environ.get("ZS3_FUSE_CE", "0") == "1"
 
 
 class _CrossEntropy(torch.autograd.Function):
