@@ -550,9 +550,14 @@ def test_bn_finalize_short_and_tall_partial_buffers(dev, chunks, c):
     assert torch.allclose(c2.double().cpu(), q / count, rtol=2e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("classes,tdtype,padded", [(21, torch.float32, True), (60, torch.int64, True), (5, torch.int64, False),
-                                                   (21, torch.int64, False)])
-def test_fused_ce_upsample_backward(dev, classes, tdtype, padded):
+@pytest.mark.parametrize("classes,tdtype,padded,sizes", [
+    (21, torch.float32, True, (17, 19, 65, 73)),     # the training step's 4x upsample: 8x8 tiles, float4 taps
+    (60, torch.int64, True, (17, 19, 65, 73)),       # Pascal-Context: 4x4 tiles
+    (5, torch.int64, False, (17, 19, 65, 73)),       # dense rows: scalar taps
+    (21, torch.int64, False, (17, 19, 60, 50)),      # a ratio that is not 4: general candidate ranges
+    (21, torch.float32, True, (33, 33, 129, 129)),   # several tiles per image, ragged last tile
+    (21, torch.float32, True, (5, 6, 65, 70))])      # 13x upsample: more candidates than the tiled gather unrolls -> per-thread form
+def test_fused_ce_upsample_backward(dev, monkeypatch, classes, tdtype, padded, sizes):
     """zs3_ce_bilinear_bwd (CE backward + align_corners upsample backward in one launch, taken when the criterion receives the
     tensor DeepLab tagged with its low-resolution scores) against the two-kernel path and against fp64 torch on the host
     (deeplab.py:44,55 + loss.py:31-46)."""
@@ -561,7 +566,7 @@ def test_fused_ce_upsample_backward(dev, classes, tdtype, padded):
     from zs3_amd import ops
     from zs3_amd.utils import loss as L
     g = torch.Generator().manual_seed(classes)
-    n, h, w, H, W = 2, 17, 19, 65, 73
+    n, (h, w, H, W) = 2, sizes
     cp = (classes + 7) // 8 * 8 if padded else classes
     base = (torch.randn(n, h, w, cp, generator=g) * 3).to(dev)
     target = torch.randint(0, classes, (n, H, W), generator=g)
@@ -570,6 +575,7 @@ def test_fused_ce_upsample_backward(dev, classes, tdtype, padded):
     weight = torch.rand(classes, generator=g) + 0.5
     weight[3] = 100.0
     grads, losses = [], []
+    monkeypatch.setattr(L, "FUSE_UPSAMPLE_CE", True)      # off by default (measured slower than the two kernels it replaces)
     for fuse in (True, False):
         lr = base.clone()[..., :classes].requires_grad_()
         out = ops.nchw(Fz.bilinear(lr, (H, W)))
@@ -594,6 +600,7 @@ def test_fused_ce_upsample_backward(dev, classes, tdtype, padded):
     lr = base.clone()[..., :classes].requires_grad_()
     out = ops.nchw(Fz.bilinear(lr, (H, W)))
     out._zs3_lowres = lr
+    assert L.FUSE_UPSAMPLE_CE
     L.cross_entropy_2d(out[:, :, :, :], target.to(dev).to(tdtype), weight.to(dev)).backward()
     assert (lr.grad - grads[1]).abs().max().item() == 0.0
 

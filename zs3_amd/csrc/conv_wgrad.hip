@@ -716,12 +716,15 @@ int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, hipStream_t
   return ZS3_LAUNCH_CHECK();
 }
 
-static int wgrad_cus() {   // CUs one launch is sized for: 256 / (streams of the wgrad pool), ZS3_WGRAD_CUS
+// CUs one launch is sized for (split-K factors and grids aim at this many workgroup slots), ZS3_WGRAD_CUS.  The launches run on
+// two side streams next to the dgrad chain; same-box sweep of the supervised step (tools/probe/r2r.sh, ms per step): 64 -> 54.4,
+// 96 -> 48.3, 128 -> 48.9, 176 -> 48.4, 256 on one stream -> 49.8, 96 on three streams -> 49.1.
+static int wgrad_cus() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("ZS3_WGRAD_CUS");
-    v = e ? atoi(e) : 128;   // default: two streams in the pool (functional.WGRAD_STREAMS)
-    if (v < 8 || v > 256) v = 128;
+    v = e ? atoi(e) : 96;
+    if (v < 8 || v > 256) v = 96;
   }
   return v;
 }

@@ -11,10 +11,13 @@ from .._lib import I, P, check, lib, require_gpu, stream
 
 # The model's last op is the 4x bilinear upsample of the class scores (deeplab.py:44,55) and the criterion is the first thing
 # that touches the result.  DeepLab tags the tensor it returns with the low-resolution scores it was resized from
-# (`_zs3_lowres`); when that tag is present the CE's backward computes d(loss)/d(low-resolution scores) in one launch
-# (zs3_ce_bilinear_bwd) instead of writing the 354 MB full-resolution gradient and gathering it back: 0.23 + 0.36 ms -> ~0.1 ms
-# per step at B=16, 513x513.  The tag does not survive views / slices / arithmetic, so anything but "pass the model output to
-# the criterion" takes the two-kernel path.  ZS3_FUSE_CE=0 switches the fusion off.
+# (`_zs3_lowres`); with FUSE_UPSAMPLE_CE the CE's backward computes d(loss)/d(low-resolution scores) in one launch
+# (zs3_ce_bilinear_bwd) instead of writing the 354 MB full-resolution gradient and gathering it back.  Measured at B=16, 513x513
+# (same-box A/B, tools/probe/r2p.sh, r2q.sh): the two kernels it replaces take 0.23 + 0.36 ms; the fused launch takes 1.7 ms in
+# its one-thread-per-low-resolution-pixel form (49 softmaxes recomputed per thread) and 0.88 ms in its tiled form (softmax once
+# per output pixel into 128 KB of LDS -> one workgroup per CU, nothing hides the tap loads' latency).  Not a win yet, so it is
+# OFF by default (ZS3_FUSE_CE=1 turns it on); parity of both forms is covered by tests/test_gpu_ops.py.  The tag does not
+# survive views / slices / arithmetic, so anything but "pass the model output to the criterion" takes the two-kernel path.
 FUSE_UPSAMPLE_CE = os.environ.get("ZS3_FUSE_CE", "0") == "1"
 
 
