@@ -622,3 +622,27 @@ def test_label_order_matches_torch_sequence(dev, shape, size, tdtype):
     assert torch.equal(tgt_cls.cpu(), torch.where(want == 255, torch.zeros_like(want), want))
     assert torch.equal(hist.cpu(), torch.stack([torch.bincount(r, minlength=256) for r in want]))
     assert torch.equal(order.cpu(), torch.argsort(want, dim=1, stable=True))
+
+
+@pytest.mark.parametrize("hw", [(33, 37), (65, 65)])
+def test_stem_wgrad_folds_the_taps(dev, hw):
+    """The stem's weight gradient (7x7/s2 conv as a 7x1 filter over 32-float NHWC4 windows, resnet.py:73): zs3_conv_wgrad folds
+    the seven taps into the channel axis (one 224-channel launch instead of seven half-empty tiles) -- against torch's
+    conv2d weight gradient in fp64."""
+    from zs3_amd import ops
+    from zs3_amd._lib import I, P, check, lib, stream
+    g = torch.Generator().manual_seed(hw[0])
+    n, (h, w) = 2, hw
+    image = torch.randn(n, 3, h, w, generator=g)
+    ho, wo = ops.conv_out_size(h, 7, 2, 3, 1), ops.conv_out_size(w, 7, 2, 3, 1)
+    dy = torch.randn(n, 64, ho, wo, generator=g)
+    wp = max(w + 7, 2 * (wo - 1) + 8)
+    xp = torch.empty((n, h, wp, 4), dtype=torch.float32, device=dev)
+    check(lib().zs3_nchw3_to_nhwc4(P(image.to(dev)), P(xp), I(n), I(h), I(w), I(wp), I(3), stream()), "zs3_nchw3_to_nhwc4")
+    dy_d = dy.to(dev).permute(0, 2, 3, 1).contiguous()
+    dw = ops.conv2d_wgrad(dy_d, xp, 64, 32, 7, 1, 2, 3, 0, 1, ci_read=32)            # [64, 7, 1, 32]
+    got = dw.reshape(64, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2).double().cpu()
+    want = torch.nn.grad.conv2d_weight(image.double(), (64, 3, 7, 7), dy.double(), stride=2, padding=3)
+    assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
+    # the pad lanes of the windows (8th pixel, 4th channel) multiply zero weights in the forward; their gradient entries are
+    # whatever the window holds and are dropped by the view above -- nothing to assert about them

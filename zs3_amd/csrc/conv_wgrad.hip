@@ -32,6 +32,7 @@ struct WgradArgs {
   int lddy, ldx, ldw, cin_w;
   int M, chunk;
   long slab;  // elements per split-K slab
+  int fold;   // > 0: the KH taps of a KH x 1 filter over `fold`-channel rows are folded into the channel axis (see zs3_conv_wgrad)
 };
 
 template <int BC, int BD, int PREC>  // BC = dy-channel (co) tile, BD = x-channel (ci) tile
@@ -97,7 +98,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         bow[i][e] = rem - boh[i][e] * p.Wo;
       }
   }
-  const int tap_h = kh * p.dil - p.pad_h, tap_w = kw * p.dil - p.pad_w;
+  // fold mode (the stem's 7x1 filter over 32-float windows): "input channel" c of this launch is (tap c / fold, channel c % fold),
+  // so the tap is a property of the staging thread's channel quad, not of the workgroup: one workgroup covers several taps and
+  // dy is read once per 128 folded channels instead of once per tap
+  const int cfull = ci0 + cqb;
+  const int kh_t = p.fold > 0 ? cfull / p.fold : kh;
+  const int cch = p.fold > 0 ? cfull - kh_t * p.fold : cfull;
+  const int tap_h = kh_t * p.dil - p.pad_h, tap_w = kw * p.dil - p.pad_w;
 
   auto load_tile = [&]() {
 #pragma unroll
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       for (int e = 0; e < 2; ++e) {
         const int hi = boh[i][e] * p.stride + tap_h, wi = bow[i][e] * p.stride + tap_w;
         const bool ok = b_cok && bm[i][e] < m_end && ((hi | wi) >= 0) && hi < p.H && wi < p.W;
-        const float* ptr = ok ? p.x + ((((size_t)bn[i][e] * p.H + hi) * p.W + wi) * p.ldx + ci0 + cqb) : p.zero;
+        const float* ptr = ok ? p.x + ((((size_t)bn[i][e] * p.H + hi) * p.W + wi) * p.ldx + cch) : p.zero;
         breg[i][e] = *reinterpret_cast<const f32x4*>(ptr);
         // advance this slot by 32 pixels
         bm[i][e] += 32;
@@ -792,6 +799,7 @@ static int pick_splitk_dma(int M, int tiles, long out_elems) {
   }
   return best;
 }
+constexpr int STEM_FOLD = 32;   // channel count of the stem's NHWC4 windows (8 pixels x 4 channels)
 extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
   int s;
   const int wd = dma_width(co, ci, Wo, M);
@@ -801,6 +809,10 @@ extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int*
     int bc = pick_tile_dim(co), bd = pick_tile_dim(ci);
     if (tile_override() == 64) { bc = 64; bd = 64; }
     int tiles = ((co + bc - 1) / bc) * ((ci + bd - 1) / bd) * taps;
+    if (ci == STEM_FOLD && taps == 7) {   // the folded stem launch of zs3_conv_wgrad: 224 channels, one tap
+      bd = pick_tile_dim(ci * taps);
+      tiles = ((co + bc - 1) / bc) * ((ci * taps + bd - 1) / bd);
+    }
     s = pick_splitk(M, tiles);
   }
   *splitk_out = s;
@@ -819,7 +831,7 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil;
   a.co_read = co_read; a.co_write = co_write; a.ci_read = ci_read; a.ci_write = ci_write;
-  a.lddy = lddy; a.ldx = ldx; a.cin_w = ci_write; a.ldw = KH * KW * ci_write;
+  a.lddy = lddy; a.ldx = ldx; a.cin_w = ci_write; a.ldw = KH * KW * ci_write; a.fold = 0;
   a.M = N * Ho * Wo;
   const int taps = KH * KW;
   int splitk;
@@ -858,12 +870,23 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
     r.dw = a.dw + wd;
     r.ci_write = ci_write - wd;
     r.ci_read = ci_read - wd;
+    int taps_r = taps;
+    if (wd == 0 && KH == 7 && KW == 1 && pad_w == 0 && ci_write == STEM_FOLD && ci_read == STEM_FOLD) {
+      // the stem (7x7/s2 as a 7x1 filter over 32-float windows, resnet.py:73): per tap the tile would be 64 x 32 of a 64 x 64
+      // MFMA tile and the 271 MB gradient would be read seven times (574 us at B=16).  [co][kh][1][32] weights are [co][224]
+      // rows, so the taps fold into the channel axis: one tap, 224 channels, the staging thread derives its tap from its channel.
+      r.fold = STEM_FOLD;
+      r.KH = 1;
+      r.ci_write = r.ci_read = KH * STEM_FOLD;
+      r.cin_w = KH * STEM_FOLD;
+      taps_r = 1;
+    }
     int bc = pick_tile_dim(r.co_write), bd = pick_tile_dim(r.ci_write);
     if (tile_override() == 64) { bc = 64; bd = 64; }
-    if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(r, taps, splitk, prec, st);
-    else if (bc == 128) rc = launch_wgrad<128, 64>(r, taps, splitk, prec, st);
-    else if (bd == 128) rc = launch_wgrad<64, 128>(r, taps, splitk, prec, st);
-    else rc = launch_wgrad<64, 64>(r, taps, splitk, prec, st);
+    if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(r, taps_r, splitk, prec, st);
+    else if (bc == 128) rc = launch_wgrad<128, 64>(r, taps_r, splitk, prec, st);
+    else if (bd == 128) rc = launch_wgrad<64, 128>(r, taps_r, splitk, prec, st);
+    else rc = launch_wgrad<64, 64>(r, taps_r, splitk, prec, st);
   }
   if (rc) return rc;
   if (splitk > 1) {
