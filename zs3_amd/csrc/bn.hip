@@ -221,29 +221,57 @@ struct AffArgs {
   int C, ldx, ldr, ldo, div, act, accumulate;
   float alpha, leak;
 };
+// per-channel operands of one float4 column: loaded once per thread when the grid stride is a multiple of the row length (every
+// power-of-two channel count: the thread then stays in its column), else once per element
+struct AffCol {
+  f32x4 scale, shift;
+};
+__device__ __forceinline__ AffCol aff_col(const AffArgs& p, int cq) {
+  AffCol c;
+  c.scale = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cq) : f32x4{1.f, 1.f, 1.f, 1.f};
+  c.shift = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  return c;
+}
+__device__ __forceinline__ void aff_elem(const AffArgs& p, long i, long m, int cq, const AffCol& col) {
+  const long ms = p.div > 1 ? m / p.div : m;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ms * p.ldx + cq);
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+  if (p.res) r = *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + cq);
+  if (p.scale) v = v * col.scale;
+  if (p.shift) v = v + col.shift;
+  v = v * p.alpha;
+  if (p.res) v = v + r;
+  if (p.mask) p.mask[i] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
+  if (p.act == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.leak;
+  }
+  float* dst = p.out + m * p.ldo + cq;
+  if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
+  *reinterpret_cast<f32x4*>(dst) = v;
+}
 __global__ __launch_bounds__(256) void affine_act_kernel(const AffArgs p) {
   const int c4n = p.C >> 2;
   const long total = p.M * c4n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / c4n;
-    const int cq = (int)(i - m * c4n) * 4;
-    const long ms = p.div > 1 ? m / p.div : m;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ms * p.ldx + cq);
-    if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + cq);
-    if (p.shift) v = v + *reinterpret_cast<const f32x4*>(p.shift + cq);
-    v = v * p.alpha;
-    if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + cq);
-    if (p.mask) p.mask[i] = (unsigned char)((v[0] > 0.f) | ((v[1] > 0.f) << 1) | ((v[2] > 0.f) << 2) | ((v[3] > 0.f) << 3));
-    if (p.act == 1) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-    } else if (p.act == 2) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.leak;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (stride % c4n == 0) {
+    // the thread keeps its channel quad: scale / shift are read once (they were an L1 round trip per element, issued after
+    // the data had arrived) and the 64-bit division per element becomes an addition
+    long m = i0 / c4n;
+    const int cq = (int)(i0 - m * c4n) * 4;
+    const long dm = stride / c4n;
+    const AffCol col = aff_col(p, cq);
+    for (long i = i0; i < total; i += stride, m += dm) aff_elem(p, i, m, cq, col);
+  } else {
+    for (long i = i0; i < total; i += stride) {
+      const long m = i / c4n;
+      const int cq = (int)(i - m * c4n) * 4;
+      aff_elem(p, i, m, cq, aff_col(p, cq));
     }
-    float* dst = p.out + m * p.ldo + cq;
-    if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
-    *reinterpret_cast<f32x4*>(dst) = v;
   }
 }
 
@@ -265,46 +293,72 @@ struct BnBwdArgs {
   int C, ldd, lda, ldy, ldo, ldr, dres_accumulate, act;
   float leak;
 };
+struct BwdCol {
+  f32x4 is, g, mu, c1, c2, msc, msh;
+};
+__device__ __forceinline__ BwdCol bwd_col(const BnBwdArgs& p, int cq) {
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  BwdCol c;
+  c.is = p.dy ? *reinterpret_cast<const f32x4*>(p.invstd + cq) : one;
+  c.g = (p.dy && p.gamma) ? *reinterpret_cast<const f32x4*>(p.gamma + cq) : one;
+  c.mu = (p.dy && p.c1) ? *reinterpret_cast<const f32x4*>(p.mean + cq) : zero;
+  c.c1 = (p.dy && p.c1) ? *reinterpret_cast<const f32x4*>(p.c1 + cq) : zero;
+  c.c2 = (p.dy && p.c1) ? *reinterpret_cast<const f32x4*>(p.c2 + cq) : zero;
+  const bool from_y = !p.mbits && !p.a && p.mscale;
+  c.msc = from_y ? *reinterpret_cast<const f32x4*>(p.mscale + cq) : one;
+  c.msh = from_y ? *reinterpret_cast<const f32x4*>(p.mshift + cq) : zero;
+  return c;
+}
+__device__ __forceinline__ void bwd_elem(const BnBwdArgs& p, long i, long m, int cq, const BwdCol& col) {
+  f32x4 dz = *reinterpret_cast<const f32x4*>(p.dA + m * p.ldd + cq);
+  f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+  if (p.y) yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
+  if (p.mbits) {
+    const unsigned mb = p.mbits[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dz[k] = (mb >> k) & 1u ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
+  } else if (p.a) {
+    f32x4 av = *reinterpret_cast<const f32x4*>(p.a + m * p.lda + cq);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
+  } else if (p.mscale) {
+    f32x4 av = yv * col.msc + col.msh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
+  }
+  if (p.dres) {
+    float* dr = p.dres + m * p.ldr + cq;
+    f32x4 o = dz;
+    if (p.dres_accumulate) o = o + *reinterpret_cast<const f32x4*>(dr);
+    *reinterpret_cast<f32x4*>(dr) = o;
+  }
+  if (p.dy) {
+    f32x4 out;
+    if (p.c1) {
+      f32x4 xhat = (yv - col.mu) * col.is;
+      out = col.g * col.is * (dz - col.c1 - xhat * col.c2);
+    } else {
+      out = col.g * col.is * dz;
+    }
+    *reinterpret_cast<f32x4*>(p.dy + m * p.ldo + cq) = out;
+  }
+}
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
   const int c4n = p.C >> 2;
   const long total = p.M * c4n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / c4n;
-    const int cq = (int)(i - m * c4n) * 4;
-    f32x4 dz = *reinterpret_cast<const f32x4*>(p.dA + m * p.ldd + cq);
-    f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-    if (p.y) yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
-    if (p.mbits) {
-      const unsigned mb = p.mbits[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dz[k] = (mb >> k) & 1u ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
-    } else if (p.a) {
-      f32x4 av = *reinterpret_cast<const f32x4*>(p.a + m * p.lda + cq);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
-    } else if (p.mscale) {
-      f32x4 av = yv * *reinterpret_cast<const f32x4*>(p.mscale + cq) + *reinterpret_cast<const f32x4*>(p.mshift + cq);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
-    }
-    if (p.dres) {
-      float* dr = p.dres + m * p.ldr + cq;
-      f32x4 o = dz;
-      if (p.dres_accumulate) o = o + *reinterpret_cast<const f32x4*>(dr);
-      *reinterpret_cast<f32x4*>(dr) = o;
-    }
-    if (p.dy) {
-      f32x4 is = *reinterpret_cast<const f32x4*>(p.invstd + cq);
-      f32x4 g = p.gamma ? *reinterpret_cast<const f32x4*>(p.gamma + cq) : f32x4{1.f, 1.f, 1.f, 1.f};
-      f32x4 out;
-      if (p.c1) {
-        f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + cq);
-        f32x4 xhat = (yv - mu) * is;
-        out = g * is * (dz - *reinterpret_cast<const f32x4*>(p.c1 + cq) - xhat * *reinterpret_cast<const f32x4*>(p.c2 + cq));
-      } else {
-        out = g * is * dz;
-      }
-      *reinterpret_cast<f32x4*>(p.dy + m * p.ldo + cq) = out;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (stride % c4n == 0) {   // the thread keeps its channel quad: its seven per-channel operands are read once (affine_act_kernel)
+    long m = i0 / c4n;
+    const int cq = (int)(i0 - m * c4n) * 4;
+    const long dm = stride / c4n;
+    const BwdCol col = bwd_col(p, cq);
+    for (long i = i0; i < total; i += stride, m += dm) bwd_elem(p, i, m, cq, col);
+  } else {
+    for (long i = i0; i < total; i += stride) {
+      const long m = i / c4n;
+      const int cq = (int)(i - m * c4n) * 4;
+      bwd_elem(p, i, m, cq, bwd_col(p, cq));
     }
   }
 }
