@@ -236,6 +236,10 @@ int zs3_gather_cat_noise(const float* a, int lda, const long* idx, int Ca, int C
 /* out = dropout_backward(dy; p, seed, row_idx) * leaky_relu'(h; leak): Dropout + LeakyReLU backward of gmmn.py:19-22 */
 int zs3_dropout_act_bwd(const float* dy, int ldd, const float* h, int ldh, float* out, int ldo, long M, int C, float p,
                         unsigned long long seed, const long* row_idx, const void* seed_dev, float leak, void* stream);
+/* out = srcs[0] + ... + srcs[n-1] in that order, 2 <= n <= 8 dense fp32 arrays of `count` elements: the gradient of a tensor
+ * with several consumers (aspp.py:104-108: x feeds five branches; deeplab.py:41-42: layer1's output feeds layer2 and the
+ * decoder) in one pass -- autograd would add pairwise.  srcs: HOST array of device pointers; out may alias srcs[0]. */
+int zs3_sum_n(const void* const* srcs, int n, float* out, long count, void* stream);
 /* out[c] = sum_m x[m][c] (rows in order): bias gradients of the generator's Linear layers */
 int zs3_colsum(const float* x, int ldx, int M, int C, float* out, void* stream);
 /* torch.optim.Adam for several tensors in one launch, device-resident step count; table[e] = {p, g, exp_avg, exp_avg_sq,

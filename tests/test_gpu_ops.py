@@ -646,3 +646,23 @@ def test_stem_wgrad_folds_the_taps(dev, hw):
     assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
     # the pad lanes of the windows (8th pixel, 4th channel) multiply zero weights in the forward; their gradient entries are
     # whatever the window holds and are dropped by the view above -- nothing to assert about them
+
+
+def test_fork_sums_consumer_gradients_in_one_launch(dev):
+    """Fz.fork: n aliases of a tensor for n consumers (ASPP's input, layer1's output); backward = zs3_sum_n over the consumers'
+    gradients in consumer order, equal to autograd's pairwise accumulation up to summation order."""
+    from zs3_amd import functional as Fz
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 9, 11, 64, generator=g).to(dev).requires_grad_()
+    ws = [torch.randn(2, 9, 11, 64, generator=g).to(dev) for _ in range(5)]
+    parts = Fz.fork(x, 5)
+    assert all(p.data_ptr() == x.data_ptr() for p in parts)
+    sum((p * w).sum() for p, w in zip(parts[:4], ws)).backward()     # the fifth consumer contributes no gradient
+    want = ws[0] + ws[1] + ws[2] + ws[3]
+    assert torch.allclose(x.grad, want, rtol=1e-6, atol=1e-6)
+    x.grad = None
+    a, b = Fz.fork(x, 2)
+    (a * ws[0]).sum().backward()                                      # one live consumer: its gradient is handed through
+    assert torch.equal(x.grad, ws[0])
+    with torch.no_grad():
+        assert Fz.fork(x, 3)[2] is x

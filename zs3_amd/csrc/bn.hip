@@ -11,6 +11,7 @@
 // Replaces native_batch_norm fwd/bwd + relu_/threshold_backward + residual add_ at resnet.py:33-53,
 // aspp.py:25-29,111-116, decoder.py:30-32,15-24 (113 BN layers; numerics of F.batch_norm, i.e.
 // invstd = 1/sqrt(var_biased + eps), running_var uses the unbiased variance).
+#include <cstdint>
 #include <cstdlib>
 #include "common.h"
 #include "zs3hip.h"
@@ -363,6 +364,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
   }
 }
 
+// out = src[0] + src[1] + ... (fixed order), float4: the gradient of a tensor that feeds several branches (ASPP's input has
+// five consumers, layer1's output two) in one pass instead of n-1 pairwise library adds
+struct SumArgs {
+  const float* src[8];
+  float* out;
+  long n4;
+  int n;
+};
+__global__ __launch_bounds__(256) void sum_n_kernel(const SumArgs p) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < p.n) v[k] = reinterpret_cast<const f32x4*>(p.src[k])[i];
+    f32x4 acc = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (k < p.n) acc += v[k];
+    reinterpret_cast<f32x4*>(p.out)[i] = acc;
+  }
+}
+
 // out[g][c] = scale * sum_{r<R} x[(g*R + r)][c]     (global average pool, pooled-branch backward)
 // (64 channel quads per block left the ASPP pool -- 16 images x 2048 channels x 1089 pixels, 143 MB -- with 128 workgroups of
 // 272-row serial chains: 154 us; 16 quads per block = 512 workgroups, 68 rows per thread.)
@@ -512,5 +535,19 @@ extern "C" int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, fl
   int tx_n = c4n < GCS_TX ? c4n : GCS_TX;
   dim3 grid((c4n + tx_n - 1) / tx_n, G);
   hipLaunchKernelGGL(group_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, scale, out, ldo);
+  return ZS3_LAUNCH_CHECK();
+}
+
+/* out[i] = src[0][i] + ... + src[n-1][i], 2 <= n <= 8 dense fp32 arrays of `count` elements (count % 4 == 0, 16-byte aligned);
+ * srcs: HOST array of n device pointers.  out may alias src[0]. */
+extern "C" int zs3_sum_n(const void* const* srcs, int n, float* out, long count, void* stream) {
+  if (n < 2 || n > 8 || count <= 0 || (count & 3) || ((uintptr_t)out & 15)) return -1;
+  SumArgs a = {};
+  for (int k = 0; k < n; ++k) {
+    if (!srcs[k] || ((uintptr_t)srcs[k] & 15)) return -1;
+    a.src[k] = (const float*)srcs[k];
+  }
+  a.out = out; a.n4 = count / 4; a.n = n;
+  hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(count / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }

@@ -5,6 +5,7 @@ contiguous).  Each Function is one *fused layer* (conv + BatchNorm + residual + 
 training step is ~150 autograd nodes instead of ~700 ATen ops.  Nothing here falls back to torch
 compute: tensors must live on the GPU and libzs3hip.so must be present.
 """
+import ctypes
 import os
 import random
 import weakref
@@ -627,6 +628,47 @@ class _Broadcast(torch.autograd.Function):
 
 def broadcast_to(x, size, out=None):
     return _Broadcast.apply(x, tuple(size), out)
+
+
+class _Fork(torch.autograd.Function):
+    """x -> n aliases of x for n consumers; the backward adds the n gradients in ONE launch (zs3_sum_n) in consumer order,
+    where autograd would add them pairwise (n-1 passes over the tensor: ASPP's input has five consumers, aspp.py:104-108)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view(x.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        dense = [_dense_rows(g) for g in gs]
+        same = all(g.shape == dense[0].shape and g.stride() == dense[0].stride() and g.dtype == torch.float32 and g.is_cuda
+                   for g in dense)
+        n = dense[0].numel()
+        if not same or len(dense) > 8 or n % 4 or ops._rows(dense[0])[2] != dense[0].shape[-1]:
+            out = dense[0]
+            for g in dense[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(dense[0])
+        ptrs = (ctypes.c_void_p * len(dense))(*[g.data_ptr() for g in dense])
+        ops.check(ops.lib().zs3_sum_n(ptrs, ops.I(len(dense)), ops.P(out), ctypes.c_long(n), ops.stream()), "zs3_sum_n")
+        return out, None
+
+
+FORK_SUM = os.environ.get("ZS3_FORK_SUM", "1") != "0"   # 0: leave the fan-out gradients to autograd's pairwise accumulation
+
+
+def fork(x, n):
+    """n aliases of x, one per consumer (see _Fork); a plain tuple of x when nothing needs a gradient"""
+    if n < 2 or not FORK_SUM or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return _Fork.apply(x, n)
 
 
 class _CatSlices(torch.autograd.Function):

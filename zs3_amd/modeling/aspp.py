@@ -76,12 +76,14 @@ class ASPP(nn.Module):
         cat = torch.empty((n, h, w, 1280), dtype=torch.float32, device=x.device)
         bn = self.global_avg_pool[2] if isinstance(self.global_avg_pool[2], nn.BatchNorm2d) else None
 
+        xs = Fz.fork(x, 5)    # five consumers: their gradients are added in one launch, not pairwise
+
         def branch(i):
             br = (self.aspp1, self.aspp2, self.aspp3, self.aspp4)[i]
-            return br.forward_nhwc(x, out=cat[..., 256 * i:256 * (i + 1)])
+            return br.forward_nhwc(xs[i], out=cat[..., 256 * i:256 * (i + 1)])
 
         def pooled():
-            p = self.global_avg_pool[1].forward_nhwc(Fz.global_avg_pool(x), bn, act=Fz.ACT_RELU)   # [N,1,1,256]
+            p = self.global_avg_pool[1].forward_nhwc(Fz.global_avg_pool(xs[4]), bn, act=Fz.ACT_RELU)   # [N,1,1,256]
             return Fz.broadcast_to(p, (h, w), out=cat[..., 1024:1280])
 
         concurrent = x.is_cuda and not torch.cuda.is_current_stream_capturing()

@@ -97,7 +97,7 @@ class ResNet(nn.Module):
         x = Fz.max_pool(x, 3, 2, 1)
         for blk in self.layer1:
             x = blk.forward_nhwc(x)
-        low = x
+        x, low = Fz.fork(x, 2)   # layer1's output feeds layer2 and the decoder (deeplab.py:41-42): gradients added by zs3_sum_n
         for layer in (self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 x = blk.forward_nhwc(x)
