@@ -60,7 +60,10 @@ def pick_tile(m, ncols, k=0):
     # >= ~1000 tiles (>= 2 resident per CU for several rounds), else 64x64 (4 blocks per CU).  The rules were re-checked
     # inside the whole step (same-box A/B runs of bench.py): layers that are a toss-up in isolation favour the small
     # tiles there (3x3 128->128: -0.24 ms per step on 64x64 tiles although the DMA kernel is level in isolation), and
-    # the DMA kernel must keep the 1x1 1024->256 layers (+1.1 ms per step without it).
+    # the DMA kernel must keep the 1x1 1024->256 layers (+1.1 ms per step without it).  Re-checked at the end of round 2 with the
+    # wgrad streams at 96 CUs (tools/probe/r2v.sh, same box, ms per step): these rules 47.0 / 47.3; short-K wide layers on the
+    # DMA kernel 47.4 / 47.6, on 128x128 tiles 47.0 / 47.3; the 128x128-vs-64x64 switch at 400 tiles 47.4 / 47.1, at 3000
+    # tiles 47.3 / 47.1 -- nothing left in the rules.
     if ncols <= 64:
         return 14
     if m >= 8192 and k >= 512 and ncols >= 256:
