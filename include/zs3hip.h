@@ -93,10 +93,12 @@ int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace,
 int zs3_colstats_plan(int M, int C, int* chunks, int* rows_per_block);
 int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, void* stream);
 /* ReLU mask, first that is given: mask_bits (one byte per 4 channels, dense [M][C/4], written by zs3_affine_act),
-   a_out (> 0), or recomputed as y*mask_scale + mask_shift > 0 (layers without residual) */
+   a_out (> 0), or recomputed as y*mask_scale + mask_shift > 0 (layers without residual).
+   drop_p > 0: dA is the gradient of a dropout fused behind the activation (zs3_affine_act): its mask is applied first. */
 int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
                      const float* invstd, const float* mask_scale, const float* mask_shift,
-                     const unsigned char* mask_bits, int M, int C, float* partial, void* stream);
+                     const unsigned char* mask_bits, int M, int C, float* partial, float drop_p,
+                     unsigned long long drop_seed, void* stream);
 /* num_batches_tracked (nullable): BatchNorm's int64 step counter, incremented by the kernel.
    count_dev (nullable): device-resident sample count that overrides `count` (cross-rank SyncBN: the count is
    all-reduced together with the sums and never visits the host) */
@@ -111,15 +113,19 @@ int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, c
                         float* dbeta, float* c1, float* c2, int use_batch_stats, void* stream);
 /* out[m][c] = act(alpha*(x[m/div][c]*scale[c] + shift[c]) + res[m][c]) (+= if accumulate); act 0/1/2.
    mask_out (nullable): [M][C/4] bytes, bit k of byte q = "pre-activation value of channel 4q+k was > 0" -- the
-   residual blocks' ReLU mask for the backward pass, 1/16 of the bytes of re-reading the output twice */
+   residual blocks' ReLU mask for the backward pass, 1/16 of the bytes of re-reading the output twice.
+   drop_p > 0: nn.Dropout fused behind the activation (aspp.py:100, decoder.py:19,23): out = keep ? act(...)/(1-p) : 0 with
+   the mask zs3_dropout draws for (drop_seed, element m*C + c) -- saves a read + write of the activation per dropout. */
 int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shift, float alpha, const float* res,
                    int ldr, float* out, int ldo, long M, int C, int div, int act, float leak, int accumulate,
-                   unsigned char* mask_out, void* stream);
-/* dz = act'(a_out)*dA; dres (=|+=) dz; dy = gamma*invstd*(dz - c1 - xhat*c2)  (c1==NULL: dy = gamma*invstd*dz) */
+                   unsigned char* mask_out, float drop_p, unsigned long long drop_seed, void* stream);
+/* dz = act'(a_out)*dA; dres (=|+=) dz; dy = gamma*invstd*(dz - c1 - xhat*c2)  (c1==NULL: dy = gamma*invstd*dz);
+   drop_p > 0: dA is first passed through the backward of the fused dropout (same mask, recomputed) */
 int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
                    const float* invstd, const float* gamma, const float* c1, const float* c2, const float* mask_scale,
                    const float* mask_shift, const unsigned char* mask_bits, float* dy, int ldo, float* dres, int ldr,
-                   int dres_accumulate, long M, int C, int act, float leak, void* stream);
+                   int dres_accumulate, long M, int C, int act, float leak, float drop_p, unsigned long long drop_seed,
+                   void* stream);
 /* out[g][c] = scale * sum_{r<R} x[g*R + r][c]: AdaptiveAvgPool2d((1,1)) of aspp.py:85 and its broadcast backward */
 int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo, void* stream);
 

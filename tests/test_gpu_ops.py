@@ -666,3 +666,45 @@ def test_fork_sums_consumer_gradients_in_one_launch(dev):
     assert torch.equal(x.grad, ws[0])
     with torch.no_grad():
         assert Fz.fork(x, 3)[2] is x
+
+
+@pytest.mark.parametrize("mode", ["train", "frozen_bn", "no_grad"])
+def test_dropout_fused_into_bn_apply_equals_separate_pass(dev, monkeypatch, mode):
+    """conv + BN + ReLU + nn.Dropout (aspp.py:97-100, decoder.py:16-23) as ONE fused layer (mask applied inside zs3_affine_act,
+    its backward inside zs3_bn_act_bwd / zs3_bn_bwd_stats) against the same layer with the stand-alone dropout pass: same seed
+    stream position, same mask, same arithmetic -> identical outputs and gradients."""
+    from zs3_amd import functional as Fz
+    from zs3_amd.modeling.layers import BatchNorm2d, Conv2d, Dropout
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randn(2, 17, 19, 32, generator=g).to(dev)
+    wt = torch.randn(2, 17, 19, 64, generator=g).to(dev)
+    torch.manual_seed(4)
+    conv0 = Conv2d(32, 64, 3, padding=1, bias=False)
+    bn0 = BatchNorm2d(64)
+    with torch.no_grad():
+        bn0.weight.uniform_(0.5, 1.5)
+        bn0.bias.uniform_(-0.3, 0.3)
+    results = []
+    for fused in (True, False):
+        monkeypatch.setattr(Fz, "DROPOUT_FUSED", fused)
+        Fz.manual_seed(21)
+        import copy
+        conv, bn, drop = copy.deepcopy(conv0).to(dev), copy.deepcopy(bn0).to(dev), Dropout(0.3)
+        conv.to_channels_last_()
+        if mode == "frozen_bn":
+            bn.eval()
+        x = x0.clone().requires_grad_(mode != "no_grad")
+        if mode == "no_grad":
+            with torch.no_grad():
+                y = conv.forward_nhwc(x, bn, act=Fz.ACT_RELU, dropout=drop)
+            results.append([y])
+            continue
+        y = conv.forward_nhwc(x, bn, act=Fz.ACT_RELU, dropout=drop)
+        (y * wt).sum().backward()
+        results.append([y.detach(), x.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(),
+                        bn.running_var.clone()])
+    keep = (results[0][0] != 0).float().mean().item()
+    assert 0.25 < keep < 0.45          # ReLU zeros + 30 % dropped
+    for a, b in zip(*results):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), (mode, (a - b).abs().max().item())
+    assert torch.equal(results[0][0], results[1][0])

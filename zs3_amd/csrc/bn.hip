@@ -32,6 +32,8 @@ struct ColArgs {
   const unsigned char* mbits;  // MODE1, optional: ReLU mask as one byte per 4 channels (bit k = channel 4q+k was positive)
   float* partial;
   int M, C, ldx, lda, ldy, rows_per_block;
+  float drop_p, drop_inv_keep;          // MODE1, optional: dA is the gradient of dropout(act(bn(y))): its mask is applied first
+  unsigned long long drop_seed;
 };
 
 template <int MODE>
@@ -66,6 +68,11 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
           q += v * v;
         } else {
           f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + (size_t)r * p.ldy + cq * 4);
+          if (p.drop_p > 0.f) {
+            const unsigned long long e = (unsigned long long)r * p.C + cq * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = u01(p.drop_seed, e + k) >= p.drop_p ? v[k] * p.drop_inv_keep : 0.f;
+          }
           if (p.mbits) {
             const unsigned mb = p.mbits[(size_t)r * c4n + cq];
 #pragma unroll
@@ -221,6 +228,8 @@ struct AffArgs {
   long M;
   int C, ldx, ldr, ldo, div, act, accumulate;
   float alpha, leak;
+  float drop_p, drop_inv_keep;          // > 0: out = dropout(act(...)), mask of element (m, c) = u01(drop_seed, m*C + c) >= p
+  unsigned long long drop_seed;         // (the mask zs3_dropout draws on the dense [M][C] tensor)
 };
 // per-channel operands of one float4 column: loaded once per thread when the grid stride is a multiple of the row length (every
 // power-of-two channel count: the thread then stays in its column), else once per element
@@ -249,6 +258,11 @@ __device__ __forceinline__ void aff_elem(const AffArgs& p, long i, long m, int c
   } else if (p.act == 2) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * p.leak;
+  }
+  if (p.drop_p > 0.f) {   // nn.Dropout fused behind the activation (aspp.py:100, decoder.py:19,23)
+    const unsigned long long e = (unsigned long long)m * p.C + cq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = u01(p.drop_seed, e + k) >= p.drop_p ? v[k] * p.drop_inv_keep : 0.f;
   }
   float* dst = p.out + m * p.ldo + cq;
   if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
@@ -293,6 +307,8 @@ struct BnBwdArgs {
   long M;
   int C, ldd, lda, ldy, ldo, ldr, dres_accumulate, act;
   float leak;
+  float drop_p, drop_inv_keep;          // > 0: dA is the gradient of the dropout output (see AffArgs)
+  unsigned long long drop_seed;
 };
 struct BwdCol {
   f32x4 is, g, mu, c1, c2, msc, msh;
@@ -314,6 +330,11 @@ __device__ __forceinline__ void bwd_elem(const BnBwdArgs& p, long i, long m, int
   f32x4 dz = *reinterpret_cast<const f32x4*>(p.dA + m * p.ldd + cq);
   f32x4 yv = {0.f, 0.f, 0.f, 0.f};
   if (p.y) yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
+  if (p.drop_p > 0.f) {   // backward of the fused dropout: the same mask, recomputed
+    const unsigned long long e = (unsigned long long)m * p.C + cq;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dz[k] = u01(p.drop_seed, e + k) >= p.drop_p ? dz[k] * p.drop_inv_keep : 0.f;
+  }
   if (p.mbits) {
     const unsigned mb = p.mbits[i];
 #pragma unroll
@@ -451,9 +472,10 @@ extern "C" int zs3_colstats(const float* x, int ldx, int M, int C, float* partia
 extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
                                 const float* mean, const float* invstd, const float* mask_scale,
                                 const float* mask_shift, const unsigned char* mask_bits, int M, int C, float* partial,
-                                void* stream) {
-  if (C % 4 || ldd % 4 || ldy % 4 || (a_out && lda % 4)) return -1;
+                                float drop_p, unsigned long long drop_seed, void* stream) {
+  if (C % 4 || ldd % 4 || ldy % 4 || (a_out && lda % 4) || drop_p < 0.f || drop_p >= 1.f) return -1;
   ColArgs a{};
+  a.drop_p = drop_p; a.drop_inv_keep = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
   a.x = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.partial = partial;
   a.mscale = mask_scale; a.mshift = mask_shift; a.mbits = mask_bits;
   a.M = M; a.C = C; a.ldx = ldd; a.lda = lda; a.ldy = ldy;
@@ -501,10 +523,12 @@ extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, doub
 
 extern "C" int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shift, float alpha,
                               const float* res, int ldr, float* out, int ldo, long M, int C, int div, int act,
-                              float leak, int accumulate, unsigned char* mask_out, void* stream) {
-  if (C % 4 || ldx % 4 || ldo % 4 || (res && ldr % 4)) return -1;
+                              float leak, int accumulate, unsigned char* mask_out, float drop_p,
+                              unsigned long long drop_seed, void* stream) {
+  if (C % 4 || ldx % 4 || ldo % 4 || (res && ldr % 4) || drop_p < 0.f || drop_p >= 1.f) return -1;
   if (M <= 0) return 0;
   AffArgs a;
+  a.drop_p = drop_p; a.drop_inv_keep = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
   a.x = x; a.scale = scale; a.shift = shift; a.res = res; a.out = out; a.mask = mask_out; a.M = M; a.C = C; a.ldx = ldx; a.ldr = ldr;
   a.ldo = ldo; a.div = div; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.leak = leak;
   hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
@@ -515,10 +539,12 @@ extern "C" int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int 
                               const float* mean, const float* invstd, const float* gamma, const float* c1,
                               const float* c2, const float* mask_scale, const float* mask_shift,
                               const unsigned char* mask_bits, float* dy, int ldo, float* dres, int ldr,
-                              int dres_accumulate, long M, int C, int act, float leak, void* stream) {
-  if (C % 4 || ldd % 4 || (dy && ldo % 4) || (a_out && lda % 4) || (dres && ldr % 4)) return -1;
+                              int dres_accumulate, long M, int C, int act, float leak, float drop_p,
+                              unsigned long long drop_seed, void* stream) {
+  if (C % 4 || ldd % 4 || (dy && ldo % 4) || (a_out && lda % 4) || (dres && ldr % 4) || drop_p < 0.f || drop_p >= 1.f) return -1;
   if (M <= 0) return 0;
   BnBwdArgs a;
+  a.drop_p = drop_p; a.drop_inv_keep = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
   a.dA = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.c1 = c1; a.c2 = c2;
   a.mscale = mask_scale; a.mshift = mask_shift; a.mbits = mask_bits;
   a.dy = dy; a.dres = dres; a.M = M; a.C = C; a.ldd = ldd; a.lda = lda; a.ldy = ldy; a.ldo = ldo; a.ldr = ldr;

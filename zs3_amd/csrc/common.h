@@ -62,6 +62,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// splitmix64-style counter hash -> 24-bit uniform in [0,1): the one random stream of the library (dropout masks, generator
+// noise).  A value is a pure function of (seed, element index), so any kernel that needs the mask of an element recomputes it.
+__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -20,15 +20,6 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f4;
 
-// same counter hash as misc.hip (the masks / noise of a replayed update must not depend on which kernel draws them)
-__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 // eight fp32 values -> the bf16 hi / lo fragments of one MFMA operand (bf16x3 split, common.h)
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
   unsigned h[4], l[4];

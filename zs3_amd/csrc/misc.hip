@@ -7,15 +7,6 @@
 
 namespace {
 
-// splitmix64-style counter hash -> 24-bit uniform in [0,1)
-__device__ __forceinline__ float u01(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 inline int ew_blocks(long total) {
   long b = (total + 255) / 256;
   if (b > 16384) b = 16384;

@@ -23,6 +23,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # next to the dgrad / BatchNorm chain; the main stream joins it once, at the end of backward.
 WGRAD_SIDE_STREAM = True
 FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
+DROPOUT_FUSED = os.environ.get("ZS3_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind conv+BN+ReLU inside the BN-apply pass
 LAZY_SKIP_GRAD = True      # identity blocks: the skip gradient dA*mask is applied by conv1's dgrad epilogue, never stored
 _lazy_skip = {}            # data_ptr of a block-output gradient -> (tensor, sign bits) it still has to be masked with
 # The layers' weight gradients are independent of each other: with WGRAD_STREAMS > 1 they go round-robin over a small pool
@@ -225,6 +226,7 @@ class _ConvBnAct(torch.autograd.Function):
         out = cfg.get("out")
         leak = cfg.get("leak", 0.2)
         prec = cfg.get("prec")
+        drop = cfg.get("drop")   # (p, seed): nn.Dropout behind this layer's activation, fused into affine_act / bn_act_bwd
         y = a = st = mbits = None
         conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, **k)) if geom is None else (
             lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, **geom, **k))
@@ -240,15 +242,17 @@ class _ConvBnAct(torch.autograd.Function):
             st = ops.bn_fwd_finalize(part, count, gamma, beta, bn["eps"], bn["momentum"], bn["running_mean"],
                                      bn["running_var"], bn.get("nbt"))
             mbits = _mask_bits_for(y, act, residual, need_grad)
-            a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits)
+            a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits, drop=drop)
         elif bn is not None:
             st = ops.bn_eval_affine(gamma, beta, bn["running_mean"], bn["running_var"], bn["eps"])
             if need_grad:
                 y, _ = conv()
                 mbits = _mask_bits_for(y, act, residual, need_grad)
-                a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits)
+                a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits, drop=drop)
             else:
                 a, _ = conv(scale=st[2], shift=st[3], res=residual, act=act, leak=leak, out=out)
+                if drop is not None:   # conv epilogue path (no gradient needed): the dropout stays a pass of its own
+                    a = ops.dropout(a, drop[0], drop[1], out=a)
         else:
             a, _ = conv(shift=bias, res=residual, act=act, leak=leak, out=out)
         ctx.cfg = cfg
@@ -298,7 +302,7 @@ class _ConvBnAct(torch.autograd.Function):
                     ops._rows(dA)[2] == dA.shape[-1]:
                 part = link.partial      # summed by the consumer's dgrad epilogue
             else:
-                part = ops.bn_bwd_stats(dA, a, y, st[0], st[1], msc, msh, mbits)
+                part = ops.bn_bwd_stats(dA, a, y, st[0], st[1], msc, msh, mbits, drop=cfg.get("drop"))
             if link is not None:
                 link.partial = link.y = link.mbits = None
             sync = (cfg.get("bn") or {}).get("sync") if ctx.bn_training else None
@@ -313,7 +317,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dgamma, dbeta = fin[0], fin[1]
                 c1, c2 = (fin[2], fin[3]) if ctx.bn_training else (None, None)
             dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, dres=dres, act=act, leak=leak, mask_scale=msc,
-                                mask_shift=msh, mask_bits=mbits)
+                                mask_shift=msh, mask_bits=mbits, drop=cfg.get("drop"))
             if lazy:
                 if len(_lazy_skip) > 256:
                     _lazy_skip.clear()
@@ -436,14 +440,27 @@ def _act_grad(a, act, leak):
 
 
 def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
-                leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False):
+                leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False, dropout=None):
     """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None.
     input_has_one_consumer: promise that `x` feeds nothing but this layer (and, with pass_through, the skip tensor this
     layer hands back), which lets this layer's dgrad produce the BN-backward sums of the layer that made `x` (BnLink)."""
+    # dropout: (p, training) of an nn.Dropout that follows this layer's activation.  conv + BN + ReLU layers without a residual
+    # (every dropout of the network sits behind one: aspp.py:100, decoder.py:19,23) take it into the BN-apply pass and its
+    # backward (same mask as the stand-alone kernel, same position in the seed stream); anything else gets the separate pass.
+    drop, drop_after = None, None
+    if dropout is not None and dropout[1] and dropout[0] > 0.0:
+        if dropout[0] >= 1.0:
+            drop_after = (1.0, None)
+        elif bn is not None and residual is None and act == ACT_RELU and not pass_through and DROPOUT_FUSED:
+            drop = (float(dropout[0]), next_seed())
+        else:
+            drop_after = (float(dropout[0]), None)
     cfg = {"stride": stride, "pad": pad, "dil": dil, "act": act, "out": out, "leak": leak, "prec": prec, "geom": geom,
+           "drop": drop,
            "wgrad": wgrad, "pass_through": pass_through,
            "in_link": getattr(x, "_zs3_bn_link", None) if (input_has_one_consumer and FUSE_BN_BWD_STATS) else None,
-           "out_link": BnLink() if (bn is not None and out is None and FUSE_BN_BWD_STATS) else None,
+           # (no hand-off behind a fused dropout: the consumer's dgrad sees the gradient of the DROPPED activation)
+           "out_link": BnLink() if (bn is not None and out is None and FUSE_BN_BWD_STATS and drop is None) else None,
            "need_grad": torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
                                                         (x, weight, bias, residual, getattr(bn, "weight", None)))}
     gamma = beta = None
@@ -467,6 +484,10 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
         (res[0] if pass_through else res)._zs3_bn_link = cfg["out_link"]
     if pass_through:
         res[1]._zs3_skip_alias = True   # lets the block's last layer know who will receive its skip gradient
+    if drop_after is not None:
+        if pass_through:
+            raise NotImplementedError("dropout behind a pass-through layer")
+        res = _dropout_pass(res, drop_after[0], True)
     return res
 
 
@@ -711,3 +732,6 @@ def dropout(x, p, training):
     if p >= 1.0:
         return x * 0.0
     return _Dropout.apply(x, float(p), next_seed())
+
+
+_dropout_pass = dropout   # conv_bn_act has a keyword of that name

@@ -104,8 +104,7 @@ class ASPP(nn.Module):
                 parts[4] = pooled()
             main.wait_stream(s1)
             main.wait_stream(s2)
-        y = self.conv1.forward_nhwc(Fz.cat_slices(cat, parts), self.bn1, act=Fz.ACT_RELU)
-        return self.dropout.forward_nhwc(y)
+        return self.conv1.forward_nhwc(Fz.cat_slices(cat, parts), self.bn1, act=Fz.ACT_RELU, dropout=self.dropout)
 
     def forward(self, x):
         return ops.nchw(self.forward_nhwc(ops.nhwc(x)))

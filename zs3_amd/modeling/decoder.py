@@ -32,10 +32,10 @@ class Decoder(nn.Module):
 
     def _head(self, x, first=True, second=True):
         lc = self.last_conv
-        if first:
-            x = lc[3].forward_nhwc(lc[0].forward_nhwc(x, lc[1], act=Fz.ACT_RELU))
-        if second:
-            x = lc[7].forward_nhwc(lc[4].forward_nhwc(x, lc[5], act=Fz.ACT_RELU))
+        if first:     # conv + BN + ReLU + Dropout(0.5): one fused layer
+            x = lc[0].forward_nhwc(x, lc[1], act=Fz.ACT_RELU, dropout=lc[3])
+        if second:    # ... + Dropout(0.1)
+            x = lc[4].forward_nhwc(x, lc[5], act=Fz.ACT_RELU, dropout=lc[7])
         return x
 
     def features_nhwc(self, x, low):

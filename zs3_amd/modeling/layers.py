@@ -20,10 +20,12 @@ class Conv2d(nn.Conv2d):
         return self
 
     def forward_nhwc(self, x, bn=None, residual=None, act=Fz.ACT_NONE, out=None, pass_through=False,
-                     input_has_one_consumer=False):
+                     input_has_one_consumer=False, dropout=None):
+        """dropout: the nn.Dropout module that follows bn + act in the reference's Sequential (fused where possible)"""
         return Fz.conv_bn_act(x, self.weight, bn=bn, bias=self.bias, residual=residual, stride=self.stride[0],
                               pad=self.padding[0], dil=self.dilation[0], act=act, out=out, pass_through=pass_through,
-                              input_has_one_consumer=input_has_one_consumer)
+                              input_has_one_consumer=input_has_one_consumer,
+                              dropout=None if dropout is None else (dropout.p, dropout.training))
 
     def forward(self, x):  # logical NCHW in / out
         return ops.nchw(self.forward_nhwc(ops.nhwc(x)))

@@ -303,9 +303,17 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps):
     return out
 
 
+def _drop_args(drop):
+    """drop: None or (p, seed) of a dropout fused behind the activation -> the two trailing C arguments"""
+    if drop is None:
+        return F(0.0), ctypes.c_ulonglong(0)
+    return F(drop[0]), ctypes.c_ulonglong(drop[1])
+
+
 def affine_act(x, scale=None, shift=None, alpha=1.0, res=None, out=None, div=1, act=0, leak=0.2, accumulate=False,
-               out_shape=None, mask_out=None):
-    """mask_out: optional uint8 tensor of M*C/4 bytes receiving the sign bits of the pre-activation values."""
+               out_shape=None, mask_out=None, drop=None):
+    """mask_out: optional uint8 tensor of M*C/4 bytes receiving the sign bits of the pre-activation values.
+    drop: (p, seed) -- nn.Dropout fused behind the activation, the mask `dropout(out, p, seed)` would draw."""
     require_gpu(x, scale, shift, res, out)
     m_in, c, ldx = _rows(x)
     if out is None:
@@ -314,12 +322,12 @@ def affine_act(x, scale=None, shift=None, alpha=1.0, res=None, out=None, div=1, 
     assert c2 == c and m == m_in * div
     ldr = _rows(res)[2] if res is not None else 0
     check(lib().zs3_affine_act(P(x), I(ldx), P(scale), P(shift), F(alpha), P(res), I(ldr), P(out), I(ldo),
-                               ctypes.c_long(m), I(c), I(div), I(act), F(leak), I(int(accumulate)), P(mask_out), stream()),
-          "zs3_affine_act")
+                               ctypes.c_long(m), I(c), I(div), I(act), F(leak), I(int(accumulate)), P(mask_out), *_drop_args(drop),
+                               stream()), "zs3_affine_act")
     return out
 
 
-def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None, mask_bits=None):
+def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None, mask_bits=None, drop=None):
     m, c, ldd = _rows(dA)
     lda = _rows(a_out)[2] if a_out is not None else 0
     ldy = _rows(y)[2]
@@ -327,7 +335,7 @@ def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None, m
     lib().zs3_colstats_plan(I(m), I(c), ctypes.byref(chunks), ctypes.byref(rpb))
     part = torch.empty((chunks.value, 2, c), dtype=torch.float32, device=dA.device)
     check(lib().zs3_bn_bwd_stats(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), P(mask_scale), P(mask_shift),
-                                 P(mask_bits), I(m), I(c), P(part), stream()), "zs3_bn_bwd_stats")
+                                 P(mask_bits), I(m), I(c), P(part), *_drop_args(drop), stream()), "zs3_bn_bwd_stats")
     return part
 
 
@@ -346,7 +354,7 @@ def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True):
 
 
 def bn_act_bwd(dA, a_out, y, mean, invstd, gamma, c1, c2, dy=None, dres=None, dres_accumulate=False, act=1, leak=0.2,
-               want_dy=True, mask_scale=None, mask_shift=None, mask_bits=None):
+               want_dy=True, mask_scale=None, mask_shift=None, mask_bits=None, drop=None):
     require_gpu(dA, a_out, y, dy, dres)
     m, c, ldd = _rows(dA)
     if want_dy and dy is None:
@@ -357,7 +365,7 @@ def bn_act_bwd(dA, a_out, y, mean, invstd, gamma, c1, c2, dy=None, dres=None, dr
     ldr = _rows(dres)[2] if dres is not None else 0
     check(lib().zs3_bn_act_bwd(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), P(gamma), P(c1), P(c2),
                                P(mask_scale), P(mask_shift), P(mask_bits), P(dy), I(ldo), P(dres), I(ldr), I(int(dres_accumulate)), ctypes.c_long(m), I(c), I(act),
-                               F(leak), stream()), "zs3_bn_act_bwd")
+                               F(leak), *_drop_args(drop), stream()), "zs3_bn_act_bwd")
     return dy
 
 
