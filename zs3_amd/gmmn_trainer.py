@@ -45,6 +45,12 @@ def _rows_gemm(x, wp, b, act=Fz.ACT_NONE, leak=0.2):
     return y.view(n, wp.cout)
 
 
+# Captured chains of generator updates (table mode): powers of two up to ZS3_GMMN_CHAIN.  A chain boundary costs a graph launch
+# (~100-200 us of idle queue when the host is not far enough ahead), so longer chains = fewer boundaries per step.
+CHAIN_MAX = max(1, int(os.environ.get("ZS3_GMMN_CHAIN", "32")))
+CHAIN_SIZES = tuple(1 << k for k in range(CHAIN_MAX.bit_length() - 1, -1, -1))
+
+
 class GMMNStep:
     def __init__(self, model, generator, optimizer, optimizer_generator, criterion, *, seen, unseen, noise_dim=300,
                  embed_dim=300, feature_dim=256, batch_size_generator=128, real_seen_features=True,
@@ -323,7 +329,7 @@ class GMMNStep:
         else:
             table_mode = bool(self._st.get("table_mode"))
             left = count
-            for size in ((32, 16, 8, 4, 2, 1) if table_mode else (1,)):
+            for size in (CHAIN_SIZES if table_mode else (1,)):
                 while left >= size:
                     key = (training, self.noise, self.context_aware, table_mode, size)
                     g = self._update_graphs.get(key)
