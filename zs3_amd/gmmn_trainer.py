@@ -52,6 +52,8 @@ CHAIN_SIZES = tuple(1 << k for k in range(CHAIN_MAX.bit_length() - 1, -1, -1))
 
 
 class GMMNStep:
+    _hook_reads_generator = True   # does _after_image() need the generator's weights up to date? (GCNContextStep: no)
+
     def __init__(self, model, generator, optimizer, optimizer_generator, criterion, *, seen, unseen, noise_dim=300,
                  embed_dim=300, feature_dim=256, batch_size_generator=128, real_seen_features=True,
                  sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True, group=None, grad_reduce=None,
@@ -393,6 +395,9 @@ class GMMNStep:
     def _after_image(self, i, label_map, real_rows_i, has_unseen):
         """called after image i's generator updates; self._st["emb"] holds its embedding rows at feature resolution"""
 
+    def _join_side_work(self):
+        pass
+
     def _extra_classifier_terms(self):
         """called after the CE backward of the stitched batch, before the gradient exchange and the SGD step"""
 
@@ -521,7 +526,8 @@ class GMMNStep:
             st["ring"] = torch.zeros((n_mmd, self.bsg), dtype=torch.int64).pin_memory()
         st["ring_pos"] = 0
         pending = 0        # table mode: sampled updates queued but not yet replayed
-        per_image_hook = type(self)._after_image is not GMMNStep._after_image
+        # a subclass hook after every image forces the queued generator updates out first only if it reads the generator
+        per_image_hook = type(self)._after_image is not GMMNStep._after_image and self._hook_reads_generator
         for i in range(b):
             classes = [c for c in range(256) if hist_h[i][c] > 0]
             has_unseen = any(c in self.unseen for c in classes)
@@ -632,6 +638,7 @@ class GMMNStep:
                 self._run_sampled_update(training, pending)
                 pending = 0
             self._after_image(i, tgt_l[i].view(fh, fw), real_rows[i], has_unseen)
+        self._join_side_work()       # (subclasses: per-image work that was queued on another stream)
         pg = None if self.group is True else self.group
         if self.group is not None:   # generator replicas -> their average (parameters only; Adam moments stay per rank)
             from .parallel import all_reduce_tensors
