@@ -224,3 +224,38 @@ def test_evaluator_seen_unseen_matches_the_reference(golden):
     ev = Evaluator_seen_unseen(21, [10, 14])
     h = ev._fast_hist(gt[0].ravel(), pred[0].ravel(), 21, target="unseen", unseen=[10, 14])
     assert h.sum() == np.isin(gt[0], [10, 14]).sum() and h[[c for c in range(21) if c not in (10, 14)]].sum() == 0
+
+
+def test_binding_declares_every_signature_from_the_header(libpath):
+    """zs3_amd/_lib.py derives ctypes argtypes / restype for every exported function from include/zs3hip.h: a call with the
+    wrong number or kind of arguments fails in Python instead of corrupting the callee's stack."""
+    from zs3_amd import _lib
+    handle = ctypes.CDLL(libpath)
+    _lib._declare(handle)
+    header = open(os.path.join(ROOT, "include", "zs3hip.h")).read()
+    declared = set(re.findall(r"^(?:int|long)\s+(zs3_\w+)\s*\(", header, flags=re.M))
+    for name in declared:
+        fn = getattr(handle, name)
+        assert fn.argtypes is not None, name
+    assert handle.zs3_ce_ws_doubles.argtypes == [] and handle.zs3_conv_streamk_workspace_bytes.restype is ctypes.c_long
+    assert len(handle.zs3_affine_act.argtypes) == 19          # x .. mask_out, drop_p, drop_seed, stream
+    with pytest.raises((ctypes.ArgumentError, TypeError)):
+        handle.zs3_colstats_plan(1000, 64)                      # two of four arguments
+    with pytest.raises((ctypes.ArgumentError, TypeError)):
+        handle.zs3_conv_igemm_mtiles("not an int", 256, 1)
+
+
+def test_bench_refuses_to_run_without_the_devices_it_was_asked_for():
+    """`python bench.py --gpus N` spawns its own ranks only when the node has N devices, and the product never falls back to
+    the CPU: both refusals are loud (this container has no GPU)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "only 0 GPU(s) visible" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
