@@ -1,0 +1,174 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_halo.hip): the launch arguments and
+// the fused output-tile epilogue (affine / residual / activation / accumulate, BatchNorm partial sums).
+#pragma once
+#include "common.h"
+
+namespace zs3conv {
+
+struct ConvArgs {
+  const float* x;
+  const unsigned short* w_pk;   // [ncols][K/32][{hi,lo}][32] bf16 (zs3_prep_weight)
+  float* y;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* stat_partial;
+  const float* zero;   // >= 256 B of zeros: source of every masked (padding / out-of-range) load
+  int N, H, W, Ho, Wo;
+  int cin_pad, cin_valid, ldx;
+  int KH, KW, stride, pad_h, pad_w, dil;
+  int ncols, ldw, ldy, ldr, M;
+  int act, accumulate, dgrad, stride_log2;
+  float leak;
+  // optional BatchNorm-backward statistics of the layer whose output gradient this launch produces (dgrad epilogue):
+  // bs_partial[mtile][2][ncols] = (sum dz, sum dz*xhat) with dz = stored value * ReLU mask, xhat = (bs_y - mean) * istd
+  const float* bs_y;
+  const float* bs_mean;
+  const float* bs_istd;
+  const float* bs_msc;            // mask = bs_y * msc + msh > 0 (no residual) ...
+  const float* bs_msh;
+  const unsigned char* bs_mbits;  // ... or sign bits [M][ncols/4] (residual layers)
+  float* bs_partial;
+  int bs_ldy;
+  // optional ReLU mask applied to `res` before it is added (sign bytes [M][ncols/4]): the skip gradient of a residual
+  // block is (block-output gradient) * mask, taken straight from the block-output gradient instead of a stored copy
+  const unsigned char* res_mbits;
+  // stream-K launches of the LDS-DMA kernel (tile_cfg 32): partial-tile slabs [grid][128 KB], one arrival flag per block
+  // (+ one error word), the launch's epoch (flags are compared with it, never reset)
+  float* sk_ws;
+  unsigned* sk_flags;
+  unsigned sk_epoch;
+};
+
+// conv_halo.hip: strip-resident 3x3 (any multi-tap, stride-1, same-size) convolution, tile_cfg 41 (256-row tiles) / 42 (192).
+// `bm` = 0 asks whether the launch is eligible at all (returns 1 / 0); otherwise launches and returns the HIP status.
+int halo_eligible(const ConvArgs& a, int bm, int prec);
+int launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st);
+
+}  // namespace zs3conv
+using zs3conv::ConvArgs;
+
+namespace {
+
+// Rows [0, nrows) of an LDS-staged output tile -> global memory as dwordx4 per lane, with the fused epilogue (affine,
+// residual, activation, accumulate).  `c4`/`r0` = this thread's column quad / first row, RPP = rows per pass.  When
+// p.bs_partial is set the thread also accumulates the BN-backward sums of its 4 columns over the rows it stores.
+// Stream-K owner: `sk` lists the partial tiles of the other workgroups that worked on this tile (raw fp32, row-major
+// [256][128] slabs); their rows are added to the staged rows before the fused epilogue, and the BatchNorm forward sums
+// (sum, sum of squares of the completed raw values) are accumulated here instead of from the accumulator registers.
+struct SkParts {
+  const float* part[4];
+  int n;          // number of partial tiles (0: none)
+  int row0;       // first tile row of the staged rows (0 or 128)
+  bool stats;     // accumulate fs_s / fs_q
+};
+template <int RPP>
+__device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* ctile, int ldc, int row_base, int nrows,
+                                                int col, int c4, int r0, f32x4 sc, f32x4 sh, bool affine, bool vec,
+                                                f32x4& bs_s, f32x4& bs_q, const SkParts* sk = nullptr,
+                                                f32x4* fs_s = nullptr, f32x4* fs_q = nullptr) {
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
+  const bool bstat = p.bs_partial != nullptr && vec && col < p.ncols;
+  if (bstat) {
+    mu = *reinterpret_cast<const f32x4*>(p.bs_mean + col);
+    is = *reinterpret_cast<const f32x4*>(p.bs_istd + col);
+    if (p.bs_msc) {
+      msc = *reinterpret_cast<const f32x4*>(p.bs_msc + col);
+      msh = *reinterpret_cast<const f32x4*>(p.bs_msh + col);
+    }
+  }
+  for (int rr = r0; rr < nrows; rr += RPP) {
+    const int row = row_base + rr;
+    if (row >= p.M || col >= p.ncols) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
+    if (sk) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)   // static indices: the pointers stay in registers
+        if (k < sk->n) v += *reinterpret_cast<const f32x4*>(sk->part[k] + (size_t)(sk->row0 + rr) * 128 + c4 * 4);
+      if (sk->stats) {
+        *fs_s += v;
+        *fs_q += v * v;
+      }
+    }
+    if (affine) v = v * sc + sh;
+    float* dst = p.y + (size_t)row * p.ldy + col;
+    if (vec) {
+      if (p.res) {
+        f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+        if (p.res_mbits) {
+          const unsigned mb = p.res_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rv[e] = (mb >> e) & 1u ? rv[e] : 0.f;
+        }
+        v = v + rv;
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
+      }
+      if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = v;
+      if (bstat) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(p.bs_y + (size_t)row * p.bs_ldy + col);
+        f32x4 dz = v;
+        if (p.bs_mbits) {
+          const unsigned mb = p.bs_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[e] = (mb >> e) & 1u ? dz[e] : 0.f;
+        } else if (p.bs_msc) {
+          const f32x4 av = yv * msc + msh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[e] = av[e] > 0.f ? dz[e] : 0.f;
+        }
+        bs_s += dz;
+        bs_q += dz * ((yv - mu) * is);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < p.ncols) {
+          float t = v[e];
+          if (p.res) t += p.res[(size_t)row * p.ldr + col + e];
+          if (p.act == 1) t = fmaxf(t, 0.f);
+          else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
+          if (p.accumulate) t += dst[e];
+          dst[e] = t;
+        }
+    }
+  }
+}
+
+// Block reduction of the per-thread BN-backward sums (fixed order: deterministic) and store of this row tile's partials.
+// Thread (r0, c4) holds the sums of columns 4*c4..4*c4+3 over its rows; `red` needs 2 * RPP * BN floats of LDS.
+template <int BN, int RPP, int NT>
+__device__ __forceinline__ void finish_bwd_stats(const ConvArgs& p, float* red, int tid, int c4, int r0, int mt, int n0,
+                                                 f32x4 bs_s, f32x4 bs_q, float* dst = nullptr) {
+  if (!dst) dst = p.bs_partial;
+  __syncthreads();   // the output tile in LDS is no longer read
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[r0 * BN + c4 * 4 + e] = bs_s[e];
+    red[(RPP + r0) * BN + c4 * 4 + e] = bs_q[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < BN; c += NT) {
+    const int col = n0 + c;
+    if (col < p.ncols) {
+      float ts = 0.f, tq = 0.f;
+      for (int g = 0; g < RPP; ++g) {
+        ts += red[g * BN + c];
+        tq += red[(RPP + g) * BN + c];
+      }
+      dst[((size_t)mt * 2 + 0) * p.ncols + col] = ts;
+      dst[((size_t)mt * 2 + 1) * p.ncols + col] = tq;
+    }
+  }
+}
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+}  // namespace

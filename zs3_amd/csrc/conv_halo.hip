@@ -1,0 +1,486 @@
+// Strip-resident multi-tap convolution for gfx950 (MI355X): forward and data-gradient of every stride-1, same-size
+// KHxKW convolution (the 3x3 / dilated 3x3 layers of the network), tile_cfg 41 (256-row tiles) and 42 (192-row tiles).
+//
+// The implicit-GEMM kernels of conv_igemm.hip fetch the A operand (256 output pixels x 32 channels) from L2 once per
+// filter tap: nine times per channel chunk for a 3x3 layer, and the measured bound of their K loop is exactly that
+// L2 -> LDS path (48 KB per K step against the ~23 B/clk/CU it delivers).  Here the nine taps share one staged copy:
+//
+//   * In flattened pixel space (m = (n*H + y)*W + x) tap (dy,dx) of output pixel m reads input pixel m + dy*W + dx, so a
+//     tile of BM consecutive output pixels needs the contiguous *strip* of input pixels [m0 + off_min, m0 + BM + off_max).
+//     For a 3x3, dilation-d layer that is BM + 2d(W+1) rows: 1.27x the tile at W = 33, 2x at W = 129 -- instead of 9x.
+//   * Two producer waves load the strip of one channel chunk (16 channels in bf16x3 mode, 32 in plain-bf16 mode) from
+//     L2 into registers ONCE, split it into bf16 hi/lo there and write 64-byte rows [hi | lo] into LDS (double buffered:
+//     the strip of chunk c+1 is converted while the nine taps of chunk c are multiplied).  The fp32 -> bf16 split -- 65 %
+//     of the issue slots of the LDS-DMA kernel's consumers -- is done once per element instead of once per tap and has
+//     left the MFMA waves altogether.
+//   * Two more producer waves stream the weight tile of every K step (128 columns x 64 B, the hi/lo lines of
+//     zs3_prep_weight) with global_load_lds_dwordx4 into a 3-slot ring, two steps ahead, counted vmcnt.
+//   * Four consumer waves (2x2, (BM/2)x64 wave tiles) do nothing but ds_read_b128 + MFMA: a tap is a *shifted window*
+//     of the strip (row + dy*W + dx), image-border taps are redirected per lane to a zero row (9-bit mask per row,
+//     computed once per tile).  Rows are 64 B apart; 16-byte chunk q of strip / weight row r sits at q ^ ((r>>2)&3), so
+//     the 16 lanes of a ds_read_b128 group (16 consecutive rows, any window shift) cover all 64 banks.
+//
+// L2 -> CU bytes per K16 step: 8 KB of weights + strip/9 (2.7 KB at W = 33) against 24 KB before.
+//
+// The epilogue (BatchNorm partial sums, affine / residual / activation / accumulate, BN-backward sums) is the shared
+// one of conv_common.h.  Replaces: the 3x3 nn.Conv2d of resnet.py:18-26 (layer 2-4 conv2), aspp.py:11-19 (atrous
+// branches), decoder.py:15-24 (last_conv) and their data gradients.
+#include <type_traits>
+
+#include "conv_common.h"
+#include "zs3hip.h"
+
+namespace {
+
+struct HaloGeom {
+  int off_min;     // smallest tap offset in flattened pixels (<= 0)
+  int s_pad;       // strip rows (multiple of 32)
+  int npass;       // 32-row conversion passes per strip
+  int npg;         // passes per K-step interval (<= 4)
+  int nch;         // channel chunks
+  int ns;          // K steps, rounded up to even (an odd tail step multiplies zeros)
+  int T;           // filter taps
+  int sgn;         // +1 forward, -1 dgrad (tap offsets mirrored)
+  int lds_bytes;
+};
+
+constexpr int HALO_BSLOT = 8192, HALO_NSLOT = 3;
+constexpr int HALO_OFF_ZERO = HALO_NSLOT * HALO_BSLOT;   // 256 B of zeros: where masked taps read
+constexpr int HALO_OFF_TAPS = HALO_OFF_ZERO + 128;    // int[16]: tap offsets in flattened pixels
+constexpr int HALO_OFF_STRIP = HALO_OFF_ZERO + 256;
+constexpr int HALO_MAXP = 4;
+
+template <int PREC, int BM, int NPG>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const HaloGeom g) {
+  constexpr int BN = 128, TM = BM / 64, TN = 2, CH = PREC == 3 ? 16 : 32;
+  constexpr int NAB = (TM % 2 == 0) ? 2 : 3;   // A-fragment buffers: fragment i lives in buffer i % NAB
+  static_assert((TM - 1) % NAB != 0, "the next step's first A fragment is prefetched into buffer 0 during the last sub-step");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = (p.ncols + BN - 1) / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / ntn, nt = tile - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int T = g.T, NS = g.nch * T, NSR = g.ns;
+  const int strip_bytes = g.s_pad * 64;
+  const bool producer = wave >= 4;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+
+  f32x16 acc[TM][TN];
+
+  if (wave >= 6) {
+    // ------------------------------------------------------------------ strip producers (128 lanes)
+    // A pass converts 32 strip rows: 4 lanes per row, each 4 (bf16x3) or 8 (plain bf16) consecutive channels.
+    constexpr int NV = PREC == 3 ? 1 : 2;
+    const int pl = tid - 384, prow = pl >> 2, cq = pl & 3;
+    const long Mtot = (long)p.N * p.H * p.W;
+    const long q0 = (long)m0 + g.off_min;
+    // NPG passes per K-step interval, a compile-time count: the group's loads are straight-line code and issue back to
+    // back (with a run-time count hipcc guards every load with a branch and waits vmcnt(0) before each one -- one L2
+    // round trip per pass).  A group that reaches past the strip's last pass repeats that pass (same data, same rows).
+    f32x4 buf[NPG][NV];
+    auto load_pass = [&](int k, int pass, int c) {
+      pass = pass < g.npass ? pass : g.npass - 1;
+      long q = q0 + pass * 32 + prow;
+      q = q < 0 ? 0 : (q >= Mtot ? Mtot - 1 : q);
+      const int ch0 = c * CH + cq * (CH / 4);
+      const float* src = p.x + q * p.ldx + ch0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const float* s = ch0 + 4 * v < p.cin_valid ? src + 4 * v : p.zero;
+        buf[k][v] = *reinterpret_cast<const f32x4*>(s);
+      }
+    };
+    auto write_pass = [&](int k, int pass, int sb) {
+      pass = pass < g.npass ? pass : g.npass - 1;
+      const int s = pass * 32 + prow, sw = (s >> 2) & 3;
+      unsigned char* row = dsm + HALO_OFF_STRIP + sb * strip_bytes + s * 64;
+      if (PREC == 3) {
+        u32x2 hi, lo;
+        unsigned h, l;
+        split_pair<3>(buf[k][0][0], buf[k][0][1], h, l); hi[0] = h; lo[0] = l;
+        split_pair<3>(buf[k][0][2], buf[k][0][3], h, l); hi[1] = h; lo[1] = l;
+        const int o = (((cq >> 1) ^ sw) << 4) + (cq & 1) * 8;
+        *reinterpret_cast<u32x2*>(row + o) = hi;
+        *reinterpret_cast<u32x2*>(row + (o ^ 32)) = lo;
+      } else {
+        u32x4 hi;
+        hi[0] = cvt_pk_bf16(buf[k][0][0], buf[k][0][1]);
+        hi[1] = cvt_pk_bf16(buf[k][0][2], buf[k][0][3]);
+        hi[2] = cvt_pk_bf16(buf[k][NV - 1][0], buf[k][NV - 1][1]);
+        hi[3] = cvt_pk_bf16(buf[k][NV - 1][2], buf[k][NV - 1][3]);
+        *reinterpret_cast<u32x4*>(row + ((cq ^ sw) << 4)) = hi;
+      }
+    };
+    if (pl < 8) *reinterpret_cast<u32x4*>(dsm + HALO_OFF_ZERO + pl * 16) = u32x4{0u, 0u, 0u, 0u};
+    if (pl < T) {   // flattened-pixel offset of every tap, read back by the consumers once per K step
+      const int th = pl / p.KW, tw = pl - th * p.KW;
+      *reinterpret_cast<int*>(dsm + HALO_OFF_TAPS + pl * 4) = g.sgn * ((th * p.dil - p.pad_h) * p.W + (tw * p.dil - p.pad_w));
+    }
+    // strip of chunk 0 (nothing to overlap it with yet)
+    for (int pass0 = 0; pass0 < g.npass; pass0 += NPG) {
+#pragma unroll
+      for (int k = 0; k < NPG; ++k) load_pass(k, pass0 + k, 0);
+#pragma unroll
+      for (int k = 0; k < NPG; ++k) write_pass(k, pass0 + k, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // B_0
+    // interval (c, t): write the passes loaded one interval ago, then load the next group -- all for the strip of chunk c+1
+    int c = 0, t = 0;
+    for (int s = 0; s < NSR; ++s) {
+      const bool live = c + 1 < g.nch;
+      if (live && t >= 1) {
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) write_pass(k, (t - 1) * NPG + k, (c + 1) & 1);
+      }
+      if (live && t + 1 < T) {
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) load_pass(k, t * NPG + k, c + 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // B_{s+1}
+      if (++t == T) {
+        t = 0;
+        ++c;
+      }
+    }
+  } else if (wave >= 4) {
+    // ------------------------------------------------------------------ weight producers (LDS-DMA, 128 lanes)
+    // One instruction = 16 tile rows x 4 chunks of 16 B; the two waves issue 4 each per K step (128 rows x 64 B).
+    const int pw = wave - 4;
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);   // which 16-byte chunk of its row this lane fetches
+    const int qoff = PREC == 3 ? (q & 1) * 16 + (q >> 1) * 64 : q * 16;
+    const unsigned char* wptr[4];
+    int wstep[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int col = n0 + (pw * 4 + k) * 16 + (lane >> 2);
+      const bool ok = col < p.ncols;
+      wptr[k] = ok ? reinterpret_cast<const unsigned char*>(p.w_pk) + (size_t)col * (4 * (size_t)p.ldw) + qoff
+                   : reinterpret_cast<const unsigned char*>(p.zero) + (lane & 3) * 16;
+      wstep[k] = ok ? 1 : 0;
+    }
+    int c = 0, t = 0;
+    auto issue = [&](int slot) {
+      const int kofs = t * p.cin_pad + c * CH;
+      int uoff = (kofs >> 5) * 128 + (PREC == 3 ? ((kofs >> 4) & 1) * 32 : 0);
+      if (c >= g.nch) uoff = -1;   // the padding step of an odd K loop: zeros
+      unsigned char* dst = dsm + slot * HALO_BSLOT + pw * 4096;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned char* src = uoff >= 0 ? wptr[k] + (size_t)uoff * wstep[k]
+                                             : reinterpret_cast<const unsigned char*>(p.zero) + (lane & 3) * 16;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + k * 1024), 16, 0, 0);
+      }
+      if (++t == T) {
+        t = 0;
+        ++c;
+      }
+    };
+    issue(0);
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // B_0: tile 0 has landed
+    int st2 = 2;
+    for (int s = 0; s < NSR; ++s) {
+      if (s + 2 < NSR) {
+        issue(st2);
+        st2 = st2 == HALO_NSLOT - 1 ? 0 : st2 + 1;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile s+1 has landed, tile s+2 stays in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // B_{s+1}
+    }
+  } else {
+    // ------------------------------------------------------------------ consumers: ds_read_b128 + MFMA only
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, kh = lane >> 5;
+    // tap masks of this lane's TM rows (bit t: tap t reads inside the image)
+    unsigned vmask[TM];
+    {
+      const int hw = p.H * p.W;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + lr;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / hw, rem = mm - n * hw;
+        const int y = rem / p.W, x = rem - y * p.W;
+        unsigned mk = 0u;
+        for (int t = 0; t < T; ++t) {
+          const int th = t / p.KW, tw = t - th * p.KW;
+          const int iy = y + g.sgn * (th * p.dil - p.pad_h), ix = x + g.sgn * (tw * p.dil - p.pad_w);
+          if (ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mk |= 1u << t;
+        }
+        vmask[i] = mk;
+      }
+    }
+    const int rb = wm * (BM / 2) + lr - g.off_min;                      // strip row of row block 0 at tap offset 0
+    const unsigned boff = (unsigned)((wn * 64 + lr) * 64 + ((kh ^ ((lr >> 2) & 3)) << 4));   // weight-tile row of column block 0
+    const unsigned zaddr = HALO_OFF_ZERO;
+
+    bf16x8 a_hi[NAB], a_lo[NAB];
+    bf16x8 b_hi[2][TN], b_lo[2][TN];
+    // K-step state (wave-uniform): tap rt / chunk rc of the step whose window is computed next
+    int rt = 0, rc = 0;
+    unsigned a0 = 0u, tbit = 0u;     // strip address of row block 0 / mask bit of the step being read
+    unsigned a0n = 0u, tbitn = 0u;   // the same for the step after it (computed a sub-step early, in the MFMA shadow)
+    int toff = 0;
+    auto next_tap = [&]() { toff = *reinterpret_cast<const int*>(dsm + HALO_OFF_TAPS + rt * 4); };   // a sub-step before its use
+    auto next_window = [&]() {       // (toff, rt, rc) -> a0n, tbitn
+      const int s0 = rb + toff;
+      a0n = (unsigned)(HALO_OFF_STRIP + (rc & 1) * strip_bytes + s0 * 64 + ((kh ^ ((s0 >> 2) & 3)) << 4));
+      tbitn = rc < g.nch ? 1u << rt : 0u;   // the padding step of an odd K loop reads the zero row
+    };
+    auto read_a = [&](int i) {
+      const unsigned addr = (vmask[i] & tbit) ? a0 + i * 2048 : zaddr;
+      a_hi[i % NAB] = *reinterpret_cast<const bf16x8*>(dsm + addr);
+      a_lo[i % NAB] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
+    };
+    auto read_b = [&](int set, int slot) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned addr = slot * HALO_BSLOT + boff + j * 2048;
+        b_hi[set][j] = *reinterpret_cast<const bf16x8*>(dsm + addr);
+        b_lo[set][j] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
+      }
+    };
+    auto advance_read = [&]() {
+      const bool wrap = rt + 1 == T;
+      rt = wrap ? 0 : rt + 1;
+      rc += wrap ? 1 : 0;
+    };
+    int slot = 0;
+    // one K step: TM sub-steps (row blocks); the MFMAs of sub-step i run from registers while the next row block's
+    // fragment is read; the step barrier sits before the last sub-step, which prefetches the next step's first A
+    // fragment and its weight fragments (the other register set).  Every MFMA slot is pinned (sched_barrier): hipcc
+    // otherwise hoists all LDS reads and issues the MFMAs as one clump.
+    auto step = [&](auto setc) {
+      constexpr int SET = decltype(setc)::value;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i == TM - 1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();   // next step's weight tile has landed; this step's LDS reads are done
+          asm volatile("" ::: "memory");
+          a0 = a0n;
+          tbit = tbitn;
+          slot = slot == HALO_NSLOT - 1 ? 0 : slot + 1;
+        }
+        const bf16x8 ah = a_hi[i % NAB], al = a_lo[i % NAB];
+        if (PREC == 3) {
+#pragma unroll
+          for (int m = 0; m < 3 * TN; ++m) {
+            const int pr = m / TN, j = m % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al : ah, pr == 1 ? b_lo[SET][j] : b_hi[SET][j],
+                                                                acc[i][j], 0, 0, 0);
+            if (m == 0) {
+              if (i < TM - 1) {
+                read_a(i + 1);
+              } else {
+                read_a(0);
+                read_b(SET ^ 1, slot);
+              }
+            }
+            if (i == 0 && m == 1) {
+              advance_read();
+              next_tap();
+            }
+            if (i == 1 && m == 1) next_window();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < 2 * TN; ++m) {
+            const int pr = m / TN, j = m % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? ah : al, pr == 0 ? b_hi[SET][j] : b_lo[SET][j],
+                                                                acc[i][j], 0, 0, 0);
+            if (m == 0) {
+              if (i < TM - 1) {
+                read_a(i + 1);
+              } else {
+                read_a(0);
+                read_b(SET ^ 1, slot);
+              }
+            }
+            if (i == 0 && m == 1) {
+              advance_read();
+              next_tap();
+            }
+            if (i == 1 && m == 1) next_window();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
+    __builtin_amdgcn_s_barrier();   // B_0: strip 0 and weight tile 0 are in LDS
+    asm volatile("" ::: "memory");
+    next_tap();
+    next_window();
+    a0 = a0n;
+    tbit = tbitn;
+    read_a(0);
+    read_b(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < NSR; s += 2) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+    }
+  }
+
+  // ---------------------------------------------------------------------- epilogue (all eight waves store rows)
+  __syncthreads();   // every DMA has landed and been consumed; nobody reads the operand LDS any more
+  float* ctile = reinterpret_cast<float*>(dsm);
+  if (p.stat_partial) {
+    float* red = ctile;
+    if (!producer) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float s = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            s += v;
+            q2 = fmaf(v, v, q2);
+          }
+        s += __shfl_xor(s, 32, 64);
+        q2 += __shfl_xor(q2, 32, 64);
+        if (lane < 32) {
+          red[(wm * 2 + 0) * BN + wn * 64 + j * 32 + lane] = s;
+          red[(wm * 2 + 1) * BN + wn * 64 + j * 32 + lane] = q2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int col = n0 + tid;
+      if (col < p.ncols) {
+        p.stat_partial[((size_t)mt * 2 + 0) * p.ncols + col] = red[tid] + red[2 * BN + tid];
+        p.stat_partial[((size_t)mt * 2 + 1) * p.ncols + col] = red[BN + tid] + red[3 * BN + tid];
+      }
+    }
+  }
+  constexpr int LDC = BN + 4;
+  const bool affine = (p.scale != nullptr) || (p.shift != nullptr);
+  constexpr int C4 = BN / 4, RPP = 512 / C4;
+  const int c4 = tid % C4, r0 = tid / C4;
+  const int col = n0 + c4 * 4;
+  const bool vec = ((p.ldy & 3) == 0) && ((p.ncols & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (col + e < p.ncols) {
+      if (p.scale) sc[e] = p.scale[col + e];
+      if (p.shift) sh[e] = p.shift[col + e];
+    }
+  f32x4 bs_s = {0.f, 0.f, 0.f, 0.f}, bs_q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (!producer && wm == half) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ctile[row * LDC + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
+  }
+  if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
+}
+
+bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
+  const int T = a.KH * a.KW;
+  if (a.stride != 1 || a.H != a.Ho || a.W != a.Wo || T < 3 || T > 16) return false;
+  if ((a.ldx & 3) || (a.cin_valid & 3) || (a.cin_pad & 31) || a.M <= 0) return false;
+  if (bm != 256 && bm != 192) return false;
+  HaloGeom g;
+  g.T = T;
+  g.sgn = a.dgrad ? -1 : 1;
+  long omin = 0, omax = 0;
+  for (int th = 0; th < a.KH; ++th)
+    for (int tw = 0; tw < a.KW; ++tw) {
+      const long o = (long)g.sgn * ((long)(th * a.dil - a.pad_h) * a.W + (tw * a.dil - a.pad_w));
+      omin = o < omin ? o : omin;
+      omax = o > omax ? o : omax;
+    }
+  const long S = bm + omax - omin;
+  if (S > 4096) return false;
+  g.off_min = (int)omin;
+  g.s_pad = (int)((S + 31) / 32 * 32);
+  g.npass = g.s_pad / 32;
+  g.npg = (g.npass + (T - 2)) / (T - 1);
+  if (g.npg > HALO_MAXP) return false;
+  const int ch = prec == 3 ? 16 : 32;
+  g.nch = (a.cin_valid + ch - 1) / ch;
+  if (g.nch * ch > a.cin_pad) return false;
+  g.ns = (g.nch * T + 1) & ~1;
+  const int epi = (bm / 2) * (128 + 4) * 4;
+  const int loop = HALO_OFF_STRIP + 2 * g.s_pad * 64;
+  g.lds_bytes = loop > epi ? loop : epi;
+  if (g.lds_bytes > 160 * 1024) return false;
+  if (out) *out = g;
+  return true;
+}
+
+template <int PREC, int BM, int NPG>
+int launch_halo_n(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<PREC, BM, NPG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return -4;
+    configured = true;
+  }
+  const int grid = ((a.M + BM - 1) / BM) * ((a.ncols + 127) / 128);
+  hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG>), dim3(grid), dim3(512), g.lds_bytes, st, a, g);
+  return ZS3_LAUNCH_CHECK();
+}
+template <int PREC, int BM>
+int launch_halo_t(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
+  switch (g.npg) {
+    case 1: return launch_halo_n<PREC, BM, 1>(a, g, st);
+    case 2: return launch_halo_n<PREC, BM, 2>(a, g, st);
+    case 3: return launch_halo_n<PREC, BM, 3>(a, g, st);
+    case 4: return launch_halo_n<PREC, BM, 4>(a, g, st);
+  }
+  return -7;
+}
+
+}  // namespace
+
+int zs3conv::halo_eligible(const ConvArgs& a, int bm, int prec) { return halo_geometry(a, bm, prec, nullptr) ? 1 : 0; }
+
+int zs3conv::launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st) {
+  HaloGeom g;
+  if (!halo_geometry(a, bm, prec, &g)) return -7;
+  if (bm == 256) return prec == 1 ? launch_halo_t<1, 256>(a, g, st) : launch_halo_t<3, 256>(a, g, st);
+  return prec == 1 ? launch_halo_t<1, 192>(a, g, st) : launch_halo_t<3, 192>(a, g, st);
+}
+
+// Whether tile_cfg 41 / 42 can run this convolution (callers fall back to tile_cfg 31 otherwise).
+extern "C" int zs3_conv_halo_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW,
+                                int stride, int pad_h, int pad_w, int dil, int dgrad, int prec, int tile_cfg) {
+  ConvArgs a{};
+  a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  a.cin_pad = cin_pad; a.cin_valid = cin_valid; a.ldx = ldx;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w; a.dil = dil;
+  a.dgrad = dgrad; a.M = N * Ho * Wo;
+  return zs3conv::halo_eligible(a, tile_cfg == 42 ? 192 : 256, prec);
+}

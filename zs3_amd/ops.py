@@ -51,6 +51,27 @@ def streamk_errors():
 STREAMK = os.environ.get("ZS3_STREAMK", "0") == "1"
 
 
+HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
+
+
+def halo_ok(x_shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg):
+    """zs3_conv_halo_ok: can tile_cfg 41 / 42 (csrc/conv_halo.hip) run this launch?"""
+    n, h, w_ = x_shape[:3]
+    return bool(lib().zs3_conv_halo_ok(I(n), I(h), I(w_), I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride),
+                                       I(pad_h), I(pad_w), I(dil), I(int(dgrad)), I(prec), I(tile_cfg)))
+
+
+def pick_halo_tile(m, ncols):
+    """256- or 192-row tiles for the strip-resident kernel: the tile height that needs fewer rounds x rows on 256 CUs
+    (16 x 33 x 33 output pixels x 256 channels: 138 tiles of 256 rows -> one round at 54 % of the chip; 182 tiles of
+    192 rows -> one round at 71 %, each 0.75x as long)."""
+    nt = (ncols + 127) // 128
+    def cost(bm):
+        tiles = ((m + bm - 1) // bm) * nt
+        return ((tiles + 255) // 256) * (bm + 24)      # + ~24 rows' worth of prologue / epilogue per tile
+    return 42 if cost(192) < cost(256) else 41
+
+
 def pick_tile(m, ncols, k=0):
     """Tile / kernel choice for the implicit-GEMM conv (zs3_conv_igemm tile_cfg): 1x = register-staged 4-wave kernel
     (11: 128x128, 14: 64x64 block tile), 31 = wave-specialised 256x128 kernel fed by LDS-DMA."""
@@ -176,6 +197,16 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     m = n * ho * wo
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
+        if HALO and tile_cfg in (31, 32) and kh * kw > 1:
+            cand = pick_halo_tile(m, ncols)
+            if halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, cand):
+                tile_cfg = cand
+            elif cand == 41 and halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad,
+                                        prec, 42):
+                tile_cfg = 42      # the strip of a 256-row tile does not fit the LDS (ASPP, dilation 12): 192 rows do
+    elif tile_cfg in (41, 42) and not halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil,
+                                              dgrad, prec, tile_cfg):
+        tile_cfg = 31              # not a stride-1 same-size multi-tap layer (or the strip does not fit)
     if tile_cfg == 32:
         if torch.cuda.is_current_stream_capturing():
             tile_cfg = 31      # the workspace registration allocates: not inside a graph capture
@@ -212,7 +243,8 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
               "zs3_conv_igemm")
     if prof:
         e1.record()
-        PROFILE.append(("conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
+        PROFILE.append(("conv_halo<%d,128,%d>" % (256 if tile_cfg == 41 else 192, prec) if tile_cfg in (41, 42) else
+                        "conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
 
