@@ -55,7 +55,7 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 5e-5
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 21, 31, 32])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 21, 31, 32, 41, 42])
 def test_conv_every_tile_config(dev, cfg):
     """every kernel variant behind zs3_conv_igemm (register-staged tiles, wave-specialised, LDS-DMA) on ragged shapes:
     M tails, channel tails (304 -> 320, 21 -> 24), stride 2, dilation, fused epilogue and BN partial sums"""
@@ -92,7 +92,7 @@ def test_conv_every_tile_config(dev, cfg):
         assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 5e-5, (cfg, ci, co)
 
 
-@pytest.mark.parametrize("cfg", [11, 14, 21, 31, 32])
+@pytest.mark.parametrize("cfg", [11, 14, 21, 31, 32, 41, 42])
 @pytest.mark.parametrize("mask", ["none", "from_y", "bits"])
 def test_dgrad_epilogue_bn_backward_sums(dev, cfg, mask):
     """zs3_conv_igemm_bnstats: the dgrad epilogue's (sum dz, sum dz*xhat) equal the separate zs3_bn_bwd_stats pass over the
@@ -708,3 +708,53 @@ def test_dropout_fused_into_bn_apply_equals_separate_pass(dev, monkeypatch, mode
     for a, b in zip(*results):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), (mode, (a - b).abs().max().item())
     assert torch.equal(results[0][0], results[1][0])
+
+
+HALO_GEOMS = [  # N, H, W, Cin, Cout, dilation: the stride-1 3x3 layer geometries of the network at their real spatial sizes
+    (2, 33, 33, 256, 256, 1), (1, 33, 33, 512, 512, 2), (1, 33, 33, 512, 512, 4), (1, 33, 33, 512, 512, 8),
+    (1, 33, 33, 2048, 256, 6), (1, 33, 33, 2048, 256, 12), (1, 65, 65, 128, 128, 1), (1, 129, 129, 304, 256, 1),
+    (1, 129, 129, 256, 256, 1), (3, 31, 35, 64, 96, 1), (2, 20, 17, 40, 300, 3),
+]
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("geom", HALO_GEOMS)
+def test_conv_halo_kernel_geometries(dev, geom, prec):
+    """csrc/conv_halo.hip (tile_cfg 41 / 42) against the LDS-DMA kernel (tile_cfg 31: same bf16 products, another
+    summation order) on every 3x3 geometry it serves -- forward with BN sums and fused epilogue, dgrad with accumulation --
+    and against fp64 on the smaller ones.  Configurations whose strip does not fit the LDS (dilation 8: 256-row tiles;
+    dilation 12: both) are skipped the way ops.conv_igemm skips them."""
+    from zs3_amd import ops
+    from zs3_amd.functional import _pad_channels
+    n, h, w, ci, co, d = geom
+    g = torch.Generator().manual_seed(h * w + ci + d)
+    x = torch.randn(n, h, w, ci, generator=g).to(dev)
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).to(dev)
+    wp = ops.prep_weight(wt)
+    dy = _pad_channels(torch.randn(n, h, w, co, generator=g).to(dev), 8)
+    skip = torch.randn(n, h, w, ci, generator=g).to(dev)
+    sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
+    res = torch.randn(n, h, w, co, generator=g).to(dev)
+    tol = 2e-5 if prec == 3 else 2e-5      # identical bf16 products in both kernels: only the fp32 summation order differs
+    y31, st31 = ops.conv2d_fwd(x, wp, 1, d, d, want_stats=True, tile_cfg=31, prec=prec)
+    z31, _ = ops.conv2d_fwd(x, wp, 1, d, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=31, prec=prec)
+    dx31 = ops.conv2d_dgrad(dy, wp, (h, w), 1, d, d, tile_cfg=31, prec=prec, out=skip.clone(), accumulate=True)
+    ran = 0
+    for cfg in (41, 42):
+        if not ops.halo_ok(x.shape, h, w, wp.cin_pad, min(ops._round_up(ci, 4), x.shape[-1]), x.shape[-1], 3, 3, 1, d, d, d,
+                           False, prec, cfg):
+            continue
+        ran += 1
+        y, st = ops.conv2d_fwd(x, wp, 1, d, d, want_stats=True, tile_cfg=cfg, prec=prec)
+        assert rel(y, y31) < tol, (cfg, "fwd")
+        s31, s = st31.double().sum(0), st.double().sum(0)
+        assert ((s - s31).abs().max() / s31.abs().max()).item() < 1e-5, (cfg, "bn sums")
+        z, _ = ops.conv2d_fwd(x, wp, 1, d, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=cfg, prec=prec)
+        assert rel(z, z31) < tol, (cfg, "fused epilogue")
+        dx = ops.conv2d_dgrad(dy, wp, (h, w), 1, d, d, tile_cfg=cfg, prec=prec, out=skip.clone(), accumulate=True)
+        assert rel(dx, dx31) < tol, (cfg, "dgrad")
+    assert ran >= 1 or d >= 12, "no strip-resident configuration ran"     # dilation 12: the strip of even a 192-row tile exceeds the LDS
+    if n * h * w * ci * co <= 2 * 33 * 33 * 256 * 256 and prec == 3:
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), padding=d, dilation=d)
+        y, _ = ops.conv2d_fwd(x, wp, 1, d, d, tile_cfg=0)     # the rule's own choice for this layer
+        assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5

@@ -13,6 +13,8 @@ SHAPES = [(23, 33, 256, 1024, 1, 1, 1), (22, 33, 1024, 256, 1, 1, 1), (22, 33, 2
           (1, 33, 512, 512, 3, 1, 2), (1, 33, 512, 512, 3, 1, 4), (1, 33, 512, 512, 3, 1, 8), (1, 33, 1024, 2048, 1, 1, 1),
           (1, 33, 2048, 256, 1, 1, 1), (1, 33, 2048, 256, 3, 1, 6), (1, 33, 2048, 256, 3, 1, 12), (1, 33, 2048, 256, 3, 1, 18),
           (1, 33, 1280, 256, 1, 1, 1), (1, 129, 256, 48, 1, 1, 1), (1, 129, 304, 256, 3, 1, 1), (1, 129, 256, 256, 3, 1, 1)]
+if os.environ.get("ZS3_SHAPES"):   # e.g. ZS3_SHAPES=2,16,26: only these rows of the table
+    SHAPES = [SHAPES[int(i)] for i in os.environ["ZS3_SHAPES"].split(",")]
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]
 mode = sys.argv[2] if len(sys.argv) > 2 else "fwd"
 ops.PREC_DEFAULT = int(os.environ.get("ZS3_PREC", "3"))   # 1 = plain bf16 products
@@ -32,7 +34,7 @@ for (cnt, h, ci, co, k, s, d) in SHAPES:
     line = f"{cnt:2d}x {h:3d}^2 {ci:4d}->{co:4d} k{k} s{s} d{d:2d}: "
     for c0 in cfgs:
         c = c0
-        if c >= 31 and (co if mode == "dgrad" else ci) % 32: c = 21
+        if c in (31, 32) and (co if mode == "dgrad" else ci) % 32: c = 21
         if c == 32 and ops.pick_tile(B * ho * ho if mode == "fwd" else B * h * h, co if mode == "fwd" else ci, (ci if mode == "fwd" else co) * k * k) not in (31, 32): c = 31
         if mode == "fwd": t = timeit(lambda: ops.conv2d_fwd(x, wp, s, pad, d, tile_cfg=c, want_stats=True))
         elif mode == "dgrad": t = timeit(lambda: ops.conv2d_dgrad(dy, wp, (h, h), s, pad, d, tile_cfg=c))

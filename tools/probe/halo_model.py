@@ -5,7 +5,7 @@ usage: python tools/probe/halo_model.py"""
 import itertools
 import numpy as np
 
-BSLOT, NSLOT = 8192, 3
+BSLOT, NSLOT = 8192, 4
 OFF_ZERO = NSLOT * BSLOT
 OFF_TAPS = OFF_ZERO + 128
 OFF_STRIP = OFF_ZERO + 256
@@ -33,10 +33,10 @@ def geometry(N, H, W, cin_valid, cin_pad, KH, KW, pad, dil, dgrad, prec, bm):
     S = bm + omax - omin
     s_pad = (S + 31) // 32 * 32
     npass = s_pad // 32
-    npg = (npass + T - 2) // (T - 1)
+    npg = (npass + 5) // 6
     ch = 16 if prec == 3 else 32
     nch = (cin_valid + ch - 1) // ch
-    assert nch * ch <= cin_pad and npg <= 4
+    assert nch * ch <= cin_pad and npg <= 6 and T == 9
     return dict(T=T, sgn=sgn, off_min=omin, s_pad=s_pad, npass=npass, npg=npg, nch=nch, ns=(nch * T + 1) & ~1, ch=ch, offs=offs)
 
 
@@ -132,7 +132,7 @@ def run_tile(x, wpk, N, H, W, cin_valid, cin_pad, ldx, KH, KW, pad, dil, dgrad, 
         c, t = divmod(s, T)
         if t == 0 and c + 1 < g["nch"]:
             strip_fill(c + 1, (c + 1) & 1)     # (the kernel spreads this over the chunk's intervals)
-        weight_fill(c, t, s % 3)
+        weight_fill(c, t, s % NSLOT)
         for wave in range(4):
             wm, wn = wave >> 1, wave & 1
             A = np.zeros((TM, 32, 16, 2))      # [row block][row][k][hi/lo]
@@ -149,7 +149,7 @@ def run_tile(x, wpk, N, H, W, cin_valid, cin_pad, ldx, KH, KW, pad, dil, dgrad, 
                     A[i, lr, 8 * kh:8 * kh + 8, 1] = frag(addr ^ 32)
                 boff = (wn * 64 + lr) * 64 + ((kh ^ ((lr >> 2) & 3)) << 4)
                 for j in range(2):
-                    addr = (s % 3) * BSLOT + boff + j * 2048
+                    addr = (s % NSLOT) * BSLOT + boff + j * 2048
                     B[j, lr, 8 * kh:8 * kh + 8, 0] = frag(addr)
                     B[j, lr, 8 * kh:8 * kh + 8, 1] = frag(addr ^ 32)
             for i in range(TM):

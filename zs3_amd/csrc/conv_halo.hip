@@ -14,7 +14,7 @@
 //     of the issue slots of the LDS-DMA kernel's consumers -- is done once per element instead of once per tap and has
 //     left the MFMA waves altogether.
 //   * Two more producer waves stream the weight tile of every K step (128 columns x 64 B, the hi/lo lines of
-//     zs3_prep_weight) with global_load_lds_dwordx4 into a 3-slot ring, two steps ahead, counted vmcnt.
+//     zs3_prep_weight) with global_load_lds_dwordx4 into a 4-slot ring, three steps ahead, counted vmcnt.
 //   * Four consumer waves (2x2, (BM/2)x64 wave tiles) do nothing but ds_read_b128 + MFMA: a tap is a *shifted window*
 //     of the strip (row + dy*W + dx), image-border taps are redirected per lane to a zero row (9-bit mask per row,
 //     computed once per tile).  Rows are 64 B apart; 16-byte chunk q of strip / weight row r sits at q ^ ((r>>2)&3), so
@@ -25,6 +25,7 @@
 // The epilogue (BatchNorm partial sums, affine / residual / activation / accumulate, BN-backward sums) is the shared
 // one of conv_common.h.  Replaces: the 3x3 nn.Conv2d of resnet.py:18-26 (layer 2-4 conv2), aspp.py:11-19 (atrous
 // branches), decoder.py:15-24 (last_conv) and their data gradients.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -41,20 +42,19 @@ struct HaloGeom {
   int ns;          // K steps, rounded up to even (an odd tail step multiplies zeros)
   int T;           // filter taps
   int sgn;         // +1 forward, -1 dgrad (tap offsets mirrored)
+  int toff0, tstep_col, tstep_row;   // flattened-pixel offset of tap 0; its change to the next tap in a row / to the next row's first tap
   int lds_bytes;
+  int debug;       // ZS3_HALO_DEBUG ablations (timing probes, wrong results): 1 = no strip refills, 2 = no weight refills
 };
 
-constexpr int HALO_BSLOT = 8192, HALO_NSLOT = 3;
+constexpr int HALO_BSLOT = 8192, HALO_NSLOT = 4;   // weight ring: tiles s+1 .. s+3 in flight / landed while tile s is multiplied
 constexpr int HALO_OFF_ZERO = HALO_NSLOT * HALO_BSLOT;   // 256 B of zeros: where masked taps read
-constexpr int HALO_OFF_TAPS = HALO_OFF_ZERO + 128;    // int[16]: tap offsets in flattened pixels
 constexpr int HALO_OFF_STRIP = HALO_OFF_ZERO + 256;
-constexpr int HALO_MAXP = 4;
+constexpr int HALO_MAXP = 6;
 
 template <int PREC, int BM, int NPG>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const HaloGeom g) {
   constexpr int BN = 128, TM = BM / 64, TN = 2, CH = PREC == 3 ? 16 : 32;
-  constexpr int NAB = (TM % 2 == 0) ? 2 : 3;   // A-fragment buffers: fragment i lives in buffer i % NAB
-  static_assert((TM - 1) % NAB != 0, "the next step's first A fragment is prefetched into buffer 0 during the last sub-step");
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -77,11 +77,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     const int pl = tid - 384, prow = pl >> 2, cq = pl & 3;
     const long Mtot = (long)p.N * p.H * p.W;
     const long q0 = (long)m0 + g.off_min;
-    // NPG passes per K-step interval, a compile-time count: the group's loads are straight-line code and issue back to
-    // back (with a run-time count hipcc guards every load with a branch and waits vmcnt(0) before each one -- one L2
-    // round trip per pass).  A group that reaches past the strip's last pass repeats that pass (same data, same rows).
-    f32x4 buf[NPG][NV];
-    auto load_pass = [&](int k, int pass, int c) {
+    // The strip of chunk c+1 is converted while the nine taps of chunk c are multiplied: six groups of NPG passes, group k
+    // loaded in interval k and written three intervals later (k + 3), so that a load has ~3 K steps (~2500 cycles) to come
+    // back from L2 / the Infinity Cache -- with one interval of slack the loop ran at the latency of these loads.  The
+    // nine intervals are unrolled: register sets are indexed statically and hipcc counts its own vmcnt waits (a group is
+    // waited for with the two younger groups still in flight).  A group that reaches past the strip's last pass repeats
+    // that pass (same data, same rows).
+    constexpr int DIST = 3, NGRP = 9 - DIST;
+    f32x4 buf[DIST][NPG][NV];
+    auto load_pass = [&](f32x4 (&dstv)[NV], int pass, int c) {
       pass = pass < g.npass ? pass : g.npass - 1;
       long q = q0 + pass * 32 + prow;
       q = q < 0 ? 0 : (q >= Mtot ? Mtot - 1 : q);
@@ -90,63 +94,66 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const float* s = ch0 + 4 * v < p.cin_valid ? src + 4 * v : p.zero;
-        buf[k][v] = *reinterpret_cast<const f32x4*>(s);
+        dstv[v] = *reinterpret_cast<const f32x4*>(s);
       }
     };
-    auto write_pass = [&](int k, int pass, int sb) {
+    auto write_pass = [&](const f32x4 (&srcv)[NV], int pass, int sb) {
       pass = pass < g.npass ? pass : g.npass - 1;
       const int s = pass * 32 + prow, sw = (s >> 2) & 3;
       unsigned char* row = dsm + HALO_OFF_STRIP + sb * strip_bytes + s * 64;
       if (PREC == 3) {
         u32x2 hi, lo;
         unsigned h, l;
-        split_pair<3>(buf[k][0][0], buf[k][0][1], h, l); hi[0] = h; lo[0] = l;
-        split_pair<3>(buf[k][0][2], buf[k][0][3], h, l); hi[1] = h; lo[1] = l;
+        split_pair<3>(srcv[0][0], srcv[0][1], h, l); hi[0] = h; lo[0] = l;
+        split_pair<3>(srcv[0][2], srcv[0][3], h, l); hi[1] = h; lo[1] = l;
         const int o = (((cq >> 1) ^ sw) << 4) + (cq & 1) * 8;
         *reinterpret_cast<u32x2*>(row + o) = hi;
         *reinterpret_cast<u32x2*>(row + (o ^ 32)) = lo;
       } else {
         u32x4 hi;
-        hi[0] = cvt_pk_bf16(buf[k][0][0], buf[k][0][1]);
-        hi[1] = cvt_pk_bf16(buf[k][0][2], buf[k][0][3]);
-        hi[2] = cvt_pk_bf16(buf[k][NV - 1][0], buf[k][NV - 1][1]);
-        hi[3] = cvt_pk_bf16(buf[k][NV - 1][2], buf[k][NV - 1][3]);
+        hi[0] = cvt_pk_bf16(srcv[0][0], srcv[0][1]);
+        hi[1] = cvt_pk_bf16(srcv[0][2], srcv[0][3]);
+        hi[2] = cvt_pk_bf16(srcv[NV - 1][0], srcv[NV - 1][1]);
+        hi[3] = cvt_pk_bf16(srcv[NV - 1][2], srcv[NV - 1][3]);
         *reinterpret_cast<u32x4*>(row + ((cq ^ sw) << 4)) = hi;
       }
     };
     if (pl < 8) *reinterpret_cast<u32x4*>(dsm + HALO_OFF_ZERO + pl * 16) = u32x4{0u, 0u, 0u, 0u};
-    if (pl < T) {   // flattened-pixel offset of every tap, read back by the consumers once per K step
-      const int th = pl / p.KW, tw = pl - th * p.KW;
-      *reinterpret_cast<int*>(dsm + HALO_OFF_TAPS + pl * 4) = g.sgn * ((th * p.dil - p.pad_h) * p.W + (tw * p.dil - p.pad_w));
-    }
-    // strip of chunk 0 (nothing to overlap it with yet)
-    for (int pass0 = 0; pass0 < g.npass; pass0 += NPG) {
+    // strip of chunk 0 (nothing to overlap it with yet): three groups in flight at a time
 #pragma unroll
-      for (int k = 0; k < NPG; ++k) load_pass(k, pass0 + k, 0);
+    for (int g0 = 0; g0 < NGRP; g0 += DIST) {
 #pragma unroll
-      for (int k = 0; k < NPG; ++k) write_pass(k, pass0 + k, 0);
+      for (int s = 0; s < DIST; ++s)
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) load_pass(buf[s][k], (g0 + s) * NPG + k, 0);
+#pragma unroll
+      for (int s = 0; s < DIST; ++s)
+#pragma unroll
+        for (int k = 0; k < NPG; ++k) write_pass(buf[s][k], (g0 + s) * NPG + k, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // B_0
-    // interval (c, t): write the passes loaded one interval ago, then load the next group -- all for the strip of chunk c+1
-    int c = 0, t = 0;
-    for (int s = 0; s < NSR; ++s) {
-      const bool live = c + 1 < g.nch;
-      if (live && t >= 1) {
+    for (int c = 0; c < g.nch; ++c) {
+      if (c + 1 < g.nch && !(g.debug & 1)) {
 #pragma unroll
-        for (int k = 0; k < NPG; ++k) write_pass(k, (t - 1) * NPG + k, (c + 1) & 1);
-      }
-      if (live && t + 1 < T) {
+        for (int t = 0; t < 9; ++t) {
+          if (t >= DIST) {
 #pragma unroll
-        for (int k = 0; k < NPG; ++k) load_pass(k, t * NPG + k, c + 1);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // B_{s+1}
-      if (++t == T) {
-        t = 0;
-        ++c;
+            for (int k = 0; k < NPG; ++k) write_pass(buf[(t - DIST) % DIST][k], (t - DIST) * NPG + k, (c + 1) & 1);
+          }
+          if (t < NGRP) {
+#pragma unroll
+            for (int k = 0; k < NPG; ++k) load_pass(buf[t % DIST][k], t * NPG + k, c + 1);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();   // B_{s+1}
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) __builtin_amdgcn_s_barrier();
       }
     }
+    if (NSR > NS) __builtin_amdgcn_s_barrier();   // the padding step of an odd K loop
   } else if (wave >= 4) {
     // ------------------------------------------------------------------ weight producers (LDS-DMA, 128 lanes)
     // One instruction = 16 tile rows x 4 chunks of 16 B; the two waves issue 4 each per K step (128 rows x 64 B).
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     auto issue = [&](int slot) {
       const int kofs = t * p.cin_pad + c * CH;
       int uoff = (kofs >> 5) * 128 + (PREC == 3 ? ((kofs >> 4) & 1) * 32 : 0);
-      if (c >= g.nch) uoff = -1;   // the padding step of an odd K loop: zeros
+      if (c >= g.nch) uoff = -1;   // the padding step of an odd K loop (and anything past it): zeros
       unsigned char* dst = dsm + slot * HALO_BSLOT + pw * 4096;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -180,20 +187,27 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
         ++c;
       }
     };
+    // tile s+1 must have landed at barrier B_{s+1}; tile s+4 goes into the slot of tile s, which the consumers read for the
+    // last time before B_{s+1}.  Waiting FIRST and issuing AFTER the barrier keeps the issue work (address VALU + four DMA
+    // instructions at 100-180 cycles each next to the consumers' LDS traffic) off the barrier's critical path.
     issue(0);
     issue(1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    issue(2);
+    issue(3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // B_0: tile 0 has landed
-    int st2 = 2;
+    int st = 0;
     for (int s = 0; s < NSR; ++s) {
-      if (s + 2 < NSR) {
-        issue(st2);
-        st2 = st2 == HALO_NSLOT - 1 ? 0 : st2 + 1;
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile s+1 has landed, tile s+2 stays in flight
+      if (s + 3 < NSR) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile s+1 has landed, tiles s+2 and s+3 stay in flight
+      } else if (s + 2 < NSR) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();   // B_{s+1}
+      if (s + 4 < NSR && !(g.debug & 2)) issue(st);
+      st = st == HALO_NSLOT - 1 ? 0 : st + 1;
     }
   } else {
     // ------------------------------------------------------------------ consumers: ds_read_b128 + MFMA only
@@ -228,108 +242,81 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     const unsigned boff = (unsigned)((wn * 64 + lr) * 64 + ((kh ^ ((lr >> 2) & 3)) << 4));   // weight-tile row of column block 0
     const unsigned zaddr = HALO_OFF_ZERO;
 
-    bf16x8 a_hi[NAB], a_lo[NAB];
+    bf16x8 a_hi[TM], a_lo[TM];        // one buffer per row block: fragment f is read two sub-steps before its MFMAs
     bf16x8 b_hi[2][TN], b_lo[2][TN];
-    // K-step state (wave-uniform): tap rt / chunk rc of the step whose window is computed next
-    int rt = 0, rc = 0;
+    // K-step state (wave-uniform): tap (rt, column rtw) / chunk rc / flattened-pixel offset rtoff of the step whose window
+    // is computed next -- all scalar, advanced incrementally (no division, no table)
+    int rt = 0, rtw = 0, rc = 0, rtoff = g.toff0;
     unsigned a0 = 0u, tbit = 0u;     // strip address of row block 0 / mask bit of the step being read
-    unsigned a0n = 0u, tbitn = 0u;   // the same for the step after it (computed a sub-step early, in the MFMA shadow)
-    int toff = 0;
-    auto next_tap = [&]() { toff = *reinterpret_cast<const int*>(dsm + HALO_OFF_TAPS + rt * 4); };   // a sub-step before its use
-    auto next_window = [&]() {       // (toff, rt, rc) -> a0n, tbitn
-      const int s0 = rb + toff;
+    unsigned a0n = 0u, tbitn = 0u;   // the same for the step after it (computed in sub-step 0, in the MFMA shadow)
+    auto advance_read = [&]() {
+      const bool wcol = rtw + 1 == p.KW, wtap = rt + 1 == T;
+      rtoff = wtap ? g.toff0 : rtoff + (wcol ? g.tstep_row : g.tstep_col);
+      rtw = (wcol || wtap) ? 0 : rtw + 1;
+      rt = wtap ? 0 : rt + 1;
+      rc += wtap ? 1 : 0;
+    };
+    auto next_window = [&]() {       // (rtoff, rt, rc) -> a0n, tbitn
+      const int s0 = rb + rtoff;
       a0n = (unsigned)(HALO_OFF_STRIP + (rc & 1) * strip_bytes + s0 * 64 + ((kh ^ ((s0 >> 2) & 3)) << 4));
       tbitn = rc < g.nch ? 1u << rt : 0u;   // the padding step of an odd K loop reads the zero row
     };
-    auto read_a = [&](int i) {
-      const unsigned addr = (vmask[i] & tbit) ? a0 + i * 2048 : zaddr;
-      a_hi[i % NAB] = *reinterpret_cast<const bf16x8*>(dsm + addr);
-      a_lo[i % NAB] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
+    auto read_a = [&](int f) {
+      const unsigned addr = (vmask[f] & tbit) ? a0 + f * 2048 : zaddr;
+      a_hi[f] = *reinterpret_cast<const bf16x8*>(dsm + addr);
+      a_lo[f] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
     };
-    auto read_b = [&](int set, int slot) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const unsigned addr = slot * HALO_BSLOT + boff + j * 2048;
-        b_hi[set][j] = *reinterpret_cast<const bf16x8*>(dsm + addr);
-        b_lo[set][j] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
-      }
-    };
-    auto advance_read = [&]() {
-      const bool wrap = rt + 1 == T;
-      rt = wrap ? 0 : rt + 1;
-      rc += wrap ? 1 : 0;
+    auto read_b = [&](int set, int slot, int j) {
+      const unsigned addr = slot * HALO_BSLOT + boff + j * 2048;
+      b_hi[set][j] = *reinterpret_cast<const bf16x8*>(dsm + addr);
+      b_lo[set][j] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
     };
     int slot = 0;
-    // one K step: TM sub-steps (row blocks); the MFMAs of sub-step i run from registers while the next row block's
-    // fragment is read; the step barrier sits before the last sub-step, which prefetches the next step's first A
-    // fragment and its weight fragments (the other register set).  Every MFMA slot is pinned (sched_barrier): hipcc
-    // otherwise hoists all LDS reads and issues the MFMAs as one clump.
+    // One K step = TM sub-steps (row blocks) of 3*TN (bf16x3) or 2*TN MFMAs.  Sub-step i runs from registers; in its MFMA
+    // shadow the fragment of sub-step i+2 is read: this step's row block i+2, or -- in the last two sub-steps, after the
+    // step barrier -- the next step's row blocks 0 and 1 and its weight fragments (the other register set).  The barrier
+    // (next weight tile landed, next strip complete) therefore sits before sub-step TM-2.  Every MFMA slot is pinned
+    // (sched_barrier): hipcc otherwise hoists all LDS reads and issues the MFMAs as one clump.
     auto step = [&](auto setc) {
       constexpr int SET = decltype(setc)::value;
+      constexpr int NM = (PREC == 3 ? 3 : 2) * TN;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        if (i == TM - 1) {
+        if (i == TM - 2) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();   // next step's weight tile has landed; this step's LDS reads are done
+          __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
           a0 = a0n;
           tbit = tbitn;
           slot = slot == HALO_NSLOT - 1 ? 0 : slot + 1;
         }
-        const bf16x8 ah = a_hi[i % NAB], al = a_lo[i % NAB];
-        if (PREC == 3) {
+        const bf16x8 ah = a_hi[i], al = a_lo[i];
 #pragma unroll
-          for (int m = 0; m < 3 * TN; ++m) {
-            const int pr = m / TN, j = m % TN;
+        for (int m = 0; m < NM; ++m) {
+          const int pr = m / TN, j = m % TN;
+          if (PREC == 3)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al : ah, pr == 1 ? b_lo[SET][j] : b_hi[SET][j],
                                                                 acc[i][j], 0, 0, 0);
-            if (m == 0) {
-              if (i < TM - 1) {
-                read_a(i + 1);
-              } else {
-                read_a(0);
-                read_b(SET ^ 1, slot);
-              }
-            }
-            if (i == 0 && m == 1) {
-              advance_read();
-              next_tap();
-            }
-            if (i == 1 && m == 1) next_window();
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
-#pragma unroll
-          for (int m = 0; m < 2 * TN; ++m) {
-            const int pr = m / TN, j = m % TN;
+          else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? ah : al, pr == 0 ? b_hi[SET][j] : b_lo[SET][j],
                                                                 acc[i][j], 0, 0, 0);
-            if (m == 0) {
-              if (i < TM - 1) {
-                read_a(i + 1);
-              } else {
-                read_a(0);
-                read_b(SET ^ 1, slot);
-              }
-            }
-            if (i == 0 && m == 1) {
-              advance_read();
-              next_tap();
-            }
-            if (i == 1 && m == 1) next_window();
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          if (m == 0) read_a((i + 2) % TM);
+          if (i == TM - 2 && m >= 1 && m <= TN) read_b(SET ^ 1, slot, m - 1);
+          if (i == 0 && m == 1) advance_read();
+          if (i == 0 && m == 2) next_window();
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
     __builtin_amdgcn_s_barrier();   // B_0: strip 0 and weight tile 0 are in LDS
     asm volatile("" ::: "memory");
-    next_tap();
     next_window();
     a0 = a0n;
     tbit = tbitn;
     read_a(0);
-    read_b(0, 0);
+    read_a(1);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) read_b(0, 0, j);
     __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < NSR; s += 2) {
       step(std::integral_constant<int, 0>{});
@@ -407,7 +394,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
 
 bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   const int T = a.KH * a.KW;
-  if (a.stride != 1 || a.H != a.Ho || a.W != a.Wo || T < 3 || T > 16) return false;
+  if (a.stride != 1 || a.H != a.Ho || a.W != a.Wo || T != 9) return false;   // the strip schedule is unrolled for 9 taps
   if ((a.ldx & 3) || (a.cin_valid & 3) || (a.cin_pad & 31) || a.M <= 0) return false;
   if (bm != 256 && bm != 192) return false;
   HaloGeom g;
@@ -423,9 +410,12 @@ bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   const long S = bm + omax - omin;
   if (S > 4096) return false;
   g.off_min = (int)omin;
+  g.toff0 = g.sgn * (-a.pad_h * a.W - a.pad_w);
+  g.tstep_col = g.sgn * a.dil;
+  g.tstep_row = g.sgn * (a.dil * a.W - (a.KW - 1) * a.dil);
   g.s_pad = (int)((S + 31) / 32 * 32);
   g.npass = g.s_pad / 32;
-  g.npg = (g.npass + (T - 2)) / (T - 1);
+  g.npg = (g.npass + 5) / 6;   // six load groups per chunk (conv_halo_kernel: NGRP)
   if (g.npg > HALO_MAXP) return false;
   const int ch = prec == 3 ? 16 : 32;
   g.nch = (a.cin_valid + ch - 1) / ch;
@@ -435,6 +425,8 @@ bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   const int loop = HALO_OFF_STRIP + 2 * g.s_pad * 64;
   g.lds_bytes = loop > epi ? loop : epi;
   if (g.lds_bytes > 160 * 1024) return false;
+  static const int dbg = getenv("ZS3_HALO_DEBUG") ? atoi(getenv("ZS3_HALO_DEBUG")) : 0;
+  g.debug = dbg;
   if (out) *out = g;
   return true;
 }
@@ -459,6 +451,8 @@ int launch_halo_t(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
     case 2: return launch_halo_n<PREC, BM, 2>(a, g, st);
     case 3: return launch_halo_n<PREC, BM, 3>(a, g, st);
     case 4: return launch_halo_n<PREC, BM, 4>(a, g, st);
+    case 5: return launch_halo_n<PREC, BM, 5>(a, g, st);
+    case 6: return launch_halo_n<PREC, BM, 6>(a, g, st);
   }
   return -7;
 }
