@@ -247,12 +247,12 @@ def main():
             by_cfg = {}
             for tag, flops, e0, e1, cfg in warm_prof:
                 by_cfg[cfg] = by_cfg.get(cfg, 0.0) + e0.elapsed_time(e1)
-            for group in ({31, 32},):      # whole-tile and stream-K launches of the LDS-DMA kernel are one kernel
+            for group in ({31, 32}, {41, 42}):      # whole-tile / stream-K launches of the LDS-DMA kernel, both tile heights of the strip kernel
                 tot = sum(by_cfg.pop(c, 0.0) for c in group)
                 if tot:
                     by_cfg[min(group)] = tot
             best = max(by_cfg, key=by_cfg.get) if by_cfg else None
-            ops.PROFILE_CFGS = ({31, 32} if best == 31 else {best}) if best is not None else None
+            ops.PROFILE_CFGS = ({31, 32} if best == 31 else {41, 42} if best == 41 else {best}) if best is not None else None
             timed_prof = []
 
             def instrument(i):
@@ -350,16 +350,23 @@ def pmc_traffic(tag):
         return None, None
     path = found[-1]            # the latest round's passes
     import re
+    kernels = json.load(open(path))["kernels"]
+    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    hm = re.match(r"conv_halo<(\d)>", tag)
+    if hm:   # the strip-resident kernel is one source kernel in several instantiations (tile height, strip passes per step)
+        fam = [v for k, v in kernels.items() if k.startswith(f"conv_halo_kernel<{hm.group(1)},")]
+        n = sum(v["launches"] for v in fam)
+        if not n:
+            return None, None
+        return sum(v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in fam) / n, src
     m = re.match(r"conv_igemm(_ws|_dma)?<(\d+),(\d+),(\d)(?:,pipe(\d))?>", tag)
     if not m:
         return None, None
     name = (f"conv_igemm{m.group(1)}_kernel<{m.group(4)}, false>" if m.group(1) == "_dma" else f"conv_igemm{m.group(1)}_kernel<{m.group(4)}>") if m.group(1) else f"conv_igemm_kernel<{m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}>"
-    kernels = json.load(open(path))["kernels"]
     k = kernels.get(name) or kernels.get(name.replace(", false>", ">"))
     if not k:
         return None, None
-    return (k["read_bytes_per_launch"] + k["write_bytes_per_launch"],
-            f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)")
+    return k["read_bytes_per_launch"] + k["write_bytes_per_launch"], src
 
 
 def cpu_baseline(args):

@@ -5,7 +5,7 @@ usage: python tools/probe/halo_model.py"""
 import itertools
 import numpy as np
 
-BSLOT, NSLOT = 8192, 4
+BSLOT, NSLOT = 8192, 2
 OFF_ZERO = NSLOT * BSLOT
 OFF_TAPS = OFF_ZERO + 128
 OFF_STRIP = OFF_ZERO + 256
@@ -31,12 +31,12 @@ def geometry(N, H, W, cin_valid, cin_pad, KH, KW, pad, dil, dgrad, prec, bm):
     offs = [sgn * ((th * dil - pad) * W + (tw * dil - pad)) for th in range(KH) for tw in range(KW)]
     omin, omax = min(0, min(offs)), max(0, max(offs))
     S = bm + omax - omin
-    s_pad = (S + 31) // 32 * 32
-    npass = s_pad // 32
+    s_pad = (S + 63) // 64 * 64
+    npass = s_pad // 64
     npg = (npass + 5) // 6
     ch = 16 if prec == 3 else 32
     nch = (cin_valid + ch - 1) // ch
-    assert nch * ch <= cin_pad and npg <= 6 and T == 9
+    assert nch * ch <= cin_pad and npg <= 3 and T == 9
     return dict(T=T, sgn=sgn, off_min=omin, s_pad=s_pad, npass=npass, npg=npg, nch=nch, ns=(nch * T + 1) & ~1, ch=ch, offs=offs)
 
 
@@ -71,12 +71,12 @@ def run_tile(x, wpk, N, H, W, cin_valid, cin_pad, ldx, KH, KW, pad, dil, dgrad, 
     # ---- producers
     def strip_fill(c, sb):
         for p_ in range(g["npass"]):
-            for pl in range(128):
+            for pl in range(256):
                 prow, cq = pl >> 2, pl & 3
-                q = m0 + g["off_min"] + p_ * 32 + prow
+                q = m0 + g["off_min"] + p_ * 64 + prow
                 q = min(max(q, 0), M - 1)
                 ch0 = c * CH + cq * (CH // 4)
-                s = p_ * 32 + prow
+                s = p_ * 64 + prow
                 sw = (s >> 2) & 3
                 row = OFF_STRIP + sb * strip_bytes + s * 64
                 if prec == 3:
@@ -97,17 +97,17 @@ def run_tile(x, wpk, N, H, W, cin_valid, cin_pad, ldx, KH, KW, pad, dil, dgrad, 
     def weight_fill(c, t, slot):
         kofs = t * cin_pad + c * CH
         uoff = (kofs >> 5) * 128 + ((((kofs >> 4) & 1) * 32) if prec == 3 else 0)
-        for pw in range(2):
-            for k in range(4):
-                for lane in range(64):
-                    q = (lane & 3) ^ ((lane >> 4) & 3)
-                    qoff = ((q & 1) * 16 + (q >> 1) * 64) if prec == 3 else q * 16
-                    col = n0 + (pw * 4 + k) * 16 + (lane >> 2)
-                    dst = slot * BSLOT + pw * 4096 + k * 1024 + lane * 16
-                    if col < ncols and c < g["nch"]:
-                        lds[dst:dst + 16] = wbytes[col, uoff + qoff:uoff + qoff + 16]
-                    else:
-                        lds[dst:dst + 16] = 0
+        for pl in range(256):
+            prow, cq = pl >> 2, pl & 3
+            qoff = ((cq & 1) * 16 + (cq >> 1) * 64) if prec == 3 else cq * 16
+            for e in range(2):
+                wr = prow + 64 * e
+                col = n0 + wr
+                dst = slot * BSLOT + wr * 64 + ((cq ^ ((wr >> 2) & 3)) << 4)
+                if col < ncols and c < g["nch"]:
+                    lds[dst:dst + 16] = wbytes[col, uoff + qoff:uoff + qoff + 16]
+                else:
+                    lds[dst:dst + 16] = 0
 
     taps = np.array(g["offs"], np.int64)
     # ---- consumer masks

@@ -8,13 +8,13 @@
 //   * In flattened pixel space (m = (n*H + y)*W + x) tap (dy,dx) of output pixel m reads input pixel m + dy*W + dx, so a
 //     tile of BM consecutive output pixels needs the contiguous *strip* of input pixels [m0 + off_min, m0 + BM + off_max).
 //     For a 3x3, dilation-d layer that is BM + 2d(W+1) rows: 1.27x the tile at W = 33, 2x at W = 129 -- instead of 9x.
-//   * Two producer waves load the strip of one channel chunk (16 channels in bf16x3 mode, 32 in plain-bf16 mode) from
+//   * Four producer waves load the strip of one channel chunk (16 channels in bf16x3 mode, 32 in plain-bf16 mode) from
 //     L2 into registers ONCE, split it into bf16 hi/lo there and write 64-byte rows [hi | lo] into LDS (double buffered:
 //     the strip of chunk c+1 is converted while the nine taps of chunk c are multiplied).  The fp32 -> bf16 split -- 65 %
 //     of the issue slots of the LDS-DMA kernel's consumers -- is done once per element instead of once per tap and has
 //     left the MFMA waves altogether.
-//   * Two more producer waves stream the weight tile of every K step (128 columns x 64 B, the hi/lo lines of
-//     zs3_prep_weight) with global_load_lds_dwordx4 into a 4-slot ring, three steps ahead, counted vmcnt.
+//   * The same waves stream the weight tile of every K step (128 columns x 64 B, the hi/lo lines of zs3_prep_weight):
+//     plain loads three tiles ahead, ds_write_b128 into a two-slot ring one step before the tile is multiplied.
 //   * Four consumer waves (2x2, (BM/2)x64 wave tiles) do nothing but ds_read_b128 + MFMA: a tap is a *shifted window*
 //     of the strip (row + dy*W + dx), image-border taps are redirected per lane to a zero row (9-bit mask per row,
 //     computed once per tile).  Rows are 64 B apart; 16-byte chunk q of strip / weight row r sits at q ^ ((r>>2)&3), so
@@ -25,7 +25,6 @@
 // The epilogue (BatchNorm partial sums, affine / residual / activation / accumulate, BN-backward sums) is the shared
 // one of conv_common.h.  Replaces: the 3x3 nn.Conv2d of resnet.py:18-26 (layer 2-4 conv2), aspp.py:11-19 (atrous
 // branches), decoder.py:15-24 (last_conv) and their data gradients.
-#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -35,8 +34,8 @@ namespace {
 
 struct HaloGeom {
   int off_min;     // smallest tap offset in flattened pixels (<= 0)
-  int s_pad;       // strip rows (multiple of 32)
-  int npass;       // 32-row conversion passes per strip
+  int s_pad;       // strip rows (multiple of 64)
+  int npass;       // 64-row conversion passes per strip
   int npg;         // passes per K-step interval (<= 4)
   int nch;         // channel chunks
   int ns;          // K steps, rounded up to even (an odd tail step multiplies zeros)
@@ -44,13 +43,29 @@ struct HaloGeom {
   int sgn;         // +1 forward, -1 dgrad (tap offsets mirrored)
   int toff0, tstep_col, tstep_row;   // flattened-pixel offset of tap 0; its change to the next tap in a row / to the next row's first tap
   int lds_bytes;
-  int debug;       // ZS3_HALO_DEBUG ablations (timing probes, wrong results): 1 = no strip refills, 2 = no weight refills
 };
 
-constexpr int HALO_BSLOT = 8192, HALO_NSLOT = 4;   // weight ring: tiles s+1 .. s+3 in flight / landed while tile s is multiplied
+constexpr int HALO_BSLOT = 8192, HALO_NSLOT = 2;   // weight tiles in LDS: the one being multiplied and the next (three more are in flight in registers)
 constexpr int HALO_OFF_ZERO = HALO_NSLOT * HALO_BSLOT;   // 256 B of zeros: where masked taps read
 constexpr int HALO_OFF_STRIP = HALO_OFF_ZERO + 256;
-constexpr int HALO_MAXP = 6;
+constexpr int HALO_MAXP = 3;
+
+// -DZS3_HALO_ABLATE=n builds (tools/probe/build_variant.sh; timing probes, wrong results): 1 = no strip refills, 2 = no weight
+// refills -- compile-time switches: a run-time test inside the unrolled producer schedule makes hipcc wait vmcnt(0).
+#ifndef ZS3_HALO_ABLATE
+#define ZS3_HALO_ABLATE 0
+#endif
+// -DZS3_CONV_TIMING (tools/probe/build_variant.sh + tools/probe/halo_timing.py): per-wave s_memtime split of block 0's K loop,
+// written to the buffer passed as `res` when act == 99
+#ifdef ZS3_CONV_TIMING
+#define HT_DECL long ht_a = 0, ht_b = 0, ht_c = 0, ht_last = __builtin_readcyclecounter();
+#define HT(v) { const long t_ = __builtin_readcyclecounter(); v += t_ - ht_last; ht_last = t_; }
+#define HT_STORE(w) if (p.act == 99 && blockIdx.x == 0 && lane == 0) { long* o_ = reinterpret_cast<long*>(const_cast<float*>(p.res)) + (w) * 3; o_[0] = ht_a; o_[1] = ht_b; o_[2] = ht_c; }
+#else
+#define HT_DECL
+#define HT(v)
+#define HT_STORE(w)
+#endif
 
 template <int PREC, int BM, int NPG>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const HaloGeom g) {
@@ -70,24 +85,30 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
 
   f32x16 acc[TM][TN];
 
-  if (wave >= 6) {
-    // ------------------------------------------------------------------ strip producers (128 lanes)
-    // A pass converts 32 strip rows: 4 lanes per row, each 4 (bf16x3) or 8 (plain bf16) consecutive channels.
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers: four identical waves (256 lanes)
+    // Everything is a plain global_load into registers followed, a few K steps later, by a ds_write: loads of one wave
+    // pipeline freely and hipcc counts their vmcnt waits itself (global_load_lds, tried first for the weight tiles, costs
+    // the issuing wave ~190 cycles per 1-KB piece -- every piece re-programs M0 -- and two waves x 4 pieces per K step were
+    // the last to arrive at every barrier).  The nine intervals of a channel chunk are unrolled, so every register set
+    // is indexed statically.
+    //   weights: tile u = (chunk, tap) is 128 columns x 64 B; a lane owns two 16-byte chunks of it.  Loaded in interval
+    //            u-4 (three tiles in flight), written to LDS slot u&1 in interval u-1, read by the consumers after
+    //            barrier B_u.
+    //   strip  : 64-row passes (4 lanes per row, each 4 (bf16x3) or 8 (plain bf16) consecutive channels); the strip of
+    //            chunk c+1 is fetched in six groups of NPG passes during the intervals of chunk c: group k loaded in
+    //            interval k, split to bf16 hi/lo and written in interval k+3.  A group that reaches past the strip's last
+    //            pass repeats that pass (same data, same rows).
     constexpr int NV = PREC == 3 ? 1 : 2;
-    const int pl = tid - 384, prow = pl >> 2, cq = pl & 3;
+    constexpr int DIST = 3, NGRP = 9 - DIST;
+    const int pl = tid - 256, prow = pl >> 2, cq = pl & 3;
     const long Mtot = (long)p.N * p.H * p.W;
     const long q0 = (long)m0 + g.off_min;
-    // The strip of chunk c+1 is converted while the nine taps of chunk c are multiplied: six groups of NPG passes, group k
-    // loaded in interval k and written three intervals later (k + 3), so that a load has ~3 K steps (~2500 cycles) to come
-    // back from L2 / the Infinity Cache -- with one interval of slack the loop ran at the latency of these loads.  The
-    // nine intervals are unrolled: register sets are indexed statically and hipcc counts its own vmcnt waits (a group is
-    // waited for with the two younger groups still in flight).  A group that reaches past the strip's last pass repeats
-    // that pass (same data, same rows).
-    constexpr int DIST = 3, NGRP = 9 - DIST;
-    f32x4 buf[DIST][NPG][NV];
+    f32x4 sbuf[DIST][NPG][NV];
+    u32x4 wbuf[3][2];
     auto load_pass = [&](f32x4 (&dstv)[NV], int pass, int c) {
       pass = pass < g.npass ? pass : g.npass - 1;
-      long q = q0 + pass * 32 + prow;
+      long q = q0 + pass * 64 + prow;
       q = q < 0 ? 0 : (q >= Mtot ? Mtot - 1 : q);
       const int ch0 = c * CH + cq * (CH / 4);
       const float* src = p.x + q * p.ldx + ch0;
@@ -99,7 +120,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     };
     auto write_pass = [&](const f32x4 (&srcv)[NV], int pass, int sb) {
       pass = pass < g.npass ? pass : g.npass - 1;
-      const int s = pass * 32 + prow, sw = (s >> 2) & 3;
+      const int s = pass * 64 + prow, sw = (s >> 2) & 3;
       unsigned char* row = dsm + HALO_OFF_STRIP + sb * strip_bytes + s * 64;
       if (PREC == 3) {
         u32x2 hi, lo;
@@ -118,97 +139,95 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
         *reinterpret_cast<u32x4*>(row + ((cq ^ sw) << 4)) = hi;
       }
     };
-    if (pl < 8) *reinterpret_cast<u32x4*>(dsm + HALO_OFF_ZERO + pl * 16) = u32x4{0u, 0u, 0u, 0u};
-    // strip of chunk 0 (nothing to overlap it with yet): three groups in flight at a time
+    // weight tile: lane -> (tile row wr + 64 e, chunk cq), e = 0, 1; masked columns read the zero page
+    const int qoff = PREC == 3 ? (cq & 1) * 16 + (cq >> 1) * 64 : cq * 16;
+    const unsigned char* wptr[2];
+    int wstep[2];
+    unsigned wdst[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int wr = prow + 64 * e, col = n0 + wr;
+      const bool ok = col < p.ncols;
+      wptr[e] = ok ? reinterpret_cast<const unsigned char*>(p.w_pk) + (size_t)col * (4 * (size_t)p.ldw) + qoff
+                   : reinterpret_cast<const unsigned char*>(p.zero);
+      wstep[e] = ok ? 1 : 0;
+      wdst[e] = (unsigned)(wr * 64 + ((cq ^ ((wr >> 2) & 3)) << 4));
+    }
+    auto load_w = [&](u32x4 (&dstv)[2], int c, int t) {   // tile (c, t); t may run past 8 into the next chunk
+      if (t >= 9) {
+        t -= 9;
+        ++c;
+      }
+      const int kofs = t * p.cin_pad + c * CH;
+      const int uoff = (kofs >> 5) * 128 + (PREC == 3 ? ((kofs >> 4) & 1) * 32 : 0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) dstv[e] = *reinterpret_cast<const u32x4*>(wptr[e] + (size_t)uoff * wstep[e]);
+    };
+    auto write_w = [&](const u32x4 (&srcv)[2], int slot) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) *reinterpret_cast<u32x4*>(dsm + slot * HALO_BSLOT + wdst[e]) = srcv[e];
+    };
+    if (pl < 16) *reinterpret_cast<u32x4*>(dsm + HALO_OFF_ZERO + pl * 16) = u32x4{0u, 0u, 0u, 0u};
+    // ---- prologue: weight tiles 0..3 requested, strip 0 and tile 0 in LDS (NS >= 9: the four tiles exist)
+    load_w(wbuf[0], 0, 0);
+    load_w(wbuf[1], 0, 1);
+    load_w(wbuf[2], 0, 2);
 #pragma unroll
     for (int g0 = 0; g0 < NGRP; g0 += DIST) {
 #pragma unroll
       for (int s = 0; s < DIST; ++s)
 #pragma unroll
-        for (int k = 0; k < NPG; ++k) load_pass(buf[s][k], (g0 + s) * NPG + k, 0);
+        for (int k = 0; k < NPG; ++k) load_pass(sbuf[s][k], (g0 + s) * NPG + k, 0);
+      if (g0 == 0) {
+        write_w(wbuf[0], 0);
+        load_w(wbuf[0], 0, 3);
+      }
 #pragma unroll
       for (int s = 0; s < DIST; ++s)
 #pragma unroll
-        for (int k = 0; k < NPG; ++k) write_pass(buf[s][k], (g0 + s) * NPG + k, 0);
+        for (int k = 0; k < NPG; ++k) write_pass(sbuf[s][k], (g0 + s) * NPG + k, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // B_0
-    for (int c = 0; c < g.nch; ++c) {
-      if (c + 1 < g.nch && !(g.debug & 1)) {
+    HT_DECL
+    // ---- interval s = 9c + t (between B_s and B_{s+1}): write tile s+1, request tile s+4 into the set it leaves,
+    //      convert strip group t-3 of chunk c+1, request group t
+    for (int c = 0; c + 1 < g.nch; ++c) {
+      const int sb = (c + 1) & 1;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+      for (int t = 0; t < 9; ++t) {
+        write_w(wbuf[(t + 1) % 3], (c + t + 1) & 1);
+        if (!(ZS3_HALO_ABLATE & 2)) load_w(wbuf[(t + 1) % 3], c, t + 4);
+        if (!(ZS3_HALO_ABLATE & 1)) {
           if (t >= DIST) {
 #pragma unroll
-            for (int k = 0; k < NPG; ++k) write_pass(buf[(t - DIST) % DIST][k], (t - DIST) * NPG + k, (c + 1) & 1);
+            for (int k = 0; k < NPG; ++k) write_pass(sbuf[(t - DIST) % DIST][k], (t - DIST) * NPG + k, sb);
           }
           if (t < NGRP) {
 #pragma unroll
-            for (int k = 0; k < NPG; ++k) load_pass(buf[t % DIST][k], t * NPG + k, c + 1);
+            for (int k = 0; k < NPG; ++k) load_pass(sbuf[t % DIST][k], t * NPG + k, c + 1);
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();   // B_{s+1}
         }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HT(ht_a)
+        __builtin_amdgcn_s_barrier();   // B_{s+1}
+        HT(ht_c)
       }
     }
-    if (NSR > NS) __builtin_amdgcn_s_barrier();   // the padding step of an odd K loop
-  } else if (wave >= 4) {
-    // ------------------------------------------------------------------ weight producers (LDS-DMA, 128 lanes)
-    // One instruction = 16 tile rows x 4 chunks of 16 B; the two waves issue 4 each per K step (128 rows x 64 B).
-    const int pw = wave - 4;
-    const int q = (lane & 3) ^ ((lane >> 4) & 3);   // which 16-byte chunk of its row this lane fetches
-    const int qoff = PREC == 3 ? (q & 1) * 16 + (q >> 1) * 64 : q * 16;
-    const unsigned char* wptr[4];
-    int wstep[4];
+    {   // last chunk: no further strip; tiles s+1 / s+4 exist while they stay inside the chunk
+      const int c = g.nch - 1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int col = n0 + (pw * 4 + k) * 16 + (lane >> 2);
-      const bool ok = col < p.ncols;
-      wptr[k] = ok ? reinterpret_cast<const unsigned char*>(p.w_pk) + (size_t)col * (4 * (size_t)p.ldw) + qoff
-                   : reinterpret_cast<const unsigned char*>(p.zero) + (lane & 3) * 16;
-      wstep[k] = ok ? 1 : 0;
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) write_w(wbuf[(t + 1) % 3], (c + t + 1) & 1);
+        if (t + 4 < 9) load_w(wbuf[(t + 1) % 3], c, t + 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HT(ht_a)
+        __builtin_amdgcn_s_barrier();   // B_{s+1}
+        HT(ht_c)
+      }
     }
-    int c = 0, t = 0;
-    auto issue = [&](int slot) {
-      const int kofs = t * p.cin_pad + c * CH;
-      int uoff = (kofs >> 5) * 128 + (PREC == 3 ? ((kofs >> 4) & 1) * 32 : 0);
-      if (c >= g.nch) uoff = -1;   // the padding step of an odd K loop (and anything past it): zeros
-      unsigned char* dst = dsm + slot * HALO_BSLOT + pw * 4096;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned char* src = uoff >= 0 ? wptr[k] + (size_t)uoff * wstep[k]
-                                             : reinterpret_cast<const unsigned char*>(p.zero) + (lane & 3) * 16;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + k * 1024), 16, 0, 0);
-      }
-      if (++t == T) {
-        t = 0;
-        ++c;
-      }
-    };
-    // tile s+1 must have landed at barrier B_{s+1}; tile s+4 goes into the slot of tile s, which the consumers read for the
-    // last time before B_{s+1}.  Waiting FIRST and issuing AFTER the barrier keeps the issue work (address VALU + four DMA
-    // instructions at 100-180 cycles each next to the consumers' LDS traffic) off the barrier's critical path.
-    issue(0);
-    issue(1);
-    issue(2);
-    issue(3);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // B_0: tile 0 has landed
-    int st = 0;
-    for (int s = 0; s < NSR; ++s) {
-      if (s + 3 < NSR) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile s+1 has landed, tiles s+2 and s+3 stay in flight
-      } else if (s + 2 < NSR) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();   // B_{s+1}
-      if (s + 4 < NSR && !(g.debug & 2)) issue(st);
-      st = st == HALO_NSLOT - 1 ? 0 : st + 1;
-    }
+    if (NSR > NS) __builtin_amdgcn_s_barrier();   // the padding step of an odd K loop (the consumers multiply the zero row)
+    HT_STORE(wave)
   } else {
     // ------------------------------------------------------------------ consumers: ds_read_b128 + MFMA only
 #pragma unroll
@@ -272,6 +291,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
       b_lo[set][j] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
     };
     int slot = 0;
+    HT_DECL
     // One K step = TM sub-steps (row blocks) of 3*TN (bf16x3) or 2*TN MFMAs.  Sub-step i runs from registers; in its MFMA
     // shadow the fragment of sub-step i+2 is read: this step's row block i+2, or -- in the last two sub-steps, after the
     // step barrier -- the next step's row blocks 0 and 1 and its weight fragments (the other register set).  The barrier
@@ -284,8 +304,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
       for (int i = 0; i < TM; ++i) {
         if (i == TM - 2) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          HT(ht_a)
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
+          HT(ht_c)
           a0 = a0n;
           tbit = tbitn;
           slot = slot == HALO_NSLOT - 1 ? 0 : slot + 1;
@@ -322,6 +344,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
       step(std::integral_constant<int, 0>{});
       step(std::integral_constant<int, 1>{});
     }
+    HT_STORE(wave)
   }
 
   // ---------------------------------------------------------------------- epilogue (all eight waves store rows)
@@ -413,8 +436,8 @@ bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   g.toff0 = g.sgn * (-a.pad_h * a.W - a.pad_w);
   g.tstep_col = g.sgn * a.dil;
   g.tstep_row = g.sgn * (a.dil * a.W - (a.KW - 1) * a.dil);
-  g.s_pad = (int)((S + 31) / 32 * 32);
-  g.npass = g.s_pad / 32;
+  g.s_pad = (int)((S + 63) / 64 * 64);
+  g.npass = g.s_pad / 64;
   g.npg = (g.npass + 5) / 6;   // six load groups per chunk (conv_halo_kernel: NGRP)
   if (g.npg > HALO_MAXP) return false;
   const int ch = prec == 3 ? 16 : 32;
@@ -425,8 +448,6 @@ bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   const int loop = HALO_OFF_STRIP + 2 * g.s_pad * 64;
   g.lds_bytes = loop > epi ? loop : epi;
   if (g.lds_bytes > 160 * 1024) return false;
-  static const int dbg = getenv("ZS3_HALO_DEBUG") ? atoi(getenv("ZS3_HALO_DEBUG")) : 0;
-  g.debug = dbg;
   if (out) *out = g;
   return true;
 }
@@ -450,9 +471,6 @@ int launch_halo_t(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
     case 1: return launch_halo_n<PREC, BM, 1>(a, g, st);
     case 2: return launch_halo_n<PREC, BM, 2>(a, g, st);
     case 3: return launch_halo_n<PREC, BM, 3>(a, g, st);
-    case 4: return launch_halo_n<PREC, BM, 4>(a, g, st);
-    case 5: return launch_halo_n<PREC, BM, 5>(a, g, st);
-    case 6: return launch_halo_n<PREC, BM, 6>(a, g, st);
   }
   return -7;
 }

@@ -61,10 +61,23 @@ def halo_ok(x_shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad
                                        I(pad_h), I(pad_w), I(dil), I(int(dgrad)), I(prec), I(tile_cfg)))
 
 
-def pick_halo_tile(m, ncols):
+# Tile height of the strip-resident kernel.  Measured inside the training step (same-box A/B, tools/probe/ab_env.sh, ms per
+# step): no strip kernel 48.34 / 48.40, 192-row tiles wherever they need fewer rounds 48.31 / 48.07, 256 everywhere 47.79 /
+# 47.86, 192 everywhere 48.46 / 48.33, the rule below 47.66 / 47.68.  In isolation 192-row tiles win (182 tiles on 256 CUs
+# instead of 138: 78 us against 91 us for the 3x3 256->256 layer, 99 us on the LDS-DMA kernel), but in backward the
+# weight-gradient streams fill whatever CUs a launch leaves idle, so what counts there is CU-time per tile, and a 256-row
+# tile spends 75 % of its K loop issuing MFMAs against 67 % for 192 rows.
+HALO_BM = os.environ.get("ZS3_HALO_BM", "bwd256")   # auto | 256 | 192 | bwd256 (dgrad launches on 256-row tiles)
+
+
+def pick_halo_tile(m, ncols, dgrad=False):
     """256- or 192-row tiles for the strip-resident kernel: the tile height that needs fewer rounds x rows on 256 CUs
     (16 x 33 x 33 output pixels x 256 channels: 138 tiles of 256 rows -> one round at 54 % of the chip; 182 tiles of
     192 rows -> one round at 71 %, each 0.75x as long)."""
+    if HALO_BM in ("256", "192"):
+        return 41 if HALO_BM == "256" else 42
+    if HALO_BM == "bwd256" and dgrad:
+        return 41
     nt = (ncols + 127) // 128
     def cost(bm):
         tiles = ((m + bm - 1) // bm) * nt
@@ -198,7 +211,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
         if HALO and tile_cfg in (31, 32) and kh * kw > 1:
-            cand = pick_halo_tile(m, ncols)
+            cand = pick_halo_tile(m, ncols, dgrad)
             if halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, cand):
                 tile_cfg = cand
             elif cand == 41 and halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad,
@@ -243,7 +256,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
               "zs3_conv_igemm")
     if prof:
         e1.record()
-        PROFILE.append(("conv_halo<%d,128,%d>" % (256 if tile_cfg == 41 else 192, prec) if tile_cfg in (41, 42) else
+        PROFILE.append(("conv_halo<%d>" % prec if tile_cfg in (41, 42) else
                         "conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
