@@ -412,3 +412,65 @@ def test_gradient_accumulation_over_two_backwards(dev):
     torch.cuda.synchronize()
     for (name, p), g1, g2 in zip(m.named_parameters(), *single):
         assert torch.equal(p.grad, g1 + g2), name
+
+
+def test_default_init_train_step_vs_reference_goldens(dev, golden):
+    """The reference's OWN train-mode outputs for the default-initialised network (seed 1, no taming, dropout off, 65x65, B=2;
+    tests/golden/deeplab_forward.npz, written by tools/make_goldens.py from /root/reference): logits, loss, the classifier
+    and stem weight gradients and the 226 BatchNorm running statistics -- the goldens no other GPU test touches.
+
+    This configuration is ill-conditioned: batch statistics over 2 x 5 x 5 positions in 101 layers amplify a rounding
+    difference ~1e4-fold (the reference's own fp32 result sits 1.7e-3 (logits) to several 1e-2 (early-layer gradients) away
+    from its fp64 evaluation -- measured below, not assumed).  bf16x3 products carry 2^-16..2^-18 instead of fp32's 2^-24, so
+    the same amplification gives a few 1e-2.  Two kinds of assertion, both with the tolerance written next to them:
+    (1) against the reference's goldens, 3x what the kernels deliver (delivered: logits 3.6e-2, loss 3.6e-4, classifier
+        gradient 3.5e-2, running statistics 2.5e-3; the stem gradient -- the end of the longest chain -- 0.36);
+    (2) against the fp64 oracle, the error measured in units of the reference's own fp32 error: at most 64x for the logits and
+        the classifier gradient (2^8 = 256 would be the pure round-off ratio).
+    The well-conditioned variants of this step (bn3 gains 0.1, as in a trained ResNet) are held to 1e-3 / 2e-3 above."""
+    import zs3_oracle as zo
+    from zs3_amd.utils.loss import SegmentationLosses
+    g = golden("deeplab_forward.npz")
+    m, ref = build_pair(tame=False)
+    ref64 = copy.deepcopy(ref).double().train()
+    b = zo.make_synthetic_batch(2, 65, seed=7, with_label_emb=False)
+    w = torch.ones(21)
+    w[[10, 14]] = 100.0
+    m = m.to(dev).train()
+    out = m(b["image"].to(dev))
+    loss = SegmentationLosses(weight=w.to(dev), cuda=True).build_loss("ce")(out, b["label"].to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    r64 = ref64(b["image"].double())
+    zo.SegmentationLosses(weight=w.double()).build_loss("ce")(r64, b["label"]).backward()
+    gold = torch.from_numpy(g["train_logits"])
+    gp, gs = torch.from_numpy(g["grad_pred_w"]), torch.from_numpy(g["grad_stem_w"])
+    # (1) against the reference's own fp32 outputs
+    e_logits = rel(out, gold)
+    e_loss = abs(loss.item() - float(g["train_loss"])) / abs(float(g["train_loss"]))
+    e_pred = rel(m.decoder.pred_conv.weight.grad, gp)
+    e_stem = rel(m.backbone.conv1.weight.grad[:8], gs)
+    sd = m.state_dict()
+    worst_run, worst_key = 0.0, None
+    for k, r in zip(g["run_names"], g["run_stats"]):
+        t = sd[str(k)].double().cpu().reshape(-1)
+        e = abs(t.abs().sum().item() - r[1]) / max(abs(r[1]), 1e-30)
+        if e > worst_run:
+            worst_run, worst_key = e, str(k)
+    # (2) against fp64, in units of the reference's fp32 error
+    ref_logits32, ref_pred32 = rel(gold, r64), rel(gp, ref64.decoder.pred_conv.weight.grad)
+    ref_stem32 = rel(gs, ref64.backbone.conv1.weight.grad[:8])
+    our_logits, our_pred = rel(out, r64), rel(m.decoder.pred_conv.weight.grad, ref64.decoder.pred_conv.weight.grad)
+    our_stem = rel(m.backbone.conv1.weight.grad[:8], ref64.backbone.conv1.weight.grad[:8])
+    print(f"[default-init train] vs reference goldens: logits {e_logits:.2e} loss {e_loss:.2e} grad_pred_w {e_pred:.2e} "
+          f"grad_stem_w {e_stem:.2e} running stats {worst_run:.2e} ({worst_key}); vs fp64: logits {our_logits:.2e} "
+          f"(reference fp32: {ref_logits32:.2e}), grad_pred_w {our_pred:.2e} ({ref_pred32:.2e}), grad_stem_w {our_stem:.2e} "
+          f"({ref_stem32:.2e})")
+    assert e_logits < 0.11        # 3 x delivered (3.6e-2)
+    assert e_loss < 1.1e-3        # 3 x delivered (3.6e-4); the north-star 1e-3 is met
+    assert e_pred < 0.11          # 3 x delivered (3.5e-2)
+    assert worst_run < 7.5e-3     # 3 x delivered (2.5e-3)
+    assert e_stem < 1.1           # 3 x delivered (0.36): a sanity bound only, see (2)
+    assert our_logits < 64 * ref_logits32
+    assert our_pred < 64 * ref_pred32
+    assert our_stem < 64 * ref_stem32

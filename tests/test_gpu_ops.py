@@ -624,7 +624,7 @@ def test_label_order_matches_torch_sequence(dev, shape, size, tdtype):
     assert torch.equal(order.cpu(), torch.argsort(want, dim=1, stable=True))
 
 
-@pytest.mark.parametrize("hw", [(33, 37), (65, 65)])
+@pytest.mark.parametrize("hw", [(33, 37), (65, 65), (513, 513)])
 def test_stem_wgrad_folds_the_taps(dev, hw):
     """The stem's weight gradient (7x7/s2 conv as a 7x1 filter over 32-float NHWC4 windows, resnet.py:73): zs3_conv_wgrad folds
     the seven taps into the channel axis (one 224-channel launch instead of seven half-empty tiles) -- against torch's
@@ -632,7 +632,7 @@ def test_stem_wgrad_folds_the_taps(dev, hw):
     from zs3_amd import ops
     from zs3_amd._lib import I, P, check, lib, stream
     g = torch.Generator().manual_seed(hw[0])
-    n, (h, w) = 2, hw
+    n, (h, w) = (2 if hw[0] < 500 else 1), hw
     image = torch.randn(n, 3, h, w, generator=g)
     ho, wo = ops.conv_out_size(h, 7, 2, 3, 1), ops.conv_out_size(w, 7, 2, 3, 1)
     dy = torch.randn(n, 64, ho, wo, generator=g)
@@ -758,3 +758,78 @@ def test_conv_halo_kernel_geometries(dev, geom, prec):
         ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), padding=d, dilation=d)
         y, _ = ops.conv2d_fwd(x, wp, 1, d, d, tile_cfg=0)     # the rule's own choice for this layer
         assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5
+
+
+# the 34 distinct convolution shapes of DeepLabv3+ (ResNet-101, output stride 16) at 513x513 --
+# (Cin, Cout, k, stride, dilation, input H = W).  The 7x7 stem has its own test below (it runs as a 7x1 conv over NHWC4 windows).
+NETWORK_CONV_SHAPES = [
+    (256, 1024, 1, 1, 1, 33), (1024, 256, 1, 1, 1, 33), (256, 256, 3, 1, 1, 33), (64, 256, 1, 1, 1, 129), (128, 512, 1, 1, 1, 65),
+    (64, 64, 3, 1, 1, 129), (512, 128, 1, 1, 1, 65), (128, 128, 3, 1, 1, 65), (512, 2048, 1, 1, 1, 33), (256, 64, 1, 1, 1, 129),
+    (2048, 512, 1, 1, 1, 33), (64, 64, 1, 1, 1, 129), (256, 128, 1, 1, 1, 129), (128, 128, 3, 2, 1, 129), (256, 512, 1, 2, 1, 129),
+    (512, 256, 1, 1, 1, 65), (256, 256, 3, 2, 1, 65), (512, 1024, 1, 2, 1, 65), (1024, 512, 1, 1, 1, 33), (512, 512, 3, 1, 2, 33),
+    (512, 512, 3, 1, 4, 33), (512, 512, 3, 1, 8, 33), (1024, 2048, 1, 1, 1, 33), (2048, 256, 1, 1, 1, 33), (2048, 256, 3, 1, 6, 33),
+    (2048, 256, 3, 1, 12, 33), (2048, 256, 3, 1, 18, 33), (2048, 256, 1, 1, 1, 1), (1280, 256, 1, 1, 1, 33), (256, 48, 1, 1, 1, 129),
+    (304, 256, 3, 1, 1, 129), (256, 256, 3, 1, 1, 129), (256, 21, 1, 1, 1, 129),
+]
+
+
+@pytest.mark.parametrize("shape", NETWORK_CONV_SHAPES, ids=lambda s: "%dto%d_k%d_s%d_d%d_at%d" % s)
+def test_every_network_conv_shape(dev, shape):
+    """Each of the network's distinct conv shapes at its real spatial size, through the product's own autograd node
+    (Fz.conv_bn_act: the kernel / tile choice the training step makes), forward + data gradient + weight gradient against
+    fp64 torch on the host.  Batch 2 at 33x33 and below, 1 above; the classifier (256 -> 21) carries its bias."""
+    from zs3_amd import functional as Fz
+    ci, co, k, s, d, h = shape
+    n = 2 if h <= 33 else 1
+    g = torch.Generator().manual_seed(ci * 7 + co + k + d + h)
+    x = torch.randn(n, ci, h, h, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    bias = torch.randn(co, generator=g) if co == 21 else None
+    pad = d * (k // 2)
+    x64, w64 = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    b64 = bias.double().requires_grad_(True) if bias is not None else None
+    ref = F.conv2d(x64, w64, b64, stride=s, padding=pad, dilation=d)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    xg = x.to(dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    wg = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = bias.to(dev).requires_grad_(True) if bias is not None else None
+    y = Fz.conv_bn_act(xg, wg, bias=bg, stride=s, pad=pad, dil=d)
+    y.backward(dy.to(dev).permute(0, 2, 3, 1).contiguous())
+    torch.cuda.synchronize()
+    assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5
+    assert rel(xg.grad.permute(0, 3, 1, 2), x64.grad) < 5e-5
+    assert rel(wg.grad, w64.grad) < 5e-5
+    if bias is not None:
+        assert rel(bg.grad, b64.grad) < 5e-5
+
+
+def test_stem_conv_at_full_size(dev):
+    """The 34th shape: the 7x7 / stride-2 stem (3 -> 64, 513 -> 257) as the backbone runs it -- NHWC4 windows, folded taps --
+    with its BatchNorm (train mode) and ReLU, forward, weight gradient and BN gradients against fp64 torch
+    (resnet.py:79,186-188).  The upstream gradient is zeroed where the fp64 pre-activation lies within 1e-3 of the ReLU's
+    kink: there a 1e-5 difference in the conv output flips the ReLU mask, which moves sum(dz) -- the BN's beta gradient, and
+    through it every weight gradient -- by a whole element (measured without the guard: 6e-3 on dW at 513x513 from ~2 flipped
+    elements of 4.2 million, with every kernel involved exact to 5e-6; tools/probe/stem_probe.py)."""
+    import copy
+    import torch.nn as nn
+    from zs3_amd.modeling.backbone.resnet import ResNet101
+    torch.manual_seed(5)
+    net = ResNet101(16, nn.BatchNorm2d, pretrained=False)
+    w64, bn64 = net.conv1.weight.detach().double().clone().requires_grad_(True), copy.deepcopy(net.bn1).double()
+    net = net.to(dev).train()
+    g = torch.Generator().manual_seed(11)
+    image = torch.randn(1, 3, 513, 513, generator=g)
+    z64 = bn64.train()(F.conv2d(image.double(), w64, stride=2, padding=3))
+    ref = F.relu(z64)
+    up = torch.randn(ref.shape, generator=g) * (z64.detach().abs() > 1e-3).float()
+    ref.backward(up.double())
+    out = net._stem(image.to(dev))                      # NHWC
+    out.backward(up.to(dev).permute(0, 2, 3, 1).contiguous())
+    torch.cuda.synchronize()
+    assert out.shape == (1, 257, 257, 64)
+    assert rel(out.permute(0, 3, 1, 2), ref) < 5e-5
+    assert rel(net.conv1.weight.grad, w64.grad) < 1e-4
+    assert rel(net.bn1.weight.grad, bn64.weight.grad) < 1e-4
+    assert rel(net.bn1.bias.grad, bn64.bias.grad) < 1e-4
+    assert rel(net.bn1.running_var, bn64.running_var) < 1e-5
