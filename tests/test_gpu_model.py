@@ -27,6 +27,22 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+# Two SGD iterations against the fp64 oracle, relative L2 error of the accumulated update of representative weights.  Each
+# tolerance is 3x what the kernels deliver on MI355X (delivered value in the comment; the test prints them), capped at the
+# 3e-2 the test used before.  The error grows with the depth of the backward chain below the layer: every ReLU whose
+# pre-activation sits within ~1e-5 of zero may take the other branch (tests/test_gpu_ops.py::test_stem_conv_at_full_size).
+UPDATE_TOL = {
+    "decoder.pred_conv.weight": 4e-4,           # 1.2e-4
+    "decoder.pred_conv.bias": 1e-4,             # 2.4e-5
+    "decoder.last_conv.4.weight": 9e-3,         # 3.0e-3
+    "aspp.conv1.weight": 2e-2,                  # 6.7e-3
+    "backbone.layer4.2.conv3.weight": 3e-2,     # 9.8e-3
+    "backbone.layer1.0.conv1.weight": 3e-2,     # 1.6e-2 (cap)
+    "backbone.conv1.weight": 3e-2,              # 1.7e-2 (cap)
+    "backbone.bn1.weight": 3e-2,                # 1.6e-2 (cap)
+}
+
+
 def build_pair(num_classes=21, tame=True, dropout=0.0, **kw):
     import zs3_oracle as zo
     from zs3_amd.modeling.deeplab import DeepLab
@@ -217,7 +233,9 @@ def test_supervised_step_vs_oracle(dev):
     for k in ("decoder.pred_conv.weight", "decoder.pred_conv.bias", "decoder.last_conv.4.weight", "aspp.conv1.weight",
               "backbone.layer4.2.conv3.weight", "backbone.layer1.0.conv1.weight", "backbone.conv1.weight", "backbone.bn1.weight"):
         d, dr = sd[k].double().cpu() - init[k], sdr[k] - init[k]
-        assert ((d - dr).norm() / dr.norm()).item() < 3e-2, k
+        e = ((d - dr).norm() / dr.norm()).item()
+        print(f"[supervised step] update of {k}: rel L2 {e:.2e}")
+        assert e < UPDATE_TOL[k], k
 
 
 def test_context_60_classes_forward_and_step(dev):
@@ -308,8 +326,11 @@ def test_gmmn_step_vs_oracle(dev):
         # Adam moves every weight by ~lr per step whatever the gradient magnitude: where a gradient is ~0 its sign,
         # hence the step, is rounding noise.  ~50 Adam steps were taken: bound the worst element by a few steps and
         # the mean error tightly.
-        assert rel(p, pr) < 2e-2, k
-        assert ((p.detach().cpu() - pr.detach()).abs().mean() / pr.detach().abs().mean()).item() < 2e-3, k
+        e_max = rel(p, pr)
+        e_mean = ((p.detach().cpu() - pr.detach()).abs().mean() / pr.detach().abs().mean()).item()
+        print(f"[gmmn step] generator {k}: max {e_max:.2e} mean {e_mean:.2e}")
+        assert e_max < 2e-2, k          # delivered 1.3e-2 (model.0.bias): one Adam step (2e-4) of a sign flip on |w| ~ 1e-2
+        assert e_mean < 1.5e-3, k       # 3 x delivered (5.1e-4)
     assert rel(m.decoder.pred_conv.weight, ref.decoder.pred_conv.weight) < 2e-3
     assert rel(m.decoder.pred_conv.bias, ref.decoder.pred_conv.bias) < 2e-3
     assert torch.equal(m.backbone.conv1.weight.detach(), stem0)           # backbone receives no gradient
