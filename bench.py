@@ -114,8 +114,7 @@ def main():
     torch.manual_seed(1)
     model = DeepLab(num_classes=args.classes, pretrained=False, sync_bn=bool(args.sync_bn)).to(dev).train()
     broadcast_parameters(model)
-    if args.sync_bn and world > 1:
-        enable_sync_bn(model)
+    # sync_bn=True models exchange their BatchNorm sums across ranks by construction; nothing to switch on
     groups = [{"params": model.get_1x_lr_params(), "lr": 0.007}, {"params": model.get_10x_lr_params(), "lr": 0.07}]
     opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
     crit = SegmentationLosses(cuda=True, group=True if (world > 1 or args.ddp_selftest) else None).build_loss("ce")

@@ -1,0 +1,176 @@
+"""World-size-2 run of the PRODUCT's N>1 path on ONE MI355X: two processes share cuda:0 and talk through the gloo backend on
+device tensors (RCCL refuses two ranks on one device; the collectives' call sites are the same for either backend).
+
+  supervised: DeepLab(sync_bn=True) + GradSync (zero-copy buckets, hooks, end-of-backward join) + the globally normalised CE
+              on two DIFFERENT shards must equal the single-process step on the concatenated batch -- logits (SyncBN
+              statistics are global), loss, every gradient, the BN running statistics.  SyncBN is on by construction: the
+              script makes no enable call (zs3/modeling/sync_batchnorm/batchnorm.py:46-89, train_pascal.py:279).
+  GMMN step : GMMNStep(group=True) on two shards ends with identical generator / pred_conv weights on both ranks, the
+              generator equal to the average of the two single-process runs on the shards (replicas with
+              parameter averaging), the classifier loss equal to the CE normalised over both shards.
+"""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tamed_model(sync_bn):
+    from zs3_amd.modeling.deeplab import DeepLab
+    torch.manual_seed(1)
+    m = DeepLab(num_classes=21, pretrained=False, sync_bn=sync_bn)
+    for name, mod in m.named_modules():
+        if name.endswith("bn3"):
+            mod.weight.data.fill_(0.1)
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def _supervised(dev, image, label, ddp):
+    from zs3_amd.parallel import GradSync, broadcast_parameters
+    from zs3_amd.utils.loss import SegmentationLosses
+    m = _tamed_model(sync_bn=True).to(dev).train()
+    sync = None
+    if ddp:
+        broadcast_parameters(m)
+        sync = GradSync(list(m.parameters()), bucket_mb=16.0)
+    w = torch.ones(21, device=dev)
+    w[[10, 14]] = 100.0
+    crit = SegmentationLosses(weight=w, cuda=True, group=True if ddp else None).build_loss("ce")
+    out = m(image)
+    loss = crit(out, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    keys = ("decoder.pred_conv.weight", "decoder.last_conv.0.weight", "aspp.aspp2.atrous_conv.weight", "aspp.bn1.weight",
+            "backbone.layer3.5.conv2.weight", "backbone.layer3.5.bn2.bias", "backbone.layer1.0.conv1.weight",
+            "backbone.conv1.weight", "backbone.bn1.weight")
+    params = dict(m.named_parameters())
+    res = {"logits": out.detach().cpu(), "loss": float(loss.item()),
+           "grads": {k: params[k].grad.detach().float().cpu().clone() for k in keys},
+           "running": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()
+                       if k in ("backbone.bn1.running_mean", "backbone.layer3.5.bn2.running_var", "aspp.bn1.running_var",
+                                "decoder.last_conv.1.running_mean")}}
+    if sync is not None:
+        res["bytes"] = sync.bytes_reduced
+        sync.remove()
+    return res
+
+
+def _gmmn(dev, image, label, table, ddp, steps=1):
+    from zs3_amd import functional as Fz
+    from zs3_amd.gmmn_trainer import GMMNStep
+    from zs3_amd.modeling.gmmn import GMMNnetwork
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    seen = [c for c in range(21) if c not in (10, 14)]
+    m = _tamed_model(sync_bn=False).to(dev).train()
+    torch.manual_seed(4)
+    gen = GMMNnetwork(300, 300, 256, 256).to(dev).train()
+    for mod in gen.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    Fz.manual_seed(77)
+    w = torch.ones(21, device=dev)
+    w[[10, 14]] = 100.0
+    groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+    opt, opt_g = SGD(groups, momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4)
+    crit = SegmentationLosses(weight=w, cuda=True, group=True if ddp else None).build_loss("ce")
+    step = GMMNStep(m, gen, opt, opt_g, crit, seen=seen, unseen=[10, 14], noise="cpu", group=True if ddp else None)
+    losses = []
+    for it in range(steps):
+        torch.manual_seed(21 + it)
+        gl, cl, _ = step(image, label, table=table)
+        losses.append((gl, cl))
+    torch.cuda.synchronize()
+    return {"losses": losses, "gen": [p.detach().cpu().clone() for p in gen.parameters()],
+            "pred_w": m.decoder.pred_conv.weight.detach().cpu().clone(), "pred_b": m.decoder.pred_conv.bias.detach().cpu().clone()}
+
+
+def _batch():
+    import zs3_oracle as zo
+    b = zo.make_synthetic_batch(4, 65, seed=31, with_label_emb=False)
+    label = b["label"].clone()
+    seen_only = label.clone()          # GMMN part: no unseen pixels, so no generated features enter the classifier loss
+    seen_only[(seen_only == 10) | (seen_only == 14)] = 3
+    table = torch.nn.functional.normalize(torch.randn(21, 300, generator=torch.Generator().manual_seed(5)), dim=1)
+    return b["image"], label, seen_only, table
+
+
+def _worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        image, label, seen_only, table = _batch()
+        sl = slice(2 * rank, 2 * rank + 2)
+        res = {"sup": _supervised(dev, image[sl].to(dev), label[sl].to(dev), ddp=True),
+               "gmmn": _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev), ddp=True)}
+        torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_two_ranks_on_one_device_equal_the_single_process_step():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    dev = torch.device("cuda:0")
+    image, label, seen_only, table = _batch()
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_worker, args=(2, _free_port(), td), nprocs=2, join=True)
+        r = [torch.load(os.path.join(td, f"rank{k}.pt")) for k in range(2)]
+    # ---------------- supervised: two shards + SyncBN + GradSync + global CE == one process on the whole batch
+    one = _supervised(dev, image.to(dev), label.to(dev), ddp=False)
+    both = torch.cat([r[0]["sup"]["logits"], r[1]["sup"]["logits"]], 0)
+    assert _rel(both, one["logits"]) < 2e-4                 # global BN statistics in every one of the 113 layers
+    for k in range(2):
+        assert abs(r[k]["sup"]["loss"] - one["loss"]) < 1e-5 * abs(one["loss"])
+        assert r[k]["sup"]["bytes"] == 4 * 59344309         # every parameter went through the all-reduce once
+        for name, gref in one["grads"].items():
+            assert _rel(r[k]["sup"]["grads"][name], gref) < 5e-3, (k, name)
+        for name, v in one["running"].items():
+            assert _rel(r[k]["sup"]["running"][name], v) < 1e-4, (k, name)
+    for name in one["grads"]:                               # the reduced gradients are bit-identical on both ranks
+        assert torch.equal(r[0]["sup"]["grads"][name], r[1]["sup"]["grads"][name]), name
+    # ---------------- GMMN step: replicas with parameter averaging
+    for a, b in zip(r[0]["gmmn"]["gen"], r[1]["gmmn"]["gen"]):
+        assert torch.equal(a, b)
+    assert torch.equal(r[0]["gmmn"]["pred_w"], r[1]["gmmn"]["pred_w"])
+    solo = [_gmmn(dev, image[2 * k:2 * k + 2].to(dev), seen_only[2 * k:2 * k + 2].to(dev), table.to(dev), ddp=False)
+            for k in range(2)]
+    for p2, pa, pb in zip(r[0]["gmmn"]["gen"], solo[0]["gen"], solo[1]["gen"]):
+        assert _rel(p2, (pa + pb) / 2) < 1e-5               # generator = mean of the two ranks' locally trained replicas
+    # no unseen pixels -> the classifier loss does not depend on the generator, and (plain BN: per-rank statistics) each
+    # rank sees the features its shard sees alone: the globally normalised CE must be sum(w*nll) / sum(w) / B over BOTH
+    # shards (loss.py:33-46 on the gathered batch), rebuilt here from the two single-shard losses and their valid-pixel counts
+    n = [float((seen_only[2 * k:2 * k + 2] != 255).sum()) for k in range(2)]
+    expect = (solo[0]["losses"][0][1] * 2 * n[0] + solo[1]["losses"][0][1] * 2 * n[1]) / (n[0] + n[1]) / 4
+    for k in range(2):
+        assert abs(r[k]["gmmn"]["losses"][0][1] - expect) < 1e-5 * abs(expect), (r[k]["gmmn"]["losses"], expect)
+    assert not torch.equal(r[0]["gmmn"]["pred_w"], solo[0]["pred_w"])     # the classifier step used both shards' gradients

@@ -502,7 +502,11 @@ class _BnAct(torch.autograd.Function):
         if cfg["training"]:
             if m <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
-            st = ops.bn_fwd_finalize(ops.colstats(y), m, gamma, beta, cfg["eps"], cfg["momentum"], cfg["running_mean"],
+            part, count = ops.colstats(y), m
+            if cfg.get("sync") is not None:   # SynchronizedBatchNorm2d under more than one rank: global sums and count
+                from .parallel import combine_bn_partials
+                part, count = combine_bn_partials(part, count, None if cfg["sync"] is True else cfg["sync"])
+            st = ops.bn_fwd_finalize(part, count, gamma, beta, cfg["eps"], cfg["momentum"], cfg["running_mean"],
                                      cfg["running_var"], cfg.get("nbt"))
         else:
             st = ops.bn_eval_affine(gamma, beta, cfg["running_mean"], cfg["running_var"], cfg["eps"])
@@ -519,8 +523,13 @@ class _BnAct(torch.autograd.Function):
         m = y.numel() // y.shape[-1]
         part = ops.bn_bwd_stats(dA, a, y, st[0], st[1])
         fin = ops.bn_bwd_finalize(part, m, cfg["training"])
-        dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, fin[2] if cfg["training"] else None,
-                            fin[3] if cfg["training"] else None, act=cfg["act"])
+        c1, c2 = (fin[2], fin[3]) if cfg["training"] else (None, None)
+        if cfg["training"] and cfg.get("sync") is not None:
+            from .parallel import combine_bn_partials   # dgamma / dbeta stay per rank (summed by GradSync); c1, c2 are global
+            gpart, gcount = combine_bn_partials(part, m, None if cfg["sync"] is True else cfg["sync"])
+            fin_g = ops.bn_bwd_finalize(gpart, gcount, True)
+            c1, c2 = fin_g[2], fin_g[3]
+        dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, act=cfg["act"])
         return dy.reshape(y.shape), fin[0], fin[1], None
 
 
@@ -536,6 +545,7 @@ def bn_act(y, bn, act=ACT_NONE, out=None):
             nbt = bn.num_batches_tracked
     track = bn.training and bn.track_running_stats
     cfg = {"training": use_batch, "nbt": nbt, "eps": bn.eps, "momentum": mom if mom is not None else 0.0, "act": act, "out": out,
+           "sync": getattr(bn, "_zs3_sync_group", None),
            "running_mean": bn.running_mean if track or not use_batch else None,
            "running_var": bn.running_var if track or not use_batch else None}
     return _BnAct.apply(y, bn.weight, bn.bias, cfg)

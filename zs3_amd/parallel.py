@@ -225,14 +225,16 @@ def combine_bn_partials(partial, count, group=None):
     return torch.stack((hi, lo), 0), buf[2 * c:]
 
 
-def enable_sync_bn(module, group=None):
-    """Honour sync_bn=True across ranks: batch statistics (forward) and their gradients (backward) of every
-    SynchronizedBatchNorm2d are all-reduced.  Uses (var + eps)^-1/2 like F.batch_norm, not the vendored
-    clamp(var, eps)^-1/2 ('SyncBN semantics')."""
+def enable_sync_bn(module, group=None, enabled=True):
+    """SynchronizedBatchNorm2d synchronises across ranks by itself whenever torch.distributed runs with more than one rank
+    (modeling/sync_batchnorm/batchnorm.py); this call only selects a process group other than the default one, or switches
+    the exchange off (`enabled=False`: per-rank statistics, what bench.py --sync-bn 0 measures).  Returns the number of
+    SyncBN layers.  Uses (var + eps)^-1/2 like F.batch_norm, not the vendored clamp(var, eps)^-1/2."""
     from .modeling.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
     n = 0
     for m in module.modules():
         if isinstance(m, SynchronizedBatchNorm2d):
-            m._zs3_sync_group = group if group is not None else True
+            m.sync_group = group
+            m.sync_enabled = bool(enabled)
             n += 1
     return n
