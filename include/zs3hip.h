@@ -148,14 +148,7 @@ int zs3_bilinear_fwd(const float* x, int ldx, float* out, int ldo, int N, int H,
                      void* stream);
 int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int H, int W, int Ho, int Wo, int C,
                      int accumulate, void* stream);
-/* The end of the training step fused (deeplab.py:44,55 upsample + loss.py:31-46 CE, backward): d(loss)/d(lr) for
- * loss = CE(bilinear(lr -> Ho x Wo, align_corners=True), target) without the full-resolution gradient ever existing.  One
- * thread per low-resolution pixel re-samples the scores of the <= 7x7 output pixels it contributes to (the arithmetic of
- * zs3_bilinear_fwd), takes their softmax and accumulates in zs3_bilinear_bwd's order.  lr: [N,H,W,C] (C <= 64), target:
- * float32 or int64 [N,Ho,Wo], loss_ws / gout / batch / ignore_index as for zs3_ce_bwd, dlr: [N,H,W,C] with row stride ldo. */
-int zs3_ce_bilinear_bwd(const float* lr, int ldx, const void* target, int target_is_i64, const float* weight, int N, int H,
-                        int W, int Ho, int Wo, int C, int ignore_index, int batch, const float* loss_ws, const float* gout,
-                        float* dlr, int ldo, void* stream);
+
 /* Validation without shipping logits to the host (train_pascal.py:130-134, Evaluator._generate_matrix metrics.py:73-79):
  * conf[gt*C + pred] += 1 for every target pixel with 0 <= gt < C, pred = first argmax over the C channels of x
  * [N,H,W,C] bilinearly resized (align_corners=True, same arithmetic as zs3_bilinear_fwd) to Ho x Wo -- pass the

@@ -55,7 +55,7 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 5e-5
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 21, 31, 32, 41, 42])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 31, 32, 41, 42])
 def test_conv_every_tile_config(dev, cfg):
     """every kernel variant behind zs3_conv_igemm (register-staged tiles, wave-specialised, LDS-DMA) on ragged shapes:
     M tails, channel tails (304 -> 320, 21 -> 24), stride 2, dilation, fused epilogue and BN partial sums"""
@@ -92,7 +92,7 @@ def test_conv_every_tile_config(dev, cfg):
         assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 5e-5, (cfg, ci, co)
 
 
-@pytest.mark.parametrize("cfg", [11, 14, 21, 31, 32, 41, 42])
+@pytest.mark.parametrize("cfg", [11, 14, 31, 32, 41, 42])
 @pytest.mark.parametrize("mask", ["none", "from_y", "bits"])
 def test_dgrad_epilogue_bn_backward_sums(dev, cfg, mask):
     """zs3_conv_igemm_bnstats: the dgrad epilogue's (sum dz, sum dz*xhat) equal the separate zs3_bn_bwd_stats pass over the
@@ -548,61 +548,6 @@ def test_bn_finalize_short_and_tall_partial_buffers(dev, chunks, c):
     assert torch.allclose(dgamma.double().cpu(), q, rtol=2e-6, atol=1e-5)
     assert torch.allclose(c1.double().cpu(), s / count, rtol=2e-6, atol=1e-7)
     assert torch.allclose(c2.double().cpu(), q / count, rtol=2e-6, atol=1e-7)
-
-
-@pytest.mark.parametrize("classes,tdtype,padded,sizes", [
-    (21, torch.float32, True, (17, 19, 65, 73)),     # the training step's 4x upsample: 8x8 tiles, float4 taps
-    (60, torch.int64, True, (17, 19, 65, 73)),       # Pascal-Context: 4x4 tiles
-    (5, torch.int64, False, (17, 19, 65, 73)),       # dense rows: scalar taps
-    (21, torch.int64, False, (17, 19, 60, 50)),      # a ratio that is not 4: general candidate ranges
-    (21, torch.float32, True, (33, 33, 129, 129)),   # several tiles per image, ragged last tile
-    (21, torch.float32, True, (5, 6, 65, 70))])      # 13x upsample: more candidates than the tiled gather unrolls -> per-thread form
-def test_fused_ce_upsample_backward(dev, monkeypatch, classes, tdtype, padded, sizes):
-    """zs3_ce_bilinear_bwd (CE backward + align_corners upsample backward in one launch, taken when the criterion receives the
-    tensor DeepLab tagged with its low-resolution scores) against the two-kernel path and against fp64 torch on the host
-    (deeplab.py:44,55 + loss.py:31-46)."""
-    import torch.nn.functional as F
-    from zs3_amd import functional as Fz
-    from zs3_amd import ops
-    from zs3_amd.utils import loss as L
-    g = torch.Generator().manual_seed(classes)
-    n, (h, w, H, W) = 2, sizes
-    cp = (classes + 7) // 8 * 8 if padded else classes
-    base = (torch.randn(n, h, w, cp, generator=g) * 3).to(dev)
-    target = torch.randint(0, classes, (n, H, W), generator=g)
-    target[0, :5] = 255
-    target[1, 10:20, 30:] = 255
-    weight = torch.rand(classes, generator=g) + 0.5
-    weight[3] = 100.0
-    grads, losses = [], []
-    monkeypatch.setattr(L, "FUSE_UPSAMPLE_CE", True)      # off by default (measured slower than the two kernels it replaces)
-    for fuse in (True, False):
-        lr = base.clone()[..., :classes].requires_grad_()
-        out = ops.nchw(Fz.bilinear(lr, (H, W)))
-        if fuse:
-            out._zs3_lowres = lr
-        loss = L.cross_entropy_2d(out, target.to(dev).to(tdtype), weight.to(dev))
-        loss.backward()
-        assert lr.grad is not None and lr.grad.shape == lr.shape
-        grads.append(lr.grad.detach().clone())
-        losses.append(loss.item())
-    assert losses[0] == losses[1]
-    scale = grads[1].abs().max().item()
-    assert (grads[0] - grads[1]).abs().max().item() < 2e-6 * scale       # same arithmetic, fused
-    ref = base[..., :classes].double().cpu().permute(0, 3, 1, 2).requires_grad_()
-    up = F.interpolate(ref, size=(H, W), mode="bilinear", align_corners=True)
-    lref = F.cross_entropy(up, target, weight=weight.double(), ignore_index=255, reduction="mean") / n
-    lref.backward()
-    assert abs(losses[0] - lref.item()) < 1e-5 * abs(lref.item())
-    gref = ref.grad.permute(0, 2, 3, 1)
-    assert (grads[0].double().cpu() - gref).abs().max().item() < 1e-4 * gref.abs().max().item()
-    # the tag does not survive a view: that takes the two-kernel path (and still gives the same gradient)
-    lr = base.clone()[..., :classes].requires_grad_()
-    out = ops.nchw(Fz.bilinear(lr, (H, W)))
-    out._zs3_lowres = lr
-    assert L.FUSE_UPSAMPLE_CE
-    L.cross_entropy_2d(out[:, :, :, :], target.to(dev).to(tdtype), weight.to(dev)).backward()
-    assert (lr.grad - grads[1]).abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("shape,size,tdtype", [((3, 513, 513), (129, 129), torch.float32), ((2, 65, 73), (17, 19), torch.int64),

@@ -22,13 +22,16 @@ def _declare(handle):
     import re
     header = os.path.join(os.path.dirname(_HERE), "include", "zs3hip.h")
     if not os.path.exists(header):
-        return
+        # without declared argtypes ctypes would pass 64-bit device pointers and stream handles as 32-bit C ints
+        raise Zs3HipError(f"{header} not found: the ctypes signatures of libzs3hip.so are derived from it")
     text = re.sub(r"/\*.*?\*/", " ", open(header).read(), flags=re.S)
     scalar = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
               "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint}
+    declared, missing = set(), []
     for ret, name, args in re.findall(r"\b(int|long)\s+(zs3_\w+)\s*\(([^)]*)\)\s*;", text):
         fn = getattr(handle, name, None)
         if fn is None:
+            missing.append(name)
             continue
         types = []
         for a in [x.strip() for x in args.split(",")]:
@@ -42,6 +45,10 @@ def _declare(handle):
             types.append(scalar[base])
         fn.argtypes = types
         fn.restype = scalar[ret]
+        declared.add(name)
+    handle._zs3_declared = declared
+    if missing:   # a library built from another header (ZS3_LIB A/B builds): its calls would be marshalled wrongly
+        raise Zs3HipError(f"{LIB_PATH} does not export {', '.join(missing[:5])} declared in {header}: header and library differ")
 
 
 def lib():

@@ -320,273 +320,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Wave-specialised 256x128x32 variant for launches with many row tiles (512 threads, one block per CU):
-// waves 0-3 are *consumers* (2x2 grid of 128x64 wave tiles: ds_read_b128 fragments + MFMA only, and the
-// epilogue), waves 4-7 are *producers* (global loads two K steps ahead, bf16 hi/lo split, LDS writes).  One
-// consumer and one producer share each SIMD, so the matrix pipe and the VALU / VMEM / LDS-write pipes work at
-// the same time instead of alternating inside every wave.  Per K step the block moves 48 KB from L2 for
-// 2*256*128*32 MACs (vs 64 KB with two 128x128 blocks) and each LDS fragment feeds 1.5x more MFMAs.
-template <int PREC>
-__global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const ConvArgs p) {
-  constexpr int BM = 256, BN = 128, ROW = 72, TM = 4, TN = 2;
-  constexpr int STAGE = (BM + BN) * ROW;
-  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool producer = tid >= 256;
-  const int ntn = (p.ncols + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = bid / ntn, nt = bid - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int KT = p.KH * p.KW * (p.cin_pad / 32);
-  const int wm = (wave & 3) >> 1, wn = wave & 1;
-
-  f32x16 acc[TM][TN];
-
-  if (producer) {
-    const int pt = tid - 256;
-    const int q = pt & 7, tg = pt >> 3;
-    const int srow = (tg & ~5) | ((tg & 1) << 2) | ((tg >> 2) & 1);
-    constexpr int RA = BM / 32, RB = BN / 32;
-    const float* xrow[RA];
-    int bh[RA], bw[RA];
-    bool rvalid[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int m = m0 + srow + 32 * i;
-      rvalid[i] = m < p.M;
-      int mm = rvalid[i] ? m : 0;
-      int hw = p.Ho * p.Wo;
-      int n = mm / hw, rem = mm - n * hw;
-      int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-      xrow[i] = p.x + (size_t)n * p.H * p.W * p.ldx;
-      if (p.dgrad) {
-        bh[i] = oh + p.pad_h;
-        bw[i] = ow + p.pad_w;
-      } else {
-        bh[i] = oh * p.stride - p.pad_h;
-        bw[i] = ow * p.stride - p.pad_w;
-      }
-    }
-    const unsigned short* wrow[RB];
-    int wstep[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      int col = n0 + srow + 32 * j;
-      bool ok = col < p.ncols;
-      wrow[j] = ok ? p.w_pk + (size_t)col * (2 * p.ldw) + q * 8 : reinterpret_cast<const unsigned short*>(p.zero);
-      wstep[j] = ok ? 1 : 0;
-    }
-    struct Stage {
-      f32x4 areg[RA];
-      u32x4 breg[RB];
-    };
-    int kh = 0, kw = 0, c0 = 0, kofs = 0;
-    const float* abase[RA];
-    int astep[RA];
-    auto load_tile = [&](Stage& S) {
-      if (c0 == 0) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          int hi, wi;
-          bool ok = rvalid[i];
-          if (p.dgrad) {
-            const int th = bh[i] - kh * p.dil, tw = bw[i] - kw * p.dil;
-            const int mask = (1 << p.stride_log2) - 1;
-            hi = th >> p.stride_log2;
-            wi = tw >> p.stride_log2;
-            ok = ok && ((th | tw) >= 0) && (((th | tw) & mask) == 0);
-          } else {
-            hi = bh[i] + kh * p.dil;
-            wi = bw[i] + kw * p.dil;
-            ok = ok && ((hi | wi) >= 0);
-          }
-          ok = ok && hi < p.H && wi < p.W;
-          abase[i] = ok ? xrow[i] + ((hi * p.W + wi) * p.ldx + q * 4) : p.zero;
-          astep[i] = ok ? 1 : 0;
-        }
-      }
-      const bool cok = c0 + q * 4 < p.cin_valid;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const float* ptr = cok ? abase[i] + c0 * astep[i] : p.zero;
-        S.areg[i] = *reinterpret_cast<const f32x4*>(ptr);
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j) S.breg[j] = *reinterpret_cast<const u32x4*>(wrow[j] + 2 * kofs * wstep[j]);
-    };
-    auto advance = [&]() {
-      kofs += 32;
-      c0 += 32;
-      if (c0 == p.cin_pad) {
-        c0 = 0;
-        if (++kw == p.KW) {
-          kw = 0;
-          ++kh;
-        }
-      }
-    };
-    auto store_tile = [&](Stage& S, int stage) {
-      unsigned short* As = smem + stage * STAGE;
-      unsigned short* Bs = As + BM * ROW;
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        u32x2 hi, lo;
-        unsigned h, l;
-        split_pair<PREC>(S.areg[i][0], S.areg[i][1], h, l); hi[0] = h; lo[0] = l;
-        split_pair<PREC>(S.areg[i][2], S.areg[i][3], h, l); hi[1] = h; lo[1] = l;
-        unsigned short* dst = As + (srow + 32 * i) * ROW + q * 4;
-        *reinterpret_cast<u32x2*>(dst) = hi;
-        if (PREC == 3) *reinterpret_cast<u32x2*>(dst + 32) = lo;
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j)
-        *reinterpret_cast<u32x4*>(Bs + (srow + 32 * j) * ROW + (q & 3) * 8 + (q >> 2) * 32) = S.breg[j];
-    };
-
-    Stage s0, s1;
-    load_tile(s0);
-    if (KT > 1) {
-      advance();
-      load_tile(s1);
-    }
-    store_tile(s0, 0);
-    if (KT > 2) {
-      advance();
-      load_tile(s0);
-    }
-    __syncthreads();  // stage 0 is ready
-    int kt = 0;
-    for (; kt + 1 < KT; kt += 2) {
-      store_tile(s1, 1);   // consumers multiply stage 0 (tile kt) meanwhile
-      if (kt + 3 < KT) {
-        advance();
-        load_tile(s1);
-      }
-      __syncthreads();
-      if (kt + 2 < KT) store_tile(s0, 0);
-      if (kt + 4 < KT) {
-        advance();
-        load_tile(s0);
-      }
-      __syncthreads();
-    }
-    if (kt < KT) __syncthreads();
-  } else {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto compute = [&](int stage) {
-      const unsigned short* As = smem + stage * STAGE + (wm * (BM / 2) + (lane & 31)) * ROW + (lane >> 5) * 8;
-      const unsigned short* Bs = smem + stage * STAGE + BM * ROW + (wn * (BN / 2) + (lane & 31)) * ROW + (lane >> 5) * 8;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        // B fragments stay resident for the whole K16 step; A fragments are streamed one 32-row tile at a time
-        // (keeps the consumer at ~170 VGPRs: 128 accumulators + 16 B + 2 x 8 A)
-        bf16x8 b_hi[TN], b_lo[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          b_hi[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROW + kk * 16);
-          if (PREC == 3) b_lo[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROW + kk * 16 + 32);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROW + kk * 16);
-          bf16x8 a_lo;
-          if (PREC == 3) {
-            a_lo = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROW + kk * 16 + 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo[j], acc[i][j], 0, 0, 0);
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    };
-    __syncthreads();  // stage 0 is ready
-    for (int kt = 0; kt < KT; ++kt) {  // one body, LDS stage selected at run time: a single accumulator assignment
-      compute(kt & 1);
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue (consumers hold the accumulators; producers take part in the barriers and in the row stores)
-  if (p.stat_partial) {
-    float* red = reinterpret_cast<float*>(smem);
-    if (!producer) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float s = 0.f, q2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[i][j][r];
-            s += v;
-            q2 = fmaf(v, v, q2);
-          }
-        s += __shfl_xor(s, 32, 64);
-        q2 += __shfl_xor(q2, 32, 64);
-        if (lane < 32) {
-          red[(wm * 2 + 0) * BN + wn * (BN / 2) + j * 32 + lane] = s;
-          red[(wm * 2 + 1) * BN + wn * (BN / 2) + j * 32 + lane] = q2;
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      int col = n0 + tid;
-      if (col < p.ncols) {
-        p.stat_partial[((size_t)mt * 2 + 0) * p.ncols + col] = red[tid] + red[2 * BN + tid];
-        p.stat_partial[((size_t)mt * 2 + 1) * p.ncols + col] = red[BN + tid] + red[3 * BN + tid];
-      }
-    }
-  }
-  constexpr int LDC = BN + 4;
-  static_assert((BM / 2) * LDC * 4 <= 2 * STAGE * 2, "half output tile must fit in the operand LDS");
-  float* ctile = reinterpret_cast<float*>(smem);
-  const bool affine = (p.scale != nullptr) || (p.shift != nullptr);
-  constexpr int C4 = BN / 4, RPP = 512 / C4;
-  const int c4 = tid % C4, r0 = tid / C4;
-  const int col = n0 + c4 * 4;
-  const bool vec = ((p.ldy & 3) == 0) && ((p.ncols & 3) == 0) && (!p.res || (p.ldr & 3) == 0);
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (col + e < p.ncols) {
-      if (p.scale) sc[e] = p.scale[col + e];
-      if (p.shift) sh[e] = p.shift[col + e];
-    }
-  f32x4 bs_s = {0.f, 0.f, 0.f, 0.f}, bs_q = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-    if (!producer && wm == half) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            ctile[row * LDC + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
-          }
-    }
-    __syncthreads();
-    store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
-  }
-  if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
-}
-
-// ------------------------------------------------------------------------------------------------
 // LDS-DMA variant of the wave-specialised 256x128x32 kernel (tile_cfg 31).
 //
 // Producers (waves 4-7) never touch the data: every tile row is fetched with global_load_lds_dwordx4, which
@@ -1196,16 +929,6 @@ int launch_dma_sk(ConvArgs a, int prec, hipStream_t st) {
   return prec == 1 ? launch_dma_prec<1, true>(a, SK_GRID, st) : launch_dma_prec<3, true>(a, SK_GRID, st);
 }
 
-int launch_ws(const ConvArgs& a, int prec, hipStream_t st) {
-  int mt = (a.M + 255) / 256, nt = (a.ncols + 127) / 128;
-  dim3 grid(mt * nt), block(512);
-  if (prec == 1)
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<1>), grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<3>), grid, block, 0, st, a);
-  return ZS3_LAUNCH_CHECK();
-}
-
 template <int BM, int BN, int PIPE>
 int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   int mt = (a.M + BM - 1) / BM, nt = (a.ncols + BN - 1) / BN;
@@ -1240,7 +963,7 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
     if (blocks < 512) bm = 64;
   } else {
     int t = tile_cfg % 10;
-    bm = (tile_cfg == 21 || tile_cfg == 31 || tile_cfg == 32 || tile_cfg == 41) ? 256
+    bm = (tile_cfg == 31 || tile_cfg == 32 || tile_cfg == 41) ? 256
          : tile_cfg == 42 ? 192 : ((t == 3 || t == 4) ? 64 : 128);
   }
   return (M + bm - 1) / bm;
@@ -1291,7 +1014,6 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 12: return launch_cfg<128, 64, 2>(a, prec, st);
     case 13: return launch_cfg<64, 128, 2>(a, prec, st);
     case 14: return launch_cfg<64, 64, 2>(a, prec, st);
-    case 21: return launch_ws(a, prec, st);
     case 31: return launch_dma(a, prec, st);
     case 32: return launch_dma_sk(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)

@@ -444,241 +444,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(const WgradArgs p) 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Shared-conversion variant of the LDS-DMA kernel (kernel 3 of zs3_conv_wgrad; same tiles, same DMA ring discipline).
-//
-// In conv_wgrad_dma_kernel every wave gathers and splits its own operand fragments from the raw fp32 tile: with 128(co) x
-// 64(ci) wave tiles each dy value is converted by four waves and each x value by two -- 24576 conversions per K step for
-// 8192 values, ~6 VALU per MFMA, and the K loop is VALU-issue-bound (43 % MFMA).  Here a K step's 512 x 16 values are
-// converted ONCE: wave w takes the 32 dy channels and the 32 x channels of fragment w (lane = channel, lane half = 8 of the 16
-// pixels: the same conflict-free ds_read_b32 gather as before), splits them into bf16 hi/lo and stores them in MFMA fragment
-// order ([plane][fragment][lane] x 16 B, one ds_write_b128 per plane) into a second LDS buffer; every wave then reads the
-// six fragments it multiplies with ds_read_b128 (contiguous 1 KB per fragment: conflict-free).  Per wave and K step:
-// 48 VALU + 16 ds_read_b32 + 4 ds_write_b128 + 12 ds_read_b128 for 24 MFMAs -- the conversion of step t+1 sits in the
-// shadow of the MFMAs of step t, one barrier per step publishes it.  LDS: 3-slot raw ring (96 KB; tile t+1 is being
-// converted while t+2 and t+3 are in flight) + 2 x 32 KB converted operands = the CU's whole 160 KB.
-template <int PREC>
-__global__ __launch_bounds__(512) void conv_wgrad_cv_kernel(const WgradArgs p) {
-  constexpr int BC = 256, BD = 256, KPIX = 16, NR = 3;
-  constexpr int PART = KPIX * 1024, STAGE_BYTES = 2 * PART;   // raw slot: 16 dy rows then 16 x rows, 1 KB per pixel
-  constexpr int CV_PLANE = 16 * 1024;                         // one plane (hi or lo) of 8 dy + 8 x fragments, 1 KB each
-  constexpr int CV_BYTES = 2 * CV_PLANE, CV_BASE = NR * STAGE_BYTES;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_ci = (p.ci_write + BD - 1) / BD, tiles_co = (p.co_write + BC - 1) / BC;
-  const int ntiles = tiles_ci * tiles_co * p.KH * p.KW;
-  int b = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = b / ntiles;
-  b -= split * ntiles;
-  const int tci = b % tiles_ci; b /= tiles_ci;
-  const int tco = b % tiles_co; b /= tiles_co;
-  const int tap = b;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int co0 = tco * BC, ci0 = tci * BD;
-  const int m_begin = split * p.chunk;
-  const int m_end = min(p.M, m_begin + p.chunk);
-  const int KT = (m_end - m_begin + KPIX - 1) / KPIX;
-
-  // ---- loader state (as in conv_wgrad_dma_kernel): this wave fetches rows 2 wave, 2 wave + 1 of both parts of every tile
-  const bool a_cok = co0 + lane * 4 < p.co_read;
-  const bool b_cok = ci0 + lane * 4 < p.ci_read;
-  const int tap_h = kh * p.dil - p.pad_h, tap_w = kw * p.dil - p.pad_w;
-  int pm[2], pn[2], poh[2], pow_[2];
-  {
-    const int hw = p.Ho * p.Wo;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int m = m_begin + 2 * wave + r;
-      pm[r] = m;
-      int mm = m < p.M ? m : 0;
-      pn[r] = mm / hw;
-      int rem = mm - pn[r] * hw;
-      poh[r] = rem / p.Wo;
-      pow_[r] = rem - poh[r] * p.Wo;
-    }
-  }
-  const unsigned long zaddr = (unsigned long)p.zero;
-  const unsigned lane16 = lane * 16;
-  const long lane_a = a_cok ? -1L : 0L, lane_b = b_cok ? -1L : 0L;
-  auto issue_row = [&](int slot, int r) {
-    unsigned char* sA = dsm + slot * STAGE_BYTES + wave * 2048 + r * 1024;
-    const int in = (pm[r] - m_end) >> 31;
-    const unsigned long ga = (unsigned long)(p.dy + (size_t)pm[r] * p.lddy + co0) + lane16;
-    const unsigned long pa = zaddr + ((ga - zaddr) & (unsigned long)((long)in & lane_a));
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)pa, (lds_void_t*)sA, 16, 0, 0);
-    const int hi = poh[r] * p.stride + tap_h, wi = pow_[r] * p.stride + tap_w;
-    const int rok = in & ~((hi | wi) >> 31) & ((hi - p.H) >> 31) & ((wi - p.W) >> 31);
-    const int hic = hi & rok, wic = wi & rok;
-    const unsigned long gb = (unsigned long)(p.x + (((size_t)pn[r] * p.H + hic) * p.W + wic) * p.ldx + ci0) + lane16;
-    const unsigned long pb = zaddr + ((gb - zaddr) & (unsigned long)((long)rok & lane_b));
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)pb, (lds_void_t*)(sA + PART), 16, 0, 0);
-    pm[r] += KPIX;
-    pow_[r] += KPIX;
-    const int cw = (p.Wo - 1 - pow_[r]) >> 31;
-    pow_[r] -= p.Wo & cw;
-    poh[r] -= cw;
-    const int ch = (p.Ho - 1 - poh[r]) >> 31;
-    poh[r] -= p.Ho & ch;
-    pn[r] -= ch;
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int wco = wave >> 2, wci = wave & 3;
-  const int c = lane & 31, h = lane >> 5;
-  // converter role: fragment `wave` of dy and of x -- channel 32 wave + c, pixels 8h..8h+7 of a raw slot
-  const int rawA = (8 * h) * 1024 + (32 * wave + c) * 4;
-  const int rawB = PART + rawA;
-  // fragment f of dy sits at f KB, fragment f of x at (8 + f) KB of a plane; lane l at l * 16 (= (h * 32 + c) * 16)
-  const int cvw = lane * 16;
-  float raw1[8], raw2[8];
-  float t_ha = 0.f, t_hb = 0.f;
-  u32x4 ca_hi, ca_lo, cb_hi, cb_lo;
-  auto read_raw = [&](float (&raw)[8], const unsigned char* base) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) raw[e] = *reinterpret_cast<const float*>(base + e * 1024);
-  };
-  auto split_half = [&](const float (&raw)[8], u32x4& hi, u32x4& lo, int hp) {   // hp = 2*q + phase
-    const int q = hp >> 1;
-    if ((hp & 1) == 0) {
-      const unsigned hw = cvt_pk_bf16(raw[2 * q], raw[2 * q + 1]);
-      hi[q] = hw;
-      t_ha = __uint_as_float(hw << 16);
-      t_hb = __uint_as_float(hw & 0xFFFF0000u);
-    } else {
-      lo[q] = PREC == 3 ? cvt_pk_bf16(raw[2 * q] - t_ha, raw[2 * q + 1] - t_hb) : 0u;
-    }
-  };
-  auto store_cv = [&](unsigned char* cv) {
-    *reinterpret_cast<u32x4*>(cv + wave * 1024 + cvw) = ca_hi;
-    *reinterpret_cast<u32x4*>(cv + (8 + wave) * 1024 + cvw) = cb_hi;
-    if (PREC == 3) {
-      *reinterpret_cast<u32x4*>(cv + CV_PLANE + wave * 1024 + cvw) = ca_lo;
-      *reinterpret_cast<u32x4*>(cv + CV_PLANE + (8 + wave) * 1024 + cvw) = cb_lo;
-    }
-  };
-
-  // ---- prologue: tiles 0..2 in flight; tile 0 converted; tile 1 landed
-#pragma unroll
-  for (int t = 0; t < NR; ++t)
-#pragma unroll
-    for (int r = 0; r < 2; ++r) issue_row(t, r);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // tile 0 (this wave's 4 loads) has landed
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  read_raw(raw1, dsm + rawA);
-  read_raw(raw2, dsm + rawB);
-#pragma unroll
-  for (int hp = 0; hp < 8; ++hp) {
-    split_half(raw1, ca_hi, ca_lo, hp);
-  }
-#pragma unroll
-  for (int hp = 0; hp < 8; ++hp) {
-    split_half(raw2, cb_hi, cb_lo, hp);
-  }
-  store_cv(dsm + CV_BASE);
-  asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // tile 1 landed, converted tile 0 written
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  // ---- K step t: 24 MFMAs on converted tile t; in their shadow: the conversion of raw tile t+1 into the other converted
-  // buffer, and the DMA issue of tile t+3 into the raw slot tile t was converted from
-  int rs1 = 1, rs0 = 0;   // raw slot of tile t+1 (being converted) / of tile t (free: refilled with tile t+3)
-  for (int kt = 0; kt < KT; ++kt) {
-    const unsigned char* cv = dsm + CV_BASE + (kt & 1) * CV_BYTES;
-    unsigned char* cvn = dsm + CV_BASE + ((kt + 1) & 1) * CV_BYTES;
-    const unsigned char* rawn = dsm + rs1 * STAGE_BYTES;
-    bf16x8 a_hi[4], a_lo[4], b_hi[2], b_lo[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a_hi[i] = *reinterpret_cast<const bf16x8*>(cv + (4 * wco + i) * 1024 + cvw);
-      if (PREC == 3) a_lo[i] = *reinterpret_cast<const bf16x8*>(cv + CV_PLANE + (4 * wco + i) * 1024 + cvw);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      b_hi[j] = *reinterpret_cast<const bf16x8*>(cv + (8 + 2 * wci + j) * 1024 + cvw);
-      if (PREC == 3) b_lo[j] = *reinterpret_cast<const bf16x8*>(cv + CV_PLANE + (8 + 2 * wci + j) * 1024 + cvw);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int g = (PREC == 3 ? 0 : 4); g < 6; ++g) {
-        const int t = g >> 1, j = g & 1;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? a_lo[i] : a_hi[i], t == 1 ? b_lo[j] : b_hi[j], acc[i][j],
-                                                            0, 0, 0);
-        const int slot = i * 6 + g;   // 0..23 (PREC 1: 8 of them)
-        // fillers: gather raw tile t+1 (slots 0/1), DMA issue of tile t+3 (slots 2/3), split (slots 6..21), store (slot 22)
-        if (slot == (PREC == 3 ? 0 : 4)) read_raw(raw1, rawn + rawA);
-        if (slot == (PREC == 3 ? 1 : 5)) read_raw(raw2, rawn + rawB);
-        if (PREC == 3) {
-          if (slot == 2) issue_row(rs0, 0);
-          if (slot == 3) issue_row(rs0, 1);
-          if (slot >= 6 && slot < 14) split_half(raw1, ca_hi, ca_lo, slot - 6);
-          if (slot >= 14 && slot < 22) split_half(raw2, cb_hi, cb_lo, slot - 14);
-          if (slot == 22) store_cv(cvn);
-        } else {
-          if (slot == 10) issue_row(rs0, 0);
-          if (slot == 11) issue_row(rs0, 1);
-          if (slot == 16) {
-#pragma unroll
-            for (int hp = 0; hp < 8; ++hp) split_half(raw1, ca_hi, ca_lo, hp);
-          }
-          if (slot == 17) {
-#pragma unroll
-            for (int hp = 0; hp < 8; ++hp) split_half(raw2, cb_hi, cb_lo, hp);
-          }
-          if (slot == 22) store_cv(cvn);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // tile kt+2 must have landed (it is converted during step kt+1) and converted tile kt+1 must be complete before anybody
-    // starts step kt+1; tile kt+3 stays in flight
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    rs0 = rs1;
-    rs1 = rs1 == NR - 1 ? 0 : rs1 + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (masked) row loads must land before the LDS is released
-
-  float* out = p.dw + (size_t)split * p.slab;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ci = ci0 + wci * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wco * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < p.co_write && ci < p.ci_write) out[(size_t)co * p.ldw + (size_t)tap * p.cin_w + ci] = acc[i][j][r];
-      }
-    }
-}
-
-template <int PREC>
-int launch_wgrad_cv_prec(const WgradArgs& a, int taps, int splitk, hipStream_t st) {
-  constexpr int LDS_BYTES = 3 * 2 * 16 * 1024 + 2 * 2 * 16 * 1024;   // 96 KB raw ring + 64 KB converted operands = 160 KB
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_cv_kernel<PREC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-      return -4;
-    configured = true;
-  }
-  int tiles = ((a.co_write + 255) / 256) * ((a.ci_write + 255) / 256) * taps;
-  hipLaunchKernelGGL((conv_wgrad_cv_kernel<PREC>), dim3(tiles * splitk), dim3(512), LDS_BYTES, st, a);
-  return ZS3_LAUNCH_CHECK();
-}
-
 template <int PREC>
 int launch_wgrad_dma_prec(const WgradArgs& a, int taps, int splitk, hipStream_t st) {
   constexpr int LDS_BYTES = 4 * 2 * 16 * 1024;   // 128 KB ring
@@ -849,19 +614,7 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
     WgradArgs d = a;
     d.ci_write = wd;
     d.ci_read = ci_read < wd ? ci_read : wd;
-    // ZS3_WGRAD_CV=1: the shared-conversion kernel.  Parity-green (tests run both), but measured 5-12 % SLOWER than the
-    // per-wave-conversion kernel on every layer (decoder 3x3 256->256: 1795 vs 1575 us; whole step 52.6 vs 52.35 ms): the
-    // conversion VALU work was not what bounds the K loop, and the converted operands' extra LDS round trip + the fragment
-    // reads exposed at the top of every K step cost more than the 3x fewer conversions save.  Kept as the measured experiment.
-    static int use_cv = -1;
-    if (use_cv < 0) {
-      const char* e = getenv("ZS3_WGRAD_CV");
-      use_cv = e ? atoi(e) : 0;
-    }
-    if (use_cv)
-      rc = prec == 1 ? launch_wgrad_cv_prec<1>(d, taps, splitk, st) : launch_wgrad_cv_prec<3>(d, taps, splitk, st);
-    else
-      rc = prec == 1 ? launch_wgrad_dma_prec<1>(d, taps, splitk, st) : launch_wgrad_dma_prec<3>(d, taps, splitk, st);
+    rc = prec == 1 ? launch_wgrad_dma_prec<1>(d, taps, splitk, st) : launch_wgrad_dma_prec<3>(d, taps, splitk, st);
     if (rc) return rc;
   }
   if (wd < ci_write) {   // remaining (or all) input channels: register-staged kernel, same slabs and pixel chunks

@@ -354,297 +354,3 @@ extern "C" int zs3_argmax_confusion(const float* x, int ldx, int N, int H, int W
                        (const float*)target, (unsigned long long*)conf);
   return ZS3_LAUNCH_CHECK();
 }
-
-// ---------------------------------------------------------------------------------- fused CE backward + upsample backward
-// The training step ends in  logits [N,H,W,C] --bilinear, align_corners--> [N,Ho,Wo,C] --weighted CE--> loss
-// (deeplab.py:44,55 + loss.py:31-46).  Unfused, the backward writes the full-resolution gradient (354 MB at B=16, 513^2, 21
-// classes) and gathers it back to H x W.  Here one thread owns one LOW-resolution pixel: for every output pixel whose bilinear
-// footprint contains it (<= 7 x 7 at the 4x upsample) it re-samples the C scores from the four taps (the arithmetic of
-// bilinear_fwd_kernel), takes the softmax, and accumulates  wt * w[t] * coef * (p_c - [c == t])  in the candidate order of
-// bilinear_bwd_kernel.  25 MB of low-resolution logits and the label map are all it reads; the full-resolution gradient never
-// exists.  CPAD >= C is the compile-time register footprint (24 for the 21 VOC classes, 64 for the 60 of Pascal-Context).
-template <typename TT, int CPAD, bool VEC>
-__global__ __launch_bounds__(128) void ce_bilinear_bwd_kernel(const ResizeArgs p, const TT* target, const float* weight,
-                                                             int ignore_index, const float* loss_ws, const float* gout,
-                                                             float inv_batch) {
-  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= (long)p.N * p.H * p.W) return;
-  const int w = (int)(m % p.W);
-  const long r = m / p.W;
-  const int h = (int)(r % p.H), n = (int)(r / p.H);
-  const float coef = gout[0] * inv_batch / loss_ws[1];
-  int olo, ohi, wlo, whi;
-  cand_range(h, p.sh, p.Ho, olo, ohi);
-  cand_range(w, p.sw, p.Wo, wlo, whi);
-  float acc[CPAD];
-#pragma unroll
-  for (int c = 0; c < CPAD; ++c) acc[c] = 0.f;
-  const float* b = p.x + (long)n * p.H * p.W * p.ldx;
-  const TT* tg = target + (long)n * p.Ho * p.Wo;
-  for (int oh = olo; oh <= ohi; ++oh) {
-    int h0, h1;
-    float lh;
-    src_index(oh, p.sh, p.H, h0, h1, lh);
-    const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
-    if (wh == 0.f) continue;
-    for (int ow = wlo; ow <= whi; ++ow) {
-      int w0, w1;
-      float lw;
-      src_index(ow, p.sw, p.W, w0, w1, lw);
-      const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
-      if (ww == 0.f) continue;
-      const int t = (int)(long)tg[(long)oh * p.Wo + ow];
-      if (t == ignore_index || t < 0 || t >= p.C) continue;   // ignored pixels carry no gradient
-      const float wt = wh * ww;
-      const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
-      const float* q00 = b + ((long)h0 * p.W + w0) * p.ldx;
-      const float* q01 = b + ((long)h0 * p.W + w1) * p.ldx;
-      const float* q10 = b + ((long)h1 * p.W + w0) * p.ldx;
-      const float* q11 = b + ((long)h1 * p.W + w1) * p.ldx;
-      float z[CPAD];
-      if (VEC) {   // ldx >= CPAD, 16-byte aligned rows: whole float4s (lanes past C are never used)
-#pragma unroll
-        for (int c = 0; c < CPAD; c += 4) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(q00 + c), bb = *reinterpret_cast<const f32x4*>(q01 + c),
-                      cc = *reinterpret_cast<const f32x4*>(q10 + c), d = *reinterpret_cast<const f32x4*>(q11 + c);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) z[c + e] = bilerp(w00, w01, w10, w11, a[e], bb[e], cc[e], d[e]);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < CPAD; ++c) z[c] = c < p.C ? bilerp(w00, w01, w10, w11, q00[c], q01[c], q10[c], q11[c]) : 0.f;
-      }
-      float mx = z[0];
-#pragma unroll
-      for (int c = 1; c < CPAD; ++c)
-        if (c < p.C) mx = fmaxf(mx, z[c]);
-      float se = 0.f;
-#pragma unroll
-      for (int c = 0; c < CPAD; ++c)
-        if (c < p.C) {
-          z[c] = expf(z[c] - mx);
-          se += z[c];
-        }
-      const float inv = 1.f / se, wc = (weight ? weight[t] : 1.f) * coef;
-#pragma unroll
-      for (int c = 0; c < CPAD; ++c)
-        if (c < p.C) acc[c] += wt * (wc * (z[c] * inv - (c == t ? 1.f : 0.f)));
-    }
-  }
-  float* dst = p.out + m * p.ldo;
-#pragma unroll
-  for (int c = 0; c < CPAD; ++c)
-    if (c < p.C) dst[c] = acc[c];
-}
-
-// Tiled form of the above (the one that is launched whenever its LDS budget allows): the per-thread form recomputes every
-// output pixel's softmax in up to 49 threads -- 1.7 ms at B=16, 513^2, three times the two kernels it replaces.  Here a
-// workgroup owns TILE x TILE low-resolution pixels.  Phase 1: the softmax gradient dz of every output pixel that touches the
-// tile (the tile's 4x footprint plus the bilinear halo) is computed ONCE into LDS.  Phase 2: thread (pixel, class group)
-// gathers its <= 7 x 7 contributions from LDS in bilinear_bwd_kernel's order.  Halo overhead 1.4x at TILE = 8.
-constexpr int CEB_MAXCAND = 12;   // candidate output rows / columns per low-resolution pixel the gather loop is unrolled for
-template <typename TT, int CPAD, int TILE>
-__global__ __launch_bounds__(256) void ce_bilinear_bwd_tiled_kernel(const ResizeArgs p, const TT* target, const float* weight,
-                                                                   int ignore_index, const float* loss_ws, const float* gout,
-                                                                   float inv_batch, int tiles_h, int tiles_w, int vec) {
-  extern __shared__ float dzs[];   // [region pixel][C]
-  constexpr int GROUPS = 256 / (TILE * TILE), CG = (CPAD + GROUPS - 1) / GROUPS;
-  const int tid = threadIdx.x;
-  const int tw = blockIdx.x % tiles_w, th = (blockIdx.x / tiles_w) % tiles_h, n = blockIdx.x / (tiles_w * tiles_h);
-  const int h_a = th * TILE, w_a = tw * TILE;
-  const int h_b = min(h_a + TILE - 1, p.H - 1), w_b = min(w_a + TILE - 1, p.W - 1);
-  int olo, ohi, wlo, whi, tmp;
-  cand_range(h_a, p.sh, p.Ho, olo, tmp);
-  cand_range(h_b, p.sh, p.Ho, tmp, ohi);
-  cand_range(w_a, p.sw, p.Wo, wlo, tmp);
-  cand_range(w_b, p.sw, p.Wo, tmp, whi);
-  const int RW = whi - wlo + 1, R = (ohi - olo + 1) * RW;
-  const float coef = gout[0] * inv_batch / loss_ws[1];
-  const float* b = p.x + (long)n * p.H * p.W * p.ldx;
-  const TT* tg = target + (long)n * p.Ho * p.Wo;
-  for (int i = tid; i < R; i += 256) {
-    const int oh = olo + i / RW, ow = wlo + i % RW;
-    float* out = dzs + (size_t)i * p.C;
-    const int t = (int)(long)tg[(long)oh * p.Wo + ow];
-    if (t == ignore_index || t < 0 || t >= p.C) {
-      for (int c = 0; c < p.C; ++c) out[c] = 0.f;
-      continue;
-    }
-    int h0, h1, w0, w1;
-    float lh, lw;
-    src_index(oh, p.sh, p.H, h0, h1, lh);
-    src_index(ow, p.sw, p.W, w0, w1, lw);
-    const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
-    const float* q00 = b + ((long)h0 * p.W + w0) * p.ldx;
-    const float* q01 = b + ((long)h0 * p.W + w1) * p.ldx;
-    const float* q10 = b + ((long)h1 * p.W + w0) * p.ldx;
-    const float* q11 = b + ((long)h1 * p.W + w1) * p.ldx;
-    float z[CPAD];
-    if (vec) {
-#pragma unroll
-      for (int c = 0; c < CPAD; c += 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(q00 + c), bb = *reinterpret_cast<const f32x4*>(q01 + c),
-                    cc = *reinterpret_cast<const f32x4*>(q10 + c), d = *reinterpret_cast<const f32x4*>(q11 + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) z[c + e] = bilerp(w00, w01, w10, w11, a[e], bb[e], cc[e], d[e]);
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < CPAD; ++c) z[c] = c < p.C ? bilerp(w00, w01, w10, w11, q00[c], q01[c], q10[c], q11[c]) : 0.f;
-    }
-    float mx = z[0];
-#pragma unroll
-    for (int c = 1; c < CPAD; ++c)
-      if (c < p.C) mx = fmaxf(mx, z[c]);
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < CPAD; ++c)
-      if (c < p.C) {
-        z[c] = expf(z[c] - mx);
-        se += z[c];
-      }
-    const float inv = 1.f / se, wc = (weight ? weight[t] : 1.f) * coef;
-#pragma unroll
-    for (int c = 0; c < CPAD; ++c)
-      if (c < p.C) out[c] = wc * (z[c] * inv - (c == t ? 1.f : 0.f));
-  }
-  __syncthreads();
-  const int li = tid / GROUPS, g = tid - li * GROUPS;
-  const int h = h_a + li / TILE, w = w_a + li % TILE;
-  if (h > h_b || w > w_b) return;
-  int o0, o1, c0, c1;
-  cand_range(h, p.sh, p.Ho, o0, o1);
-  cand_range(w, p.sw, p.Wo, c0, c1);
-  float wwv[CEB_MAXCAND];
-#pragma unroll
-  for (int j = 0; j < CEB_MAXCAND; ++j) {
-    const int ow = c0 + j;
-    int w0, w1;
-    float lw;
-    src_index(ow <= c1 ? ow : c1, p.sw, p.W, w0, w1, lw);
-    wwv[j] = ow <= c1 ? (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f) : 0.f;
-  }
-  float acc[CG];
-#pragma unroll
-  for (int k = 0; k < CG; ++k) acc[k] = 0.f;
-  for (int oh = o0; oh <= o1; ++oh) {
-    int h0, h1;
-    float lh;
-    src_index(oh, p.sh, p.H, h0, h1, lh);
-    const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
-    if (wh == 0.f) continue;
-    const float* row = dzs + ((size_t)(oh - olo) * RW + (c0 - wlo)) * p.C + g;
-#pragma unroll
-    for (int j = 0; j < CEB_MAXCAND; ++j) {
-      if (wwv[j] == 0.f) continue;
-      const float wt = wh * wwv[j];
-      const float* src = row + (size_t)j * p.C;
-#pragma unroll
-      for (int k = 0; k < CG; ++k)
-        if (g + GROUPS * k < p.C) acc[k] += wt * src[GROUPS * k];
-    }
-  }
-  float* dst = p.out + (((long)n * p.H + h) * p.W + w) * p.ldo + g;
-#pragma unroll
-  for (int k = 0; k < CG; ++k)
-    if (g + GROUPS * k < p.C) dst[GROUPS * k] = acc[k];
-}
-
-// host twin of cand_range (same fp32 arithmetic)
-static void cand_range_host(int i, float scale, int out_n, int& lo, int& hi) {
-  if (scale <= 0.f) {
-    lo = 0;
-    hi = out_n - 1;
-    return;
-  }
-  lo = (int)floorf((float)(i - 1) / scale) - 1;
-  hi = (int)ceilf((float)(i + 1) / scale) + 1;
-  if (lo < 0) lo = 0;
-  if (hi > out_n - 1) hi = out_n - 1;
-}
-
-// largest region (output pixels) any TILE x TILE workgroup has to hold, and the largest candidate count per pixel and axis
-static void ceb_extent(const ResizeArgs& a, int tile, long& region, int& cand) {
-  int max_rh = 0, max_rw = 0;
-  cand = 0;
-  for (int axis = 0; axis < 2; ++axis) {
-    const int in_n = axis ? a.W : a.H, out_n = axis ? a.Wo : a.Ho;
-    const float sc = axis ? a.sw : a.sh;
-    int best = 0;
-    for (int t0 = 0; t0 < in_n; t0 += tile) {
-      int lo, hi, tmp;
-      cand_range_host(t0, sc, out_n, lo, tmp);
-      cand_range_host(t0 + tile - 1 < in_n - 1 ? t0 + tile - 1 : in_n - 1, sc, out_n, tmp, hi);
-      if (hi - lo + 1 > best) best = hi - lo + 1;
-    }
-    for (int i = 0; i < in_n; ++i) {
-      int lo, hi;
-      cand_range_host(i, sc, out_n, lo, hi);
-      if (hi - lo + 1 > cand) cand = hi - lo + 1;
-    }
-    (axis ? max_rw : max_rh) = best;
-  }
-  region = (long)max_rh * max_rw;
-}
-
-template <typename TT, int CPAD, int TILE>
-static int launch_ceb_tiled(const ResizeArgs& a, const void* target, const float* weight, int ignore_index, const float* loss_ws,
-                            const float* gout, float inv_batch, size_t lds, int vec, hipStream_t st) {
-  auto kern = ce_bilinear_bwd_tiled_kernel<TT, CPAD, TILE>;
-  static size_t configured = 0;
-  if (lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return -4;
-    configured = lds;
-  }
-  const int tiles_h = (a.H + TILE - 1) / TILE, tiles_w = (a.W + TILE - 1) / TILE;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * tiles_h * tiles_w)), dim3(256), lds, st, a, (const TT*)target, weight, ignore_index,
-                     loss_ws, gout, inv_batch, tiles_h, tiles_w, vec);
-  return ZS3_LAUNCH_CHECK();
-}
-
-template <typename TT>
-static int launch_ce_bilinear_bwd(const ResizeArgs& a, const void* target, const float* weight, int ignore_index,
-                                  const float* loss_ws, const float* gout, float inv_batch, hipStream_t st) {
-  const bool vec24 = a.ldx % 4 == 0 && a.ldx >= 24 && ((uintptr_t)a.x & 15) == 0;
-  const bool vec64 = a.ldx % 4 == 0 && a.ldx >= 64 && ((uintptr_t)a.x & 15) == 0;
-  constexpr size_t LDS_BUDGET = 150 * 1024;
-  long region;
-  int cand;
-  if (a.C <= 24) {
-    ceb_extent(a, 8, region, cand);
-    if (cand <= CEB_MAXCAND && (size_t)region * a.C * 4 <= LDS_BUDGET)
-      return launch_ceb_tiled<TT, 24, 8>(a, target, weight, ignore_index, loss_ws, gout, inv_batch, (size_t)region * a.C * 4, vec24, st);
-  }
-  ceb_extent(a, 4, region, cand);
-  if (cand <= CEB_MAXCAND && (size_t)region * a.C * 4 <= LDS_BUDGET) {
-    if (a.C <= 24)
-      return launch_ceb_tiled<TT, 24, 4>(a, target, weight, ignore_index, loss_ws, gout, inv_batch, (size_t)region * a.C * 4, vec24, st);
-    return launch_ceb_tiled<TT, 64, 4>(a, target, weight, ignore_index, loss_ws, gout, inv_batch, (size_t)region * a.C * 4, vec64, st);
-  }
-  // anything else (huge upsampling factors): the per-thread form
-  const long total = (long)a.N * a.H * a.W;
-  const dim3 grid((unsigned)((total + 127) / 128)), block(128);
-  const TT* t = (const TT*)target;
-  if (a.C <= 24) {
-    if (vec24) hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 24, true>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
-    else hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 24, false>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
-  } else {
-    if (vec64) hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 64, true>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
-    else hipLaunchKernelGGL((ce_bilinear_bwd_kernel<TT, 64, false>), grid, block, 0, st, a, t, weight, ignore_index, loss_ws, gout, inv_batch);
-  }
-  return ZS3_LAUNCH_CHECK();
-}
-
-/* d(loss)/d(lr) for  loss = CE(bilinear(lr -> Ho x Wo), target)  in one launch.  lr: [N,H,W,C] low-resolution class scores,
- * loss_ws / gout as for zs3_ce_bwd (loss_ws[1] = sum of the class weights over the valid pixels, written by zs3_ce_fwd on the
- * upsampled scores), dlr: [N,H,W,C] with row stride ldo (every one of the C channels of every pixel is written). */
-extern "C" int zs3_ce_bilinear_bwd(const float* lr, int ldx, const void* target, int target_is_i64, const float* weight,
-                                   int N, int H, int W, int Ho, int Wo, int C, int ignore_index, int batch,
-                                   const float* loss_ws, const float* gout, float* dlr, int ldo, void* stream) {
-  if (C < 1 || C > 64 || N < 1) return -1;
-  const ResizeArgs a = make_resize(lr, ldx, dlr, ldo, N, H, W, Ho, Wo, C, 0);
-  const float inv_batch = batch > 0 ? 1.f / (float)batch : 1.f;
-  return target_is_i64 ? launch_ce_bilinear_bwd<long>(a, target, weight, ignore_index, loss_ws, gout, inv_batch, (hipStream_t)stream)
-                       : launch_ce_bilinear_bwd<float>(a, target, weight, ignore_index, loss_ws, gout, inv_batch, (hipStream_t)stream);
-}

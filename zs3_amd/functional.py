@@ -97,12 +97,32 @@ def register_grad_buffer(param, flat_view):
         _grad_buffers[id(param)] = (weakref.ref(param), flat_view)
 
 
+_handed = set()          # parameters that already received their bucket slice in the running backward pass
+_handed_armed = [False]
+
+
+def _end_of_backward():
+    _handed.clear()
+    _handed_armed[0] = False
+
+
 def grad_buffer(param):
-    """The bucket slice a fresh gradient of `param` should be written into, or None: only when the parameter has no .grad
-    yet (otherwise autograd accumulates into the existing one and the slice may already hold it)."""
+    """The bucket slice a fresh gradient of `param` should be written into, or None.  The slice is handed out only when the
+    parameter has no .grad yet (otherwise autograd accumulates into the existing one and the slice may already hold it) and
+    only ONCE per backward pass: a weight used by two layers gets two wgrad launches (possibly on two streams of the wgrad
+    pool), AccumulateGrad sums the two contributions after both exist, and two launches writing one slice would leave
+    2 x the last one there.  The second request gets None -> a private buffer.  (Gradients returned by torch.autograd.grad for a
+    registered parameter still alias its slice: they are valid until the next backward writes it.)"""
     ent = _grad_buffers.get(id(param))
-    if ent is None or ent[0]() is not param or not param.is_leaf or param.grad is not None:
+    if ent is None or ent[0]() is not param or not param.is_leaf or param.grad is not None or id(param) in _handed:
         return None
+    _handed.add(id(param))
+    if not _handed_armed[0]:
+        try:     # only legal while the autograd engine is running a backward pass -- which is where wgrad launches come from
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+            _handed_armed[0] = True
+        except RuntimeError:
+            _handed.discard(id(param))
     return ent[1]
 
 
@@ -679,7 +699,7 @@ class _Fork(torch.autograd.Function):
             return gs[0], None
         dense = [_dense_rows(g) for g in gs]
         same = all(g.shape == dense[0].shape and g.stride() == dense[0].stride() and g.dtype == torch.float32 and g.is_cuda
-                   for g in dense)
+                   and g.data_ptr() % 16 == 0 for g in dense)   # zs3_sum_n reads float4: an offset view takes the plain adds
         n = dense[0].numel()
         if not same or len(dense) > 8 or n % 4 or ops._rows(dense[0])[2] != dense[0].shape[-1]:
             out = dense[0]

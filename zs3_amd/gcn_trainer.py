@@ -20,7 +20,6 @@ generated cluster features; an image whose label map is a single cluster contrib
 Host synchronisation: the B cluster counts (they decide tensor shapes) are read together with the step's class histogram; the
 losses are read back once per step.
 """
-import os
 
 import torch
 
@@ -30,14 +29,12 @@ from .gcn_context import ClusterGraphBatch
 from .gmmn_trainer import GMMNStep, GMMNTrainer
 
 
-# The graph generator's per-image update touches nothing the GMMN generator's update chain reads or writes (its own network,
-# optimizer and inputs), and both are latency-bound strings of small launches: the graph update runs on a second stream next to
-# the chain instead of between two chains, and the chain is no longer cut after every image.  ZS3_GCN_SIDE_STREAM=0: in line.
-GCN_SIDE_STREAM = os.environ.get("ZS3_GCN_SIDE_STREAM", "0") == "1"
+# (Running the graph generator's per-image update on a second stream next to the GMMN update chain, and not cutting the chain
+# after every image, were measured in round 2 -- +1.3 ms and noise, tools/probe/r2bb.sh, r2cc.sh -- and removed in round 3.)
 
 
 class GCNContextStep(GMMNStep):
-    _hook_reads_generator = os.environ.get("ZS3_GCN_FLUSH", "1") != "0"   # cut the GMMN update chain after every image?
+    _hook_reads_generator = True   # the graph update reads the GMMN generator: the captured update chain is cut after every image
 
     def __init__(self, model, generator, generator_GCN, optimizer, optimizer_generator, optimizer_generator_GCN, criterion,
                  criterion_generator=None, *, GCN_weight=0.1, GCN_avg_feat=False, max_clusters=1024, **kw):
@@ -51,7 +48,6 @@ class GCNContextStep(GMMNStep):
         self.criterion_generator = criterion_generator
         self.GCN_weight, self.GCN_avg_feat, self.max_clusters = float(GCN_weight), bool(GCN_avg_feat), int(max_clusters)
         self._cluster_feats, self._cluster_labels, self._gcn_losses = [], [], []
-        self._gcn_stream = None
         self.last_generator_GCN_loss = 0.0
         self.last_num_clusters = 0
 
@@ -64,19 +60,7 @@ class GCNContextStep(GMMNStep):
 
     # ---- per image: one update of the graph generator on its clusters (:399-427)
     def _after_image(self, i, label_map, real_rows_i, has_unseen):
-        if not (GCN_SIDE_STREAM and real_rows_i.is_cuda and self._st.get("table_mode")):
-            # (outside table mode the per-image embedding rows live in ONE buffer that the next image overwrites)
-            return self._graph_update(i, real_rows_i, has_unseen)
-        main = torch.cuda.current_stream(real_rows_i.device)
-        if self._gcn_stream is None:
-            self._gcn_stream = torch.cuda.Stream(device=real_rows_i.device)
-        self._gcn_stream.wait_stream(main)        # this image's embedding rows, features and cluster graph are ready
-        with torch.cuda.stream(self._gcn_stream):
-            self._graph_update(i, real_rows_i, has_unseen)
-
-    def _join_side_work(self):
-        if self._gcn_stream is not None:
-            torch.cuda.current_stream(self._gcn_stream.device).wait_stream(self._gcn_stream)
+        return self._graph_update(i, real_rows_i, has_unseen)
 
     def _graph_update(self, i, real_rows_i, has_unseen):
         graph = self._graphs.graph(i, self._st["emb"], real_rows_i)

@@ -436,6 +436,13 @@ class GMMNStep:
             main.wait_event(pf[2])
             pf[1].record_stream(main)
             return pf[1]
+        if pf is not None:
+            # the prefetched pass already updated the BN running statistics (train() mode, train_pascal_GMMN.py:136,154) and
+            # drew its dropout seeds for a batch that is now dropped: recomputing silently would count one batch twice
+            import warnings
+            warnings.warn("GMMNStep: the batch passed to prefetch()/next_image is not the tensor object of this call; its "
+                          "feature pass is discarded (the BatchNorm running statistics have seen that batch once already)",
+                          RuntimeWarning, stacklevel=3)
         return self._features(image)
 
     # ------------------------------------------------------------------ one iteration
@@ -628,6 +635,7 @@ class GMMNStep:
                     check(lib().zs3_mmd_bwd(P(gen_s), I(d), P(real_s), I(d), I(s), I(d), P(gmat), P(loss), P(st["one"]),
                                             P(dgen), I(d), stream()), "zs3_mmd_bwd")
                     self._eager_update_rows(x, h, hd, seed, ridx, dgen)
+                    st["adam_sig"] = self._adam_signature()   # the eager optimizer step advanced the host step count
                     mmd_slots.append((slot, len(classes)))
                     slot += 1
                 if not use_real:

@@ -38,7 +38,6 @@ class DeepLab(nn.Module):
 
     def _logits_to_image(self, logits_nhwc, size):
         out = ops.nchw(Fz.bilinear(logits_nhwc, size))   # align_corners=True resize of deeplab.py:44,55
-        out._zs3_lowres = logits_nhwc   # lets the criterion fuse its backward with the resize's (utils/loss.py)
         return out
 
     # ------------------------------------------------------------------ the reference's forward variants

@@ -257,7 +257,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if prof:
         e1.record()
         PROFILE.append(("conv_halo<%d>" % prec if tile_cfg in (41, 42) else
-                        "conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else "conv_igemm_ws<256,128,%d>" % prec if tile_cfg == 21 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
+                        "conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
 

@@ -1,7 +1,6 @@
 """Losses -- drop-in for zs3.utils.loss (loss.py:5-115): SegmentationLosses(...).build_loss(mode) and
 GMMNLoss(...).build_loss(), computed by the HIP kernels in csrc/loss.hip."""
 import ctypes
-import os
 
 import torch
 
@@ -9,25 +8,13 @@ from .. import ops
 from .._lib import I, P, check, lib, require_gpu, stream
 
 
-# The model's last op is the 4x bilinear upsample of the class scores (deeplab.py:44,55) and the criterion is the first thing
-# that touches the result.  DeepLab tags the tensor it returns with the low-resolution scores it was resized from
-# (`_zs3_lowres`); with FUSE_UPSAMPLE_CE the CE's backward computes d(loss)/d(low-resolution scores) in one launch
-# (zs3_ce_bilinear_bwd) instead of writing the 354 MB full-resolution gradient and gathering it back.  Measured at B=16, 513x513
-# (same-box A/B, tools/probe/r2p.sh, r2q.sh): the two kernels it replaces take 0.23 + 0.36 ms; the fused launch takes 1.7 ms in
-# its one-thread-per-low-resolution-pixel form (49 softmaxes recomputed per thread) and 0.88 ms in its tiled form (softmax once
-# per output pixel into 128 KB of LDS -> one workgroup per CU, nothing hides the tap loads' latency).  Not a win yet, so it is
-# OFF by default (ZS3_FUSE_CE=1 turns it on); parity of both forms is covered by tests/test_gpu_ops.py.  The tag does not
-# survive views / slices / arithmetic, so anything but "pass the model output to the criterion" takes the two-kernel path.
-FUSE_UPSAMPLE_CE = os.environ.get("ZS3_FUSE_CE", "0") == "1"
-
-
 class _CrossEntropy(torch.autograd.Function):
     """sum_i w[t_i] * nll_i / sum_i w[t_i] over t_i != ignore_index, then / B (loss.py:31-46).
-    lowres: None, or the [B,h,w,C] scores `logit` is the align_corners bilinear resize of (then `logit` arrives detached and
-    the gradient is returned for `lowres`)."""
+    (A backward fused with the model's final 4x upsample -- one launch producing d loss / d low-resolution scores -- was built
+    and measured in round 2: 0.88-1.7 ms against the 0.59 ms of the two kernels it replaces; removed in round 3.)"""
 
     @staticmethod
-    def forward(ctx, logit, target, weight, ignore_index, batch, group, lowres=None):
+    def forward(ctx, logit, target, weight, ignore_index, batch, group):
         require_gpu(logit, target, weight)
         b, c, h, w = logit.shape
         z = ops.nhwc(logit)                       # free view for channels_last logits
@@ -43,8 +30,7 @@ class _CrossEntropy(torch.autograd.Function):
         loss = loss_ws[0].clone()
         if group is not None:
             loss, batch = global_ce_normalise(loss_ws, batch, group)
-        ctx.fused = lowres is not None
-        ctx.save_for_backward(lowres if ctx.fused else z, target, weight, loss_ws)
+        ctx.save_for_backward(z, target, weight, loss_ws)
         ctx.meta = (b, c, h, w, ld, ignore_index, batch)
         return loss
 
@@ -53,21 +39,11 @@ class _CrossEntropy(torch.autograd.Function):
         z, target, weight, loss_ws = ctx.saved_tensors
         b, c, h, w, ld, ignore_index, batch = ctx.meta
         gout = gout.contiguous().float()
-        if ctx.fused:
-            lr = z                                       # [B, hl, wl, C] low-resolution scores (row stride >= C)
-            _, _, ldl = ops._rows(lr)
-            hl, wl = lr.shape[1], lr.shape[2]
-            cp = (c + 7) // 8 * 8                        # the gradient buffer pred_conv's backward expects (zero pad lanes)
-            dlr = (torch.zeros if cp != c else torch.empty)((b, hl, wl, cp), dtype=torch.float32, device=lr.device)[..., :c]
-            check(lib().zs3_ce_bilinear_bwd(P(lr), I(ldl), P(target), I(int(target.dtype == torch.int64)), P(weight), I(b),
-                                            I(hl), I(wl), I(h), I(w), I(c), I(ignore_index), I(batch), P(loss_ws), P(gout),
-                                            P(dlr), I(cp), stream()), "zs3_ce_bilinear_bwd")
-            return None, None, None, None, None, None, dlr
         dz = torch.empty((b, h, w, c), dtype=torch.float32, device=z.device)
         check(lib().zs3_ce_bwd(P(z), I(ld), P(target), I(int(target.dtype == torch.int64)), P(weight),
                                ctypes.c_long(b * h * w), I(c), I(ignore_index), I(batch), P(loss_ws), P(gout), P(dz), I(c),
                                stream()), "zs3_ce_bwd")
-        return ops.nchw(dz), None, None, None, None, None, None
+        return ops.nchw(dz), None, None, None, None, None
 
 
 def global_ce_normalise(loss_ws, batch, group):
@@ -87,10 +63,6 @@ def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average
     if weight is not None:
         weight = weight.to(device=logit.device, dtype=torch.float32).contiguous()
     batch = logit.shape[0] if batch_average else 0
-    lowres = getattr(logit, "_zs3_lowres", None)
-    if (FUSE_UPSAMPLE_CE and lowres is not None and torch.is_grad_enabled() and lowres.requires_grad and lowres.dim() == 4
-            and lowres.shape[0] == logit.shape[0] and lowres.shape[3] == logit.shape[1] <= 64):
-        return _CrossEntropy.apply(logit.detach(), target, weight, ignore_index, batch, group, lowres)
     return _CrossEntropy.apply(logit, target, weight, ignore_index, batch, group)
 
 
