@@ -84,6 +84,17 @@ int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const flo
                            const unsigned char* mask_bits, float* bn_partial, void* stream);
 
 /* ---- weight gradient ------------------------------------------------------------------------- */
+/* Strip-resident weight gradient (csrc/conv_wgrad_strip.hip) of the stride-1, same-size 3x3 convolutions (pad = dilation):
+ * the reduction runs over zero-padded pixel positions, so every filter tap is a constant shift of one LDS-resident strip of x
+ * (read from L2 once instead of nine times); producer waves split both operands to bf16 hi/lo once, the MFMA waves fetch
+ * their position-major fragments with ds_read_b64_tr_b16.  zs3_conv_wgrad_strip_plan returns 1 when the layer is eligible
+ * (and the split-K factor / workspace floats the launch needs), 0 otherwise (use zs3_conv_wgrad).  Arguments as zs3_conv_wgrad;
+ * dw: [co_write][3][3][ci_write].  Replaces convolution_backward(weight) at resnet.py:18-26, aspp.py:11-19, decoder.py:15-24. */
+int zs3_conv_wgrad_strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil,
+                              int co, int ci, int* splitk_out, long* workspace_floats);
+int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int dil,
+                         int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
+                         const void* zero_page, void* stream);
 /* dw[co][kh][kw][ci] = sum_m dy[m][co] * x[gather(m,kh,kw)][ci]  (channels_last weight layout).
  * dy: [M][lddy] with co_read (multiple of 4) readable channels of which co_write rows are produced;
  * x likewise (ci_read / ci_write).  Split-K over pixels: call zs3_conv_wgrad_plan (same M = N*Ho*Wo, Wo, channel

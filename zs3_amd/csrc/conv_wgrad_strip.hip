@@ -1,0 +1,383 @@
+// Strip-resident weight gradient of the stride-1, same-size 3x3 (dilated) convolutions for gfx950 (MI355X).
+//
+//   dw[co, t, ci] = sum_p dy[p, co] * x[p + tap_t, ci]                          (zs3_conv_wgrad_strip)
+//
+// conv_wgrad.hip computes this as one 256x256 GEMM per filter tap over the pixel axis: both operands are fp32
+// activations, every wave gathers and splits its own fragments (6 VALU per MFMA -- the kernel is VALU-bound at ~157 TF),
+// and x is re-read once per tap.  Here:
+//
+//   * The reduction runs over ZERO-PADDED pixel positions q = (n*(H+d) + y)*(W+d) + x: every image row carries d pad
+//     columns and every image d pad rows (shared with the next row / image), where dy and x are zero.  In that space tap
+//     (a, b) is the constant offset a*d*(W+d) + b*d for EVERY position -- border taps read pad zeros by themselves, so
+//     there are no masks, no per-pixel coordinates and no divergence in the multiply loop.  Cost: (H+d)(W+d)/(HW) more
+//     K steps (6 % at 33x33, 1.6 % at 129x129).
+//   * A workgroup owns a 64 (co) x 64 (ci) tile of ALL NINE taps and a range of K steps (split-K).  Per 16-position K
+//     step it needs 16 new rows of dy and 16 new rows of x: x lives in an LDS ring that holds the positions every tap's
+//     shifted window can reach (2d(W+d+1) + 16 rows), so x is read from L2 once instead of nine times.
+//   * Four producer waves load both operands as fp32 (plain loads, three K steps ahead), split them to bf16 hi/lo ONCE
+//     and write [position][channel] rows (hi 128 B | lo 128 B | 64 B pad = 320 B: four consecutive rows cover the 64
+//     banks) -- the conversion has left the MFMA waves.
+//   * Four consumer waves (2x2 blocks of 32 co x 32 ci, nine taps each = 144 accumulator registers) fetch their MFMA
+//     operands with ds_read_b64_tr_b16: the operand wants 8 consecutive POSITIONS per lane while memory is channel-
+//     contiguous, and the transposing read delivers exactly that from the row-major image (16 lanes read a 4-position x
+//     16-channel block, lane = channel gets the 4 positions; measured semantics: result[l][j] = source[4j + l/4][l%4]
+//     within a 16-lane group, tools/probe/tr/tr_host.hip) -- no packing, no VALU.  27 MFMAs per wave and K step against
+//     40 LDS reads and a few scalar window computations.
+//
+// The first 16 ring rows are mirrored behind the ring so that a 16-row window never wraps.  Partial sums of the split-K
+// ranges go to slabs that zs3_conv_wgrad_strip reduces in a fixed order (deterministic).
+// Replaces convolution_backward(weight) of the 3x3 nn.Conv2d of resnet.py:18-26, aspp.py:11-19, decoder.py:15-24.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "zs3hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct StripArgs {
+  const float* dy;
+  const float* x;
+  float* out;          // slab 0 (or dw itself when splitk == 1)
+  const float* zero;
+  int N, H, W;
+  int co_read, co_write, ci_read, ci_write;
+  int lddy, ldx, ldw, cin_w;
+  int Hd, Wd;          // padded extents H + d, W + d
+  long Q;              // padded positions N * Hd * Wd
+  int RL;              // positions the x stream starts before the first dy position (multiple of 16, >= the tap reach R)
+  int lead;            // K step i reads x steps i .. i + lead; (lead + 1) % 3 == 0
+  int ring_steps;      // lead + 2
+  int steps_per_split; // multiple of 6
+  int tiles_co, tiles_ci;
+  long slab;           // elements per split-K slab
+  int toff[9];         // tap offsets in padded positions
+};
+
+constexpr int WS_ROW = 320;            // bytes per LDS row: 64 ch hi | 64 ch lo | 64 B pad
+
+struct Pos {           // a lane's position in a padded stream: q and its coordinates (valid while 0 <= q)
+  long q;
+  int n, yp, xp;
+};
+
+template <int PREC>
+__global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntiles = p.tiles_co * p.tiles_ci;
+  const int split = b / ntiles;
+  b -= split * ntiles;
+  const int tco = b / p.tiles_ci, tci = b - tco * p.tiles_ci;
+  const int co0 = tco * 64, ci0 = tci * 64;
+  const int NSTEP = p.steps_per_split;                    // multiple of 6
+  const long q_begin = (long)split * NSTEP * 16;          // first dy position of this range
+  const int ring_rows = p.ring_steps * 16;
+  unsigned char* const xring = dsm;                                        // (ring_rows + 16) rows
+  unsigned char* const dyring = dsm + (size_t)(ring_rows + 16) * WS_ROW;   // 2 x 16 rows
+
+  f32x16 acc[9];
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers (256 lanes: 16 rows x 16 channel quads)
+    const int prow = (tid - 256) >> 4, cq = tid & 15;
+    const bool x_cok = ci0 + cq * 4 < p.ci_read, d_cok = co0 + cq * 4 < p.co_read;
+    auto decode = [&](long q) {
+      Pos s;
+      s.q = q;
+      const long qq = q < 0 ? 0 : q;
+      const long per = (long)p.Hd * p.Wd;
+      s.n = (int)(qq / per);
+      const int rem = (int)(qq - (long)s.n * per);
+      s.yp = rem / p.Wd;
+      s.xp = rem - s.yp * p.Wd;
+      return s;
+    };
+    auto advance = [&](Pos& s) {   // += 16 positions; Wd > 16: at most one row carry
+      s.q += 16;
+      if (s.q < 16) {              // the stream started before position 0 and is (re)entering the tensor
+        if (s.q >= 0) s = decode(s.q);
+        return;
+      }
+      s.xp += 16;
+      if (s.xp >= p.Wd) {
+        s.xp -= p.Wd;
+        if (++s.yp >= p.Hd) {
+          s.yp = 0;
+          ++s.n;
+        }
+      }
+    };
+    auto fetch = [&](const Pos& s, const float* base, int ld, int c0, bool cok) {
+      const bool real = s.q >= 0 && s.q < p.Q && s.yp < p.H && s.xp < p.W && cok;
+      const long pix = ((long)s.n * p.H + s.yp) * p.W + s.xp;
+      const float* src = real ? base + pix * ld + c0 + cq * 4 : p.zero;
+      return *reinterpret_cast<const f32x4*>(src);
+    };
+    auto conv_write = [&](const f32x4 v, unsigned char* row) {
+      u32x2 hi, lo;
+      unsigned h, l;
+      split_pair<PREC>(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
+      split_pair<PREC>(v[2], v[3], h, l); hi[1] = h; lo[1] = l;
+      *reinterpret_cast<u32x2*>(row + cq * 8) = hi;
+      if (PREC == 3) *reinterpret_cast<u32x2*>(row + 128 + cq * 8) = lo;
+    };
+    // x step k: positions q_begin - RL + 16 k + prow -> ring slot k % ring_steps; dy step i: positions q_begin + 16 i + prow
+    Pos xs = decode(q_begin - p.RL + prow), ds = decode(q_begin + prow);
+    int xslot = 0;   // ring slot of the next x step to be WRITTEN
+    auto write_x = [&](const f32x4 v) {
+      unsigned char* row = xring + (size_t)(xslot * 16 + prow) * WS_ROW;
+      conv_write(v, row);
+      if (xslot == 0) conv_write(v, row + (size_t)ring_rows * WS_ROW);   // mirror of the first 16 rows: windows never wrap
+      xslot = xslot + 1 == p.ring_steps ? 0 : xslot + 1;
+    };
+    auto load_x = [&]() {
+      const f32x4 v = fetch(xs, p.x, p.ldx, ci0, x_cok);
+      advance(xs);
+      return v;
+    };
+    auto load_d = [&]() {
+      const f32x4 v = fetch(ds, p.dy, p.lddy, co0, d_cok);
+      advance(ds);
+      return v;
+    };
+    f32x4 xbuf[3], dbuf[3];
+    // ---- prologue: x steps 0 .. lead and dy step 0 into LDS (lead + 1 is a multiple of 3: three loads in flight per trip)
+    for (int k = 0; k <= p.lead; k += 3) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) xbuf[s] = load_x();
+#pragma unroll
+      for (int s = 0; s < 3; ++s) write_x(xbuf[s]);
+    }
+    dbuf[0] = load_d();
+    conv_write(dbuf[0], dyring + (size_t)prow * WS_ROW);
+    // requested and in flight from here on: x steps lead+1 .. lead+3 (sets 0, 1, 2) and dy steps 1 .. 3 (sets 1, 2, 0)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) xbuf[s] = load_x();
+    dbuf[1] = load_d();
+    dbuf[2] = load_d();
+    dbuf[0] = load_d();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // B_0
+    // ---- interval i (consumers multiply K step i): write x step i + lead + 1 and dy step i + 1, request the steps 3 later
+    for (int i0 = 0; i0 < NSTEP; i0 += 3) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        write_x(xbuf[r]);
+        xbuf[r] = load_x();
+        conv_write(dbuf[(r + 1) % 3], dyring + (size_t)(((i0 + r + 1) & 1) * 16 + prow) * WS_ROW);
+        dbuf[(r + 1) % 3] = load_d();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // B_{i+1}
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ consumers: transposing LDS reads + MFMA
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int bi = wave >> 1, bj = wave & 1;
+    // lane -> (position row within the 16-position step, channel quad) of its transposing reads: 16-lane group g covers
+    // channels 16 (g & 1) .. +15 and positions 8 (g >> 1) .. +7; inside the group source lane l reads position (l >> 2)
+    // (+4 for the second read), channels 4 (l & 3) .. +3
+    const int g = lane >> 4, l16 = lane & 15;
+    const unsigned lane_row = (unsigned)(8 * (g >> 1) + (l16 >> 2));
+    const unsigned lane_ch = (unsigned)(16 * (g & 1) + 4 * (l16 & 3));
+    const unsigned a_off = lane_row * WS_ROW + (unsigned)(32 * bi + lane_ch) * 2;
+    const unsigned b_off = lane_row * WS_ROW + (unsigned)(32 * bj + lane_ch) * 2;
+    auto tr_pair = [&](const unsigned char* base, unsigned off) {
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + 4 * WS_ROW));
+      return bf16x8{u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+    };
+    bf16x8 a_hi[2], a_lo[2];          // dy fragments of this K step / the next one
+    bf16x8 x_hi[3], x_lo[3];          // x fragments: tap t lives in set t % 3
+    // window of tap t at K step i: ring rows (16 i + RL + toff[t]) mod ring_rows .. +15 (the mirror makes the wrap harmless)
+    int wbase = p.RL;                 // 16 i + RL, kept modulo ring_rows
+    auto window = [&](int t) {
+      int r = wbase + p.toff[t];
+      r = r >= ring_rows ? r - ring_rows : (r < 0 ? r + ring_rows : r);
+      return xring + (size_t)r * WS_ROW;
+    };
+    auto read_x = [&](int t) {
+      const unsigned char* w = window(t);
+      x_hi[t % 3] = tr_pair(w, b_off);
+      if (PREC == 3) x_lo[t % 3] = tr_pair(w, b_off + 128);
+    };
+    auto read_a = [&](int set, int slot) {
+      const unsigned char* w = dyring + (size_t)slot * 16 * WS_ROW;
+      a_hi[set] = tr_pair(w, a_off);
+      if (PREC == 3) a_lo[set] = tr_pair(w, a_off + 128);
+    };
+    // One K step: nine taps of 3 (bf16x3) or 1 MFMAs on this wave's 32 x 32 block.  The x fragment of tap t + 2 is read in
+    // the shadow of tap t; the step barrier (next dy rows / next x rows written) sits before tap 7, after which the next
+    // step's dy fragment and its first two x fragments are fetched.
+    auto step = [&](auto setc) {
+      constexpr int SET = decltype(setc)::value;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t == 7) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          wbase += 16;
+          wbase = wbase >= ring_rows ? wbase - ring_rows : wbase;
+        }
+        const bf16x8 xh = x_hi[t % 3], xl = x_lo[t % 3];
+        if (PREC == 3) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[SET], xh, acc[t], 0, 0, 0);
+          if (t == 7) read_a(SET ^ 1, SET ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[SET], xl, acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (t == 7) {
+          read_a(SET ^ 1, SET ^ 1);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[SET], xh, acc[t], 0, 0, 0);
+        // tap t + 2 of this step (t <= 6), or taps 0 / 1 of the next step (t = 7, 8: wbase already points there)
+        read_x((t + 2) % 9);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    __builtin_amdgcn_s_barrier();   // B_0
+    asm volatile("" ::: "memory");
+    read_a(0, 0);
+    read_x(0);
+    read_x(1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NSTEP; i += 2) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+    }
+    // ---- store this range's partial tile: out[split][co][tap][ci] (a lane owns one ci column of 16 co rows per tap)
+    float* out = p.out + (size_t)split * p.slab;
+    const int ci = ci0 + 32 * bj + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.co_write && ci < p.ci_write) out[(size_t)co * p.ldw + (size_t)t * p.cin_w + ci] = acc[t][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void strip_reduce_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dw, long n4, int splitk,
+                                                          long slab4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 s = part[i];
+#pragma unroll 4
+    for (int k = 1; k < splitk; ++k) s += part[(size_t)k * slab4 + i];
+    dw[i] = s;
+  }
+}
+
+struct StripPlan {
+  int ok, splitk, steps_per_split, RL, lead, ring_steps, lds_bytes;
+  long Q, workspace_floats;
+};
+
+StripPlan strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co,
+                     int ci) {
+  StripPlan s{};
+  static const int enabled = getenv("ZS3_WGRAD_STRIP") ? atoi(getenv("ZS3_WGRAD_STRIP")) : 1;
+  if (!enabled || KH != 3 || KW != 3 || stride != 1 || H != Ho || W != Wo || pad_h != dil || pad_w != dil) return s;
+  if (co < 64 || ci < 64 || (co * 9L * ci) % 4) return s;
+  const int Wd = W + dil, Hd = H + dil;
+  if (Wd <= 16) return s;
+  const int R = dil * (Wd + 1);
+  int RL = (R + 15) / 16 * 16;
+  int lead = (RL + R + 15) >> 4;
+  while ((lead + 1) % 3) {      // producer register sets are indexed by (K step) % 3
+    RL += 16;
+    lead = (RL + R + 15) >> 4;
+  }
+  s.RL = RL;
+  s.lead = lead;
+  s.ring_steps = lead + 2;
+  s.lds_bytes = ((s.ring_steps + 1) * 16 + 2 * 16) * WS_ROW;
+  if (s.lds_bytes > 160 * 1024) return s;
+  s.Q = (long)N * Hd * Wd;
+  const long steps = (s.Q + 15) / 16;
+  const int tiles = ((co + 63) / 64) * ((ci + 63) / 64);
+  // split-K: aim at ~2 rounds of 256 workgroups, at least 36 K steps per range (the prologue fills lead + 1 ring steps)
+  long want = (512 + tiles - 1) / tiles;
+  long maxs = steps / 36;
+  if (maxs < 1) maxs = 1;
+  long sk = want < maxs ? want : maxs;
+  if (sk > 256) sk = 256;
+  long per = (steps + sk - 1) / sk;
+  per = (per + 5) / 6 * 6;
+  sk = (steps + per - 1) / per;
+  s.splitk = (int)sk;
+  s.steps_per_split = (int)per;
+  s.workspace_floats = sk > 1 ? sk * (long)co * 9 * ci : 0;
+  s.ok = 1;
+  return s;
+}
+
+}  // namespace
+
+// Eligibility + split-K plan of the strip-resident weight-gradient kernel: returns 1 and the workspace size (floats) when
+// zs3_conv_wgrad_strip can run the layer (3x3, stride 1, same size, pad = dilation, >= 64 channels on both sides, ring fits
+// the LDS), else 0 (use zs3_conv_wgrad).
+extern "C" int zs3_conv_wgrad_strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w,
+                                         int dil, int co, int ci, int* splitk_out, long* workspace_floats) {
+  const StripPlan s = strip_plan(N, H, W, Ho, Wo, KH, KW, stride, pad_h, pad_w, dil, co, ci);
+  if (splitk_out) *splitk_out = s.splitk;
+  if (workspace_floats) *workspace_floats = s.workspace_floats;
+  return s.ok;
+}
+
+extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int dil,
+                                    int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
+                                    const void* zero_page, void* stream) {
+  if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 15)) return -2;
+  const StripPlan s = strip_plan(N, H, W, H, W, 3, 3, 1, dil, dil, dil, co_write, ci_write);
+  if (!s.ok) return -7;
+  if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
+  StripArgs a{};
+  a.dy = dy; a.x = x; a.zero = (const float*)zero_page;
+  a.N = N; a.H = H; a.W = W;
+  a.co_read = co_read; a.co_write = co_write; a.ci_read = ci_read; a.ci_write = ci_write;
+  a.lddy = lddy; a.ldx = ldx; a.cin_w = ci_write; a.ldw = 9 * ci_write;
+  a.Hd = H + dil; a.Wd = W + dil; a.Q = s.Q;
+  a.RL = s.RL; a.lead = s.lead; a.ring_steps = s.ring_steps; a.steps_per_split = s.steps_per_split;
+  a.tiles_co = (co_write + 63) / 64; a.tiles_ci = (ci_write + 63) / 64;
+  a.slab = (long)co_write * a.ldw;
+  a.out = s.splitk > 1 ? workspace : dw;
+  for (int t = 0; t < 9; ++t) a.toff[t] = (t / 3 - 1) * dil * a.Wd + (t % 3 - 1) * dil;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = a.tiles_co * a.tiles_ci * s.splitk;
+  static bool configured[2] = {false, false};
+  const int pi = prec == 1 ? 0 : 1;
+  if (!configured[pi]) {
+    const void* fn = prec == 1 ? reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1>)
+                               : reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<3>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -4;
+    configured[pi] = true;
+  }
+  if (prec == 1)
+    hipLaunchKernelGGL((conv_wgrad_strip_kernel<1>), dim3(grid), dim3(512), s.lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_strip_kernel<3>), dim3(grid), dim3(512), s.lds_bytes, st, a);
+  int rc = ZS3_LAUNCH_CHECK();
+  if (rc) return rc;
+  if (s.splitk > 1) {
+    const long n4 = a.slab / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(strip_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(workspace),
+                       reinterpret_cast<f32x4*>(dw), n4, s.splitk, n4);
+    rc = ZS3_LAUNCH_CHECK();
+  }
+  return rc;
+}

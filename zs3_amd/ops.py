@@ -51,6 +51,7 @@ def streamk_errors():
 STREAMK = os.environ.get("ZS3_STREAMK", "0") == "1"
 
 
+WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"   # strip-resident weight gradient of the 3x3 stride-1 layers
 HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
 
 
@@ -294,6 +295,15 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
     dw = out if out is not None else torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == cout * kh * kw * cin
     splitk, ws = ctypes.c_int(0), ctypes.c_long(0)
+    if WGRAD_STRIP and kh == 3 and kw == 3 and lib().zs3_conv_wgrad_strip_plan(
+            I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride), I(pad_h), I(pad_w), I(dil), I(cout), I(cin),
+            ctypes.byref(splitk), ctypes.byref(ws)):
+        # strip-resident kernel (csrc/conv_wgrad_strip.hip): all nine taps from one LDS-resident strip of x
+        work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
+        check(lib().zs3_conv_wgrad_strip(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(dil), I(co_read), I(cout),
+                                         I(ci_read), I(cin), I(lddy), I(ldx), I(prec), P(zero_page(x.device)), stream()),
+              "zs3_conv_wgrad_strip")
+        return dw
     lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
     work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
     check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
