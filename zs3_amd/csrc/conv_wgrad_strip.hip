@@ -307,8 +307,12 @@ StripPlan strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int st
   s.Q = (long)N * Hd * Wd;
   const long steps = (s.Q + 15) / 16;
   const int tiles = ((co + 63) / 64) * ((ci + 63) / 64);
-  // split-K: aim at ~2 rounds of 256 workgroups, at least 36 K steps per range (the prologue fills lead + 1 ring steps)
-  long want = (512 + tiles - 1) / tiles;
+  // split-K: aim at ZS3_WGRAD_STRIP_WGS workgroups (default 192), at least 36 K steps per range (the prologue fills lead + 1
+  // ring steps).  Same-box sweep inside the training step (ms per step, tools/probe/ab_env.sh): 128 -> 46.11, 192 -> 46.05 /
+  // 46.12, 256 -> 46.10 / 46.15, 384 -> 46.67 / 46.46, 512 -> 46.83 / 46.59, 1024 -> 46.85 / 46.92 (without this kernel: 47.7):
+  // the launches run next to the dgrad chain, and every split costs a [Cout][9][Cin] slab of HBM traffic.
+  static const int wgs = getenv("ZS3_WGRAD_STRIP_WGS") ? atoi(getenv("ZS3_WGRAD_STRIP_WGS")) : 192;
+  long want = (wgs + tiles - 1) / tiles;
   long maxs = steps / 36;
   if (maxs < 1) maxs = 1;
   long sk = want < maxs ? want : maxs;
