@@ -335,6 +335,12 @@ def main():
                 a[2] += e0.elapsed_time(e1) * 1e-3
             return agg
         agg, warm = aggregate(prof), aggregate(warm_prof)
+        # the strip-resident kernel is ONE source kernel (csrc/conv_halo.hip) in several template instantiations (tile height,
+        # strip passes per step): the roofline prices the family, `instantiations` lists each under its rocprof name
+        fam = {k: v for k, v in agg.items() if k.startswith("conv_halo_kernel<")}
+        if fam:
+            agg = {k: v for k, v in agg.items() if k not in fam}
+            agg["conv_halo<%d>" % (1 if args.dtype == "bf16" else 3)] = [sum(v[i] for v in fam.values()) for i in range(3)]
         tag = max(agg, key=lambda k: agg[k][2])
         n, fl, sec = agg[tag]
         ach = fl / sec / 1e12
@@ -343,6 +349,8 @@ def main():
             "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TF,
             "traffic": traffic, "traffic_source": traffic_src, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
             "instrumented_timed_steps": instrumented,
+            "instantiations": ({k: {"launches": v[0], "avg_launch_us": 1e6 * v[2] / v[0], "tflops": v[1] / v[2] / 1e12}
+                                for k, v in sorted(fam.items())} if fam and tag.startswith("conv_halo<") else None),
             "note": "achieved = algorithmic 2*M*N*K flops of the sampled launches / their HIP-event time (events around every "
                     "4th launch of this kernel, rotating phase, in every 5th timed step)" + ("; each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation "
                     "is 3x this fraction" if args.dtype == "bf16x3" else "; one bf16 MFMA per product"),

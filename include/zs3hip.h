@@ -62,8 +62,9 @@ int zs3_conv_streamk_attach(void* stream, void* workspace, long workspace_bytes,
 /* tile_cfg 41 / 42 (csrc/conv_halo.hip): strip-resident kernel for stride-1, same-size multi-tap (3x3, dilated 3x3)
  * convolutions and their data gradients, 256- / 192-row tiles.  The input strip of a tile (tile rows + the halo the taps
  * reach, one channel chunk) is loaded ONCE, split to bf16 hi/lo by two producer waves and kept in LDS while all taps read
- * shifted windows of it; weight tiles stream by LDS-DMA.  zs3_conv_halo_ok() = 1 when a launch with these arguments can
- * run on tile_cfg 41 / 42 (otherwise zs3_conv_igemm returns -7 for them: use tile_cfg 31).
+ * shifted windows of it; weight tiles are register-staged by the same producer waves.  zs3_conv_halo_ok() > 0 when a launch with
+ * these arguments can run on tile_cfg 41 / 42 (the value is the kernel instantiation's strip-passes-per-step template argument;
+ * 0: zs3_conv_igemm returns -7 for them, use tile_cfg 31).
  * Replaces the 3x3 nn.Conv2d of resnet.py:18-26, aspp.py:11-19 (atrous branches), decoder.py:15-24. */
 int zs3_conv_halo_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
                      int pad_h, int pad_w, int dil, int dgrad, int prec, int tile_cfg);

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     };
     __builtin_amdgcn_s_barrier();   // B_0: strip 0 and weight tile 0 are in LDS
     asm volatile("" ::: "memory");
+    // (s_setprio(1) for the MFMA waves: 45.84 / 45.97 ms per step against 45.74 / 45.76 without -- not kept)
     next_window();
     a0 = a0n;
     tbit = tbitn;
@@ -477,7 +478,10 @@ int launch_halo_t(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
 
 }  // namespace
 
-int zs3conv::halo_eligible(const ConvArgs& a, int bm, int prec) { return halo_geometry(a, bm, prec, nullptr) ? 1 : 0; }
+int zs3conv::halo_eligible(const ConvArgs& a, int bm, int prec) {   // 0: not eligible, else NPG (the kernel instantiation's third template argument)
+  HaloGeom g;
+  return halo_geometry(a, bm, prec, &g) ? g.npg : 0;
+}
 
 int zs3conv::launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   HaloGeom g;
@@ -486,7 +490,9 @@ int zs3conv::launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   return prec == 1 ? launch_halo_t<1, 192>(a, g, st) : launch_halo_t<3, 192>(a, g, st);
 }
 
-// Whether tile_cfg 41 / 42 can run this convolution (callers fall back to tile_cfg 31 otherwise).
+// Whether tile_cfg 41 / 42 can run this convolution (callers fall back to tile_cfg 31 otherwise): 0 = no, otherwise the number
+// of strip passes per K step the launch will use = the third template argument of the conv_halo_kernel instantiation it runs
+// (what a profiler lists it under).
 extern "C" int zs3_conv_halo_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW,
                                 int stride, int pad_h, int pad_w, int dil, int dgrad, int prec, int tile_cfg) {
   ConvArgs a{};

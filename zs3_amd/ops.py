@@ -56,9 +56,10 @@ HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_
 
 
 def halo_ok(x_shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg):
-    """zs3_conv_halo_ok: can tile_cfg 41 / 42 (csrc/conv_halo.hip) run this launch?"""
+    """zs3_conv_halo_ok: can tile_cfg 41 / 42 (csrc/conv_halo.hip) run this launch?  0 = no, else the NPG template argument
+    of the conv_halo_kernel<PREC, BM, NPG> instantiation it will run (the name a profiler lists the launch under)."""
     n, h, w_ = x_shape[:3]
-    return bool(lib().zs3_conv_halo_ok(I(n), I(h), I(w_), I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride),
+    return int(lib().zs3_conv_halo_ok(I(n), I(h), I(w_), I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride),
                                        I(pad_h), I(pad_w), I(dil), I(int(dgrad)), I(prec), I(tile_cfg)))
 
 
@@ -257,7 +258,9 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
               "zs3_conv_igemm")
     if prof:
         e1.record()
-        PROFILE.append(("conv_halo<%d>" % prec if tile_cfg in (41, 42) else
+        PROFILE.append(("conv_halo_kernel<%d, %d, %d>" % (prec, 256 if tile_cfg == 41 else 192, halo_ok(
+                            x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg))
+                        if tile_cfg in (41, 42) else
                         "conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
