@@ -471,3 +471,110 @@ def test_more_updates_than_the_staging_ring_had_rows(dev):
     gl, cl, _ = step(b["image"].to(dev), b["label"].to(dev), table=b["table"].to(dev))
     assert step.last_updates > 2 and step._st["ring"].shape[0] >= step.last_updates
     assert np.isfinite(gl) and np.isfinite(cl)
+
+
+def _u01_host(seed, idx):
+    """numpy twin of csrc/common.h::u01 (splitmix64-style counter hash -> 24-bit uniform in [0, 1))"""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx.astype(np.uint64) + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def test_device_noise_path_vs_oracle_with_the_devices_own_draws(dev, monkeypatch):
+    """the benched GMMN path (noise="device": hipGraph-captured 7-launch update, sample indices from one
+    up-front draw, counter-hash noise keyed on the sampled pixel) was only property-checked, because its random numbers are
+    not the reference's CPU stream.  Here the oracle's torch.rand / torch.randint calls (train_pascal_GMMN.py:216,229 order:
+    per image, per class) are answered with the device path's OWN draws -- the indices replayed from the same CPU seed, the
+    noise rows recomputed on the host from the hash (seed_base + update * 2^24, key = within-class pixel index) -- so the
+    two trajectories must agree to kernel accuracy: per-step generator and classifier losses, generator weights after the
+    Adam updates, pred_conv after the SGD step.  Seen-only labels (every update is a sampled MMD update); dropout off."""
+    import numpy as np
+    import zs3_oracle as zo
+    from zs3_amd import functional as Fz
+    from zs3_amd.gmmn_trainer import GMMNStep
+    from zs3_amd.modeling.gmmn import GMMNnetwork
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    seen = [c for c in range(21) if c not in (10, 14)]
+    from zs3_amd.modeling.deeplab import DeepLab
+    torch.manual_seed(1)
+    m = DeepLab(num_classes=21, pretrained=False)
+    _tame(m)
+    ref = zo.DeepLab(num_classes=21, pretrained=False)
+    ref.load_state_dict(m.state_dict())
+    _no_dropout(m, ref)
+    torch.manual_seed(9)
+    gen = GMMNnetwork(300, 300, 256, 256)
+    gen_r = zo.GMMNnetwork(300, 300, 256, 256)
+    gen_r.load_state_dict(gen.state_dict())
+    for mod in list(gen.modules()) + list(gen_r.modules()):
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    m, gen = m.to(dev).train(), gen.to(dev).train()
+    ref.train()
+    gen_r.train()
+    w = torch.ones(21)
+    w[[10, 14]] = 100.0
+
+    def groups(mod, lr):
+        return [{"params": mod.get_1x_lr_params(), "lr": lr}, {"params": mod.get_10x_lr_params(), "lr": lr * 10}]
+
+    opt, opt_g = SGD(groups(m, 0.007), momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4)
+    opt_r, opt_gr = torch.optim.SGD(groups(ref, 0.007), momentum=0.9, weight_decay=5e-4), torch.optim.Adam(gen_r.parameters(), lr=2e-4)
+    Fz.manual_seed(123)
+    step = GMMNStep(m, gen, opt, opt_g, SegmentationLosses(weight=w.to(dev), cuda=True).build_loss("ce"), seen=seen,
+                    unseen=[10, 14], noise="device")
+    bsg, nz = 128, 300
+    updates_done = 0
+    for it in range(2):
+        b = zo.make_synthetic_batch(3, 65, seed=400 + it, with_label_emb=True)     # images 0..2: no unseen class
+        torch.manual_seed(31 + it)
+        gl, cl, _ = step(b["image"].to(dev), b["label"].to(dev), table=b["table"].to(dev))
+        assert step._st["table_mode"]
+        seed_base = int(step._st["seed_base"])
+        # ---- the device path's draws, replayed: (image, class) pairs in the reference's loop order
+        fh = fw = step._st["shape"][1] ** 0.5
+        fh = fw = int(round(fh))
+        tgt = torch.nn.functional.interpolate(b["label"][:, None], size=(fh, fw), mode="nearest").reshape(3, -1)
+        pairs = [(i, float(c), int((tgt[i] == c).sum())) for i in range(3) for c in torch.unique(tgt[i]) if float(c) != 255]
+        torch.manual_seed(31 + it)
+        n_c = torch.tensor([p[2] for p in pairs], dtype=torch.float64)[:, None]
+        idx_all = torch.minimum((torch.rand((len(pairs), bsg), dtype=torch.float64) * n_c).long(), n_c.long() - 1)
+        answers = []
+        for k, (i, c, n) in enumerate(pairs):
+            seed_k = (seed_base + (updates_done + k) * (1 << 24)) % (1 << 64)
+            keys = np.arange(n, dtype=np.uint64)[:, None] * np.uint64(nz) + np.arange(nz, dtype=np.uint64)[None, :]
+            answers.append(("rand", torch.from_numpy(_u01_host(seed_k, keys))))
+            answers.append(("randint", idx_all[k].clone()))
+        updates_done += len(pairs)
+        it_ans = iter(answers)
+
+        def fake_rand(*size, **kw):
+            kind, val = next(it_ans)
+            assert kind == "rand" and tuple(val.shape) == tuple(size[0] if isinstance(size[0], (tuple, list)) else size)
+            return val
+
+        def fake_randint(*a, **kw):
+            kind, val = next(it_ans)
+            assert kind == "randint" and kw.get("high", None) is not None and int(val.max()) < kw["high"]
+            return val
+
+        monkeypatch.setattr(torch, "rand", fake_rand)
+        monkeypatch.setattr(torch, "randint", fake_randint)
+        try:
+            gl_r, cl_r = zo.gmmn_step(ref, gen_r, opt_r, opt_gr, zo.SegmentationLosses(weight=w).build_loss("ce"),
+                                      zo.GMMNLoss().build_loss(), b["image"], b["label"], b["label_emb"], seen=seen, unseen=[10, 14])
+        finally:
+            monkeypatch.undo()
+        assert next(it_ans, None) is None, "the oracle consumed fewer draws than the device path made"
+        assert abs(gl - gl_r) < 2e-3 * abs(gl_r), (it, gl, gl_r)
+        assert abs(cl - cl_r) < 1e-3 * abs(cl_r), (it, cl, cl_r)
+    assert int(step.last_updates) == len(pairs)
+    for (k, p), (_, pr) in zip(gen.named_parameters(), gen_r.named_parameters()):
+        e_mean = ((p.detach().cpu() - pr.detach()).abs().mean() / pr.detach().abs().mean()).item()
+        assert rel(p, pr) < 2e-2 and e_mean < 1.5e-3, (k, rel(p, pr), e_mean)
+    assert rel(m.decoder.pred_conv.weight, ref.decoder.pred_conv.weight) < 2e-3
