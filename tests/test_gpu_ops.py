@@ -778,3 +778,21 @@ def test_stem_conv_at_full_size(dev):
     assert rel(net.bn1.weight.grad, bn64.weight.grad) < 1e-4
     assert rel(net.bn1.bias.grad, bn64.bias.grad) < 1e-4
     assert rel(net.bn1.running_var, bn64.running_var) < 1e-5
+
+
+def test_wgrad_into_an_unaligned_bucket_slice(dev):
+    """parallel.GradSync hands the wgrad kernels a slice of its flat bucket as the output (zero-copy buckets): the slice starts at
+    an arbitrary 4-byte offset.  Both weight-gradient paths (strip-resident and the round-2 kernels) must accept it and
+    produce exactly what they write into an aligned tensor."""
+    from zs3_amd import ops
+    g = torch.Generator().manual_seed(17)
+    for (ci, co, k, h) in ((128, 64, 3, 33), (64, 128, 1, 33)):
+        x = torch.randn(2, h, h, ci, generator=g).to(dev)
+        dy = torch.randn(2, h, h, co, generator=g).to(dev)
+        ref = ops.conv2d_wgrad(dy, x, co, ci, k, k, 1, k // 2, k // 2, 1)
+        flat = torch.zeros(co * k * k * ci + 3, device=dev)
+        out = flat[1:1 + co * k * k * ci].view(co, k, k, ci)
+        assert out.data_ptr() % 16 != 0
+        got = ops.conv2d_wgrad(dy, x, co, ci, k, k, 1, k // 2, k // 2, 1, out=out)
+        assert got.data_ptr() == out.data_ptr() and torch.equal(got, ref)
+        assert flat[0].item() == 0.0 and flat[-2:].abs().sum().item() == 0.0

@@ -8,6 +8,8 @@ device tensors (RCCL refuses two ranks on one device; the collectives' call site
   GMMN step : GMMNStep(group=True) on two shards ends with identical generator / pred_conv weights on both ranks, the
               generator equal to the average of the two single-process runs on the shards (replicas with
               parameter averaging), the classifier loss equal to the CE normalised over both shards.
+  GCN-context: GCNContextStep(group=True): both generators (GMMN and graph) identical on both ranks and equal to the mean of the
+              two single-shard runs.
 """
 import os
 import socket
@@ -100,6 +102,34 @@ def _gmmn(dev, image, label, table, ddp, steps=1):
             "pred_w": m.decoder.pred_conv.weight.detach().cpu().clone(), "pred_b": m.decoder.pred_conv.bias.detach().cpu().clone()}
 
 
+def _gcn(dev, image, label, table, ddp):
+    """GCNContextStep (train_context_GMMN_GCNcontext.py:239-457) with group=: the graph generator is a second replica"""
+    from zs3_amd import functional as Fz
+    from zs3_amd.gcn_trainer import GCNContextStep
+    from zs3_amd.modeling.gmmn import GMMNnetwork, GMMNnetwork_GCN
+    from zs3_amd.optim import SGD, Adam
+    from zs3_amd.utils.loss import SegmentationLosses
+    seen = [c for c in range(21) if c not in (10, 14)]
+    m = _tamed_model(sync_bn=False).to(dev).train()
+    torch.manual_seed(4)
+    gen, gcn = GMMNnetwork(300, 300, 256, 256).to(dev).train(), GMMNnetwork_GCN(300, 300, 256, 256).to(dev).train()
+    gen.model[2].p = 0.0
+    gcn.dropout.p = 0.0
+    Fz.manual_seed(78)
+    w = torch.ones(21, device=dev)
+    w[[10, 14]] = 100.0
+    groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+    opt, opt_g, opt_c = SGD(groups, momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4), Adam(gcn.parameters(), lr=2e-4)
+    crit = SegmentationLosses(weight=w, cuda=True, group=True if ddp else None).build_loss("ce")
+    step = GCNContextStep(m, gen, gcn, opt, opt_g, opt_c, crit, seen=seen, unseen=[10, 14], noise="cpu", GCN_weight=0.1,
+                          group=True if ddp else None)
+    torch.manual_seed(22)
+    gl, gcl, cl, _ = step(image, label, table=table)
+    torch.cuda.synchronize()
+    return {"losses": (gl, gcl, cl), "gen": [p.detach().cpu().clone() for p in gen.parameters()],
+            "gcn": [p.detach().cpu().clone() for p in gcn.parameters()], "pred_w": m.decoder.pred_conv.weight.detach().cpu().clone()}
+
+
 def _batch():
     import zs3_oracle as zo
     b = zo.make_synthetic_batch(4, 65, seed=31, with_label_emb=False)
@@ -125,7 +155,8 @@ def _worker(rank, world, port, outdir):
         image, label, seen_only, table = _batch()
         sl = slice(2 * rank, 2 * rank + 2)
         res = {"sup": _supervised(dev, image[sl].to(dev), label[sl].to(dev), ddp=True),
-               "gmmn": _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev), ddp=True)}
+               "gmmn": _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev), ddp=True),
+               "gcn": _gcn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev), ddp=True)}
         torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
@@ -174,3 +205,14 @@ def test_two_ranks_on_one_device_equal_the_single_process_step():
     for k in range(2):
         assert abs(r[k]["gmmn"]["losses"][0][1] - expect) < 1e-5 * abs(expect), (r[k]["gmmn"]["losses"], expect)
     assert not torch.equal(r[0]["gmmn"]["pred_w"], solo[0]["pred_w"])     # the classifier step used both shards' gradients
+    # ---------------- GCN-context step (configs[4] flow): two replicated generators, same exchange
+    for key in ("gen", "gcn"):
+        for a, b in zip(r[0]["gcn"][key], r[1]["gcn"][key]):
+            assert torch.equal(a, b), key
+    assert torch.equal(r[0]["gcn"]["pred_w"], r[1]["gcn"]["pred_w"])
+    solo_g = [_gcn(dev, image[2 * k:2 * k + 2].to(dev), seen_only[2 * k:2 * k + 2].to(dev), table.to(dev), ddp=False)
+              for k in range(2)]
+    for key in ("gen", "gcn"):
+        for p2, pa, pb in zip(r[0]["gcn"][key], solo_g[0][key], solo_g[1][key]):
+            assert _rel(p2, (pa + pb) / 2) < 1e-5, key
+    assert not torch.equal(r[0]["gcn"]["gcn"][0], solo_g[0]["gcn"][0])

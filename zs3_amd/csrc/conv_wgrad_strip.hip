@@ -279,6 +279,17 @@ __global__ __launch_bounds__(256) void strip_reduce_kernel(const f32x4* __restri
   }
 }
 
+// (dw may be a slice of a gradient bucket at any 4-byte offset -- parallel.GradSync's zero-copy hand-off: scalar form)
+__global__ __launch_bounds__(256) void strip_reduce1_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int splitk,
+                                                           long slab) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = part[i];
+#pragma unroll 4
+    for (int k = 1; k < splitk; ++k) s += part[(size_t)k * slab + i];
+    dw[i] = s;
+  }
+}
+
 struct StripPlan {
   int ok, splitk, steps_per_split, RL, lead, ring_steps, lds_bytes;
   long Q, workspace_floats;
@@ -289,7 +300,7 @@ StripPlan strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int st
   StripPlan s{};
   static const int enabled = getenv("ZS3_WGRAD_STRIP") ? atoi(getenv("ZS3_WGRAD_STRIP")) : 1;
   if (!enabled || KH != 3 || KW != 3 || stride != 1 || H != Ho || W != Wo || pad_h != dil || pad_w != dil) return s;
-  if (co < 64 || ci < 64 || (co * 9L * ci) % 4) return s;
+  if (co < 64 || ci < 64) return s;
   const int Wd = W + dil, Hd = H + dil;
   if (Wd <= 16) return s;
   const int R = dil * (Wd + 1);
@@ -344,7 +355,7 @@ extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, 
                                     int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
                                     const void* zero_page, void* stream) {
   if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
-  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 15)) return -2;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 3)) return -2;
   const StripPlan s = strip_plan(N, H, W, H, W, 3, 3, 1, dil, dil, dil, co_write, ci_write);
   if (!s.ok) return -7;
   if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
@@ -376,11 +387,17 @@ extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, 
   int rc = ZS3_LAUNCH_CHECK();
   if (rc) return rc;
   if (s.splitk > 1) {
-    const long n4 = a.slab / 4;
-    int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(strip_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(workspace),
-                       reinterpret_cast<f32x4*>(dw), n4, s.splitk, n4);
+    if (((uintptr_t)dw & 15) == 0 && a.slab % 4 == 0) {
+      const long n4 = a.slab / 4;
+      int blocks = (int)((n4 + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(strip_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(workspace),
+                         reinterpret_cast<f32x4*>(dw), n4, s.splitk, n4);
+    } else {
+      int blocks = (int)((a.slab + 255) / 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(strip_reduce1_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, a.slab, s.splitk, a.slab);
+    }
     rc = ZS3_LAUNCH_CHECK();
   }
   return rc;
