@@ -262,12 +262,12 @@ def main():
             by_cfg = {}
             for tag, flops, e0, e1, cfg in warm_prof:
                 by_cfg[cfg] = by_cfg.get(cfg, 0.0) + e0.elapsed_time(e1)
-            for group in ({31, 32}, {41, 42}):      # whole-tile / stream-K launches of the LDS-DMA kernel, both tile heights of the strip kernel
+            for group in ({41, 42},):      # both tile heights of the strip-resident kernel are one kernel
                 tot = sum(by_cfg.pop(c, 0.0) for c in group)
                 if tot:
                     by_cfg[min(group)] = tot
             best = max(by_cfg, key=by_cfg.get) if by_cfg else None
-            ops.PROFILE_CFGS = ({31, 32} if best == 31 else {41, 42} if best == 41 else {best}) if best is not None else None
+            ops.PROFILE_CFGS = ({41, 42} if best == 41 else {best}) if best is not None else None
             timed_prof = []
 
             def instrument(i):

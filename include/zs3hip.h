@@ -49,16 +49,7 @@ int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scal
                    int ncols, int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec,
                    int tile_cfg, const void* zero_page, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
-/* tile_cfg 31: wave-specialised 256x128 LDS-DMA kernel, one tile per workgroup.  tile_cfg 32: the same kernel as a stream-K
- * launch -- 256 persistent workgroups share the (tile, K step) iterations evenly (launches whose tile count is not a
- * multiple of the 256 CUs: the 138-tile layer-3 convolutions); partial tiles travel through a per-stream workspace that
- * the host registers once: workspace of zs3_conv_streamk_workspace_bytes() bytes (16-byte aligned) and
- * zs3_conv_streamk_flag_words() ZEROED 32-bit words; launches on one stream are serialised by the stream, different streams
- * need their own workspace.  attach(stream, NULL, 0, NULL) forgets the stream.  The last flag word is an error latch
- * (a workgroup gave up waiting for a partial tile): nonzero means the outputs of that launch are invalid. */
-long zs3_conv_streamk_workspace_bytes(void);
-int zs3_conv_streamk_flag_words(void);
-int zs3_conv_streamk_attach(void* stream, void* workspace, long workspace_bytes, void* flags);
+/* tile_cfg 31: wave-specialised 256x128 LDS-DMA kernel, one tile per workgroup. */
 /* tile_cfg 41 / 42 (csrc/conv_halo.hip): strip-resident kernel for stride-1, same-size multi-tap (3x3, dilated 3x3)
  * convolutions and their data gradients, 256- / 192-row tiles.  The input strip of a tile (tile rows + the halo the taps
  * reach, one channel chunk) is loaded ONCE, split to bf16 hi/lo by two producer waves and kept in LDS while all taps read

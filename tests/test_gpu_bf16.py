@@ -77,7 +77,7 @@ def test_conv_fwd_dgrad_wgrad_bf16(dev, case):
     xg = x.to(dev).permute(0, 2, 3, 1).contiguous()
     wp = ops.prep_weight(wt.to(dev))
     dyg = _pad_channels(dy.to(dev).permute(0, 2, 3, 1).contiguous(), 8)
-    cfgs = [0, 11, 14] + ([31, 32, 41, 42] if ci % 32 == 0 and co % 32 == 0 else [])
+    cfgs = [0, 11, 14] + ([31, 41, 42] if ci % 32 == 0 and co % 32 == 0 else [])
     for cfg in cfgs:
         y, st = ops.conv2d_fwd(xg, wp, s, pad, d, want_stats=True, prec=1, tile_cfg=cfg)
         assert rel(y.permute(0, 3, 1, 2), y_b) < BF16_KERNEL_TOL, (cfg, "fwd")

@@ -55,7 +55,7 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 5e-5
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 31, 32, 41, 42])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 31, 41, 42])
 def test_conv_every_tile_config(dev, cfg):
     """every kernel variant behind zs3_conv_igemm (register-staged tiles, wave-specialised, LDS-DMA) on ragged shapes:
     M tails, channel tails (304 -> 320, 21 -> 24), stride 2, dilation, fused epilogue and BN partial sums"""
@@ -92,7 +92,7 @@ def test_conv_every_tile_config(dev, cfg):
         assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 5e-5, (cfg, ci, co)
 
 
-@pytest.mark.parametrize("cfg", [11, 14, 31, 32, 41, 42])
+@pytest.mark.parametrize("cfg", [11, 14, 31, 41, 42])
 @pytest.mark.parametrize("mask", ["none", "from_y", "bits"])
 def test_dgrad_epilogue_bn_backward_sums(dev, cfg, mask):
     """zs3_conv_igemm_bnstats: the dgrad epilogue's (sum dz, sum dz*xhat) equal the separate zs3_bn_bwd_stats pass over the
@@ -478,45 +478,6 @@ def test_sampled_noise_is_keyed_on_the_sampled_pixel(dev):
     assert 0.0 <= z.min().item() and z.max().item() < 1.0 and abs(z.mean().item() - 0.5) < 0.05
     plain = ops.gather_cat_noise(a, idx, 300, 300, 600, 6, 1234)
     assert not torch.equal(plain[0, 300:], plain[2, 300:])   # without a key: per-row noise
-
-
-def test_streamk_launches_match_whole_tile_launches(dev):
-    """tile_cfg 32 (stream-K: 256 persistent workgroups share the (tile, K step) iterations, partial tiles handed over
-    through the per-stream workspace) against tile_cfg 31 (one tile per workgroup) on the launches it exists for: the
-    layer-3 shapes at B=16 (138 tiles) and B=8 (70 tiles: up to five workgroups per tile), the ASPP atrous branch (138
-    tiles, 576 K steps) -- forward with
-    BatchNorm partial sums, fused epilogue, dgrad; repeated launches (flag epochs), two streams at once."""
-    from zs3_amd import ops
-    shapes = [(16, 33, 1024, 256, 1, 1), (16, 33, 256, 256, 3, 1), (8, 33, 1024, 256, 1, 1), (16, 33, 2048, 256, 3, 12)]
-    old, ops.STREAMK = ops.STREAMK, True
-    assert ops.pick_tile(16 * 33 * 33, 256, 2304) == 32 and ops.pick_tile(16 * 33 * 33, 256, 1024) == 31   # the opt-in rule
-    ops.STREAMK = old
-    side = torch.cuda.Stream(device=dev)
-    for (n, h, ci, co, k, d) in shapes:
-        g = torch.Generator().manual_seed(h + ci + co + k)
-        x = torch.randn(n, h, h, ci, generator=g).to(dev)
-        wt = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(dev)
-        wp = ops.prep_weight(wt)
-        pad = d * (k // 2)
-        y31, st31 = ops.conv2d_fwd(x, wp, 1, pad, d, want_stats=True, tile_cfg=31)
-        for rep in range(3):
-            y32, st32 = ops.conv2d_fwd(x, wp, 1, pad, d, want_stats=True, tile_cfg=32)
-            assert rel(y32, y31) < 5e-6, (ci, co, k, rep)      # same products, fp32 sums grouped differently
-            assert rel(st32.double().sum(0), st31.double().sum(0)) < 1e-6
-        sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
-        res = torch.randn(n, h, h, co, generator=g).to(dev)
-        z31, _ = ops.conv2d_fwd(x, wp, 1, pad, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=31)
-        torch.cuda.synchronize()
-        with torch.cuda.stream(side):     # a second stream with its own workspace, concurrently
-            z32b, _ = ops.conv2d_fwd(x, wp, 1, pad, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=32)
-        z32, _ = ops.conv2d_fwd(x, wp, 1, pad, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=32)
-        torch.cuda.synchronize()
-        assert rel(z32, z31) < 5e-6 and rel(z32b, z31) < 5e-6
-        dy = torch.randn(n, h, h, co, generator=g).to(dev)
-        dx31 = ops.conv2d_dgrad(dy, wp, (h, h), 1, pad, d, tile_cfg=31)
-        dx32 = ops.conv2d_dgrad(dy, wp, (h, h), 1, pad, d, tile_cfg=32)   # runs as whole tiles where stream-K does not apply
-        assert rel(dx32, dx31) < 5e-6
-    assert ops.streamk_errors() == 0
 
 
 @pytest.mark.parametrize("chunks,c", [(69, 256), (1057, 64), (4161, 64), (16513, 72), (2048, 8)])

@@ -34,7 +34,6 @@ for (cnt, h, ci, co, k, s, d) in SHAPES:
     line = f"{cnt:2d}x {h:3d}^2 {ci:4d}->{co:4d} k{k} s{s} d{d:2d}: "
     for c0 in cfgs:
         c = c0
-        if c == 32 and ops.pick_tile(B * ho * ho if mode == "fwd" else B * h * h, co if mode == "fwd" else ci, (ci if mode == "fwd" else co) * k * k) not in (31, 32): c = 31
         if mode == "fwd": t = timeit(lambda: ops.conv2d_fwd(x, wp, s, pad, d, tile_cfg=c, want_stats=True))
         elif mode == "dgrad": t = timeit(lambda: ops.conv2d_dgrad(dy, wp, (h, h), s, pad, d, tile_cfg=c))
         else: t = timeit(lambda: ops.conv2d_wgrad(dy, x, co, ci, k, k, s, pad, pad, d))

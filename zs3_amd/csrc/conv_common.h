@@ -33,11 +33,6 @@ struct ConvArgs {
   // optional ReLU mask applied to `res` before it is added (sign bytes [M][ncols/4]): the skip gradient of a residual
   // block is (block-output gradient) * mask, taken straight from the block-output gradient instead of a stored copy
   const unsigned char* res_mbits;
-  // stream-K launches of the LDS-DMA kernel (tile_cfg 32): partial-tile slabs [grid][128 KB], one arrival flag per block
-  // (+ one error word), the launch's epoch (flags are compared with it, never reset)
-  float* sk_ws;
-  unsigned* sk_flags;
-  unsigned sk_epoch;
 };
 
 // conv_halo.hip: strip-resident 3x3 (any multi-tap, stride-1, same-size) convolution, tile_cfg 41 (256-row tiles) / 42 (192).
@@ -53,20 +48,10 @@ namespace {
 // Rows [0, nrows) of an LDS-staged output tile -> global memory as dwordx4 per lane, with the fused epilogue (affine,
 // residual, activation, accumulate).  `c4`/`r0` = this thread's column quad / first row, RPP = rows per pass.  When
 // p.bs_partial is set the thread also accumulates the BN-backward sums of its 4 columns over the rows it stores.
-// Stream-K owner: `sk` lists the partial tiles of the other workgroups that worked on this tile (raw fp32, row-major
-// [256][128] slabs); their rows are added to the staged rows before the fused epilogue, and the BatchNorm forward sums
-// (sum, sum of squares of the completed raw values) are accumulated here instead of from the accumulator registers.
-struct SkParts {
-  const float* part[4];
-  int n;          // number of partial tiles (0: none)
-  int row0;       // first tile row of the staged rows (0 or 128)
-  bool stats;     // accumulate fs_s / fs_q
-};
 template <int RPP>
 __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* ctile, int ldc, int row_base, int nrows,
                                                 int col, int c4, int r0, f32x4 sc, f32x4 sh, bool affine, bool vec,
-                                                f32x4& bs_s, f32x4& bs_q, const SkParts* sk = nullptr,
-                                                f32x4* fs_s = nullptr, f32x4* fs_q = nullptr) {
+                                                f32x4& bs_s, f32x4& bs_q) {
   f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
   const bool bstat = p.bs_partial != nullptr && vec && col < p.ncols;
   if (bstat) {
@@ -81,15 +66,6 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
     const int row = row_base + rr;
     if (row >= p.M || col >= p.ncols) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
-    if (sk) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)   // static indices: the pointers stay in registers
-        if (k < sk->n) v += *reinterpret_cast<const f32x4*>(sk->part[k] + (size_t)(sk->row0 + rr) * 128 + c4 * 4);
-      if (sk->stats) {
-        *fs_s += v;
-        *fs_q += v * v;
-      }
-    }
     if (affine) v = v * sc + sh;
     float* dst = p.y + (size_t)row * p.ldy + col;
     if (vec) {

@@ -20,8 +20,6 @@
 //
 // Replaces: every nn.Conv2d on the reference hot path (resnet.py:16-28,79,125-131; aspp.py:11-19,86,97;
 // decoder.py:12,16,20,26) and nn.Linear of the GMMN (gmmn.py:18,33) as a 1x1 conv.
-#include <map>
-#include <mutex>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -335,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 // their row, split them into bf16 hi/lo in registers (2 VALU per MFMA, hidden under the 32-cycle MFMAs) and
 // issue the three bf16 MFMAs per product.
 
-template <int PREC, bool SK>
+template <int PREC>
 __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   constexpr int BM = 256, BN = 128, TM = 2, TN = 4, NST = 3;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -352,57 +350,17 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   const long t_kernel0 = __builtin_readcyclecounter();
   long t_loop0 = 0, t_loop1 = 0;
 #endif
-  // ---- work of this block.  Plain launch: one output tile, all of its K steps.  Stream-K launch (SK): the grid is
-  // 8 x (gridDim/8) persistent blocks; the tiles are cut into 8 contiguous groups, one per XCD (block b runs on XCD b % 8),
-  // and inside a group the (tile, K step) iterations are dealt out evenly to the group's blocks in order.  A block walks
-  // its iteration range segment by segment; a segment that does not reach its tile's last K step is stored as a raw fp32
-  // partial tile ("slab") and published with an agent-scope release + flag; the block that holds the tile's last K steps
-  // owns the tile: it waits for the earlier segments (always blocks with a lower id on the same XCD, i.e. dispatched
-  // before it), adds their slabs in a fixed order and runs the fused epilogue.  That turns 138 tiles on 256 CUs (54 % of
-  // the chip) into 256 equal shares.
-  constexpr int SK_SEGS = SK ? 2 : 1;
-  long it = 0, it_end = 1;
-  int sk_xcd = 0, sk_slot = 0, sk_per = 1, sk_tile0 = 0;
-  long sk_w = 0;
-  if (SK) {
-    const int T = ((p.M + BM - 1) / BM) * ntn;
-    sk_xcd = blockIdx.x & 7;
-    sk_slot = blockIdx.x >> 3;
-    sk_per = gridDim.x >> 3;
-    sk_tile0 = (int)((long)sk_xcd * T / 8);
-    const int tile1 = (int)((long)(sk_xcd + 1) * T / 8);
-    sk_w = (long)(tile1 - sk_tile0) * KT_TILE;
-    it = (long)sk_slot * sk_w / sk_per;
-    it_end = (long)(sk_slot + 1) * sk_w / sk_per;
-  }
-  int tile = 0, kb = 0, KT = 0, mt = 0, nt = 0, m0 = 0, n0 = 0;
-  auto next_segment = [&]() -> bool {   // KT = K steps of the segment, kb = its first K step inside the tile
-    if (it >= it_end) return false;
-    if (SK) {
-      // LAST tile of the remaining range first: a block's share is [tail of tile A | head of tile B]; the head of B is a
-      // partial tile that B's owner (the next block) waits for, the tail of A waits for the previous block's head of A.
-      // Heads first = every block publishes before it starts waiting; tails first would chain the waits through all the
-      // blocks of the XCD.
-      tile = sk_tile0 + (int)((it_end - 1) / KT_TILE);
-      const long tile_it0 = (long)(tile - sk_tile0) * KT_TILE;
-      const long seg_it0 = it > tile_it0 ? it : tile_it0;
-      kb = (int)(seg_it0 - tile_it0);
-      KT = (int)(it_end - seg_it0);
-      it_end = seg_it0;
-    } else {
-      tile = xcd_remap(blockIdx.x, gridDim.x);
-      kb = 0;
-      KT = KT_TILE;
-      it = it_end;
-    }
-    mt = tile / ntn;
-    nt = tile - mt * ntn;
-    m0 = mt * BM;
-    n0 = nt * BN;
-    return true;
-  };
-  // ---- end of a segment: stream-K hand-off of a partial tile, or the tile's fused epilogue.  Runs in both wave roles
-  // with the same barrier sequence; only the consumers hold accumulators (`acc` is a dummy for the producers).
+  // ---- work of this block: one output tile, all of its K steps.  (Round 2 also ran this kernel as a stream-K launch -- 256
+  // persistent blocks sharing the (tile, K step) iterations, partial tiles through a per-stream workspace: -8 ... -28 % per
+  // isolated launch, +0.5 ms and occasional multi-ms stalls inside the training step, where the CUs a 138-tile launch
+  // leaves idle are taken by the weight-gradient streams.  The layers it applied to (3x3 of layer 3, ASPP) moved to the
+  // strip-resident kernel in round 3 and the path was removed.)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int kb = 0, KT = KT_TILE;
+  const int mt = tile / ntn, nt = tile - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  // ---- the tile's fused epilogue.  Runs in both wave roles with the same barrier sequence; only the consumers hold
+  // accumulators (`acc` is a dummy for the producers).
   auto finish_segment = [&](auto role, auto& acc) {
     constexpr bool IS_PRODUCER = decltype(role)::value;
     // the thread index is re-read through an opaque asm: everything the epilogue derives from it (column offsets, scale /
@@ -414,80 +372,8 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   constexpr int LDC = BN + 4;
   static_assert((BM / 2) * LDC * 4 <= NST * STAGE_BYTES, "half output tile must fit in the operand LDS");
   float* ctile = reinterpret_cast<float*>(dsm);
-  SkParts parts;
-  parts.n = 0;
-  parts.stats = false;
-  if (SK) {
-    // a partial tile travels as a raw fp32 row-major [256][128] slab (128 KB per block), written and read through the same
-    // LDS staging as the epilogue: coalesced 512-byte rows by all eight waves, nothing but the accumulators in registers
-    float* slabs = p.sk_ws;
-    constexpr size_t SLAB = (size_t)BM * BN;
-    if (kb + KT < KT_TILE) {   // not the tile's last K steps: publish the partial tile, somebody else owns the epilogue
-      float* dst = slabs + (size_t)blockIdx.x * SLAB;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        __syncthreads();
-        if constexpr (!IS_PRODUCER) if ((wm >> 1) == half) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int row = (wm & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                ctile[row * LDC + j * 32 + (lane & 31)] = acc[i][j][r];
-              }
-        }
-        __syncthreads();
-        for (int e = tid; e < (BM / 2) * (BN / 4); e += 512) {
-          const int rr = e / (BN / 4), c4q = e - rr * (BN / 4);
-          *reinterpret_cast<f32x4*>(dst + (size_t)(half * (BM / 2) + rr) * BN + c4q * 4) =
-              *reinterpret_cast<const f32x4*>(ctile + rr * LDC + c4q * 4);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();   // the LDS ring is refilled by the next segment
-      return;
-    }
-    parts.stats = p.stat_partial != nullptr;
-    if (kb > 0) {   // owner of a tile whose first K steps were done by earlier blocks of this XCD (at most 4: tiles >= 64)
-      // the earlier K steps of this tile belong to the slots right below this one (no block of a stream-K launch is
-      // without work: the host requires >= 8 iterations per block), at most 4 of them (tiles >= 64)
-      const long tile_start = (long)(tile - sk_tile0) * KT_TILE;
-      bool more = true;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ps = sk_slot - 1 - c;
-        const long ps_beg = (long)ps * sk_w / sk_per, ps_end = (long)(ps + 1) * sk_w / sk_per;
-        const bool use = more && ps >= 0 && ps_end > tile_start;
-        const int pb = ps * 8 + sk_xcd;
-        if (use && tid == 0) {
-          unsigned spins = 0;
-          while (__hip_atomic_load(p.sk_flags + pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 22)) {   // ~ a second: give up instead of hanging the GPU; the host checks this word
-              __hip_atomic_store(p.sk_flags + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
-          }
-        }
-        parts.part[c] = slabs + (size_t)(use ? pb : 0) * SLAB;
-        if (use) parts.n = c + 1;
-        if (!use || ps_beg <= tile_start) more = false;
-      }
-      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // one acquire after the last flag matched
-      __syncthreads();
-    }
-  }
-
   // ---- epilogue (consumers hold the accumulators; every DMA has landed and been consumed)
-  if (!SK && p.stat_partial) {
+  if (p.stat_partial) {
     float* red = reinterpret_cast<float*>(dsm);
     if constexpr (!IS_PRODUCER) {
 #pragma unroll
@@ -533,7 +419,6 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       if (p.shift) sh[e] = p.shift[col + e];
     }
   f32x4 bs_s = {0.f, 0.f, 0.f, 0.f}, bs_q = {0.f, 0.f, 0.f, 0.f};
-  f32x4 fs_s = {0.f, 0.f, 0.f, 0.f}, fs_q = {0.f, 0.f, 0.f, 0.f};   // stream-K: BatchNorm forward sums of the completed tile
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -549,18 +434,9 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
           }
     }
     __syncthreads();
-    if (SK) {
-      parts.row0 = half * (BM / 2);
-      store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q, &parts,
-                           &fs_s, &fs_q);
-    } else {
-      store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
-    }
+    store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
   }
   if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
-  if (SK && p.stat_partial) {   // same fixed-order block reduction as the BN-backward sums, into the forward partials
-    finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, fs_s, fs_q, p.stat_partial);
-  }
 #ifdef ZS3_CONV_TIMING
   if (p.act == 99 && blockIdx.x == 0 && tid == 0) {
     long* o = reinterpret_cast<long*>(const_cast<float*>(p.res)) + 24;
@@ -569,16 +445,10 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
     o[2] = t_loop1 - t_loop0;                         // K loop
   }
 #endif
-    __syncthreads();   // the epilogue's LDS tile is dead: the next segment's DMA may refill the ring
   };
   if (producer) {
     int no_acc = 0;
-    // at most SK_SEGS segments per block (stream-K launches have no more tiles than blocks: a block's share of the
-    // iterations spans at most two tiles); fully unrolled -- as a real loop the compiler keeps enough per-thread state
-    // alive across the K loop to spill to scratch, and a kernel with scratch pays ~1 ms per dispatch on this runtime
-#pragma unroll
-    for (int seg = 0; seg < SK_SEGS; ++seg) {
-      if (!next_segment()) break;
+    {
     const int pw = wave - 4;
       int lane_s = lane;
       asm volatile("" : "+v"(lane_s));
@@ -617,13 +487,6 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
         wstep[j] = ok ? 1 : 0;
       }
       int kh = 0, kw = 0, c0 = 0, kofs = 0;
-      if (SK) {   // the segment starts at K step kb of its tile
-        const int cpt = p.cin_pad >> 5, tap = kb / cpt;
-        c0 = (kb - tap * cpt) * 32;
-        kh = tap / p.KW;
-        kw = tap - kh * p.KW;
-        kofs = kb * 32;
-      }
       const float* abase[RA];
       int astep[RA];
       auto tap_addresses = [&]() {   // per-row gather base of the current filter tap (called when a tap starts)
@@ -738,12 +601,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
     }
   } else {
     f32x16 acc[TM][TN];
-    // at most SK_SEGS segments per block (stream-K launches have no more tiles than blocks: a block's share of the
-    // iterations spans at most two tiles); fully unrolled -- as a real loop the compiler keeps enough per-thread state
-    // alive across the K loop to spill to scratch, and a kernel with scratch pays ~1 ms per dispatch on this runtime
-#pragma unroll
-    for (int seg = 0; seg < SK_SEGS; ++seg) {
-      if (!next_segment()) break;
+    {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -877,56 +735,23 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   }
 }
 
-template <int PREC, bool SK>
+template <int PREC>
 int launch_dma_prec(const ConvArgs& a, int grid, hipStream_t st) {
   constexpr int LDS_BYTES = 3 * (256 + 128) * 128;   // 144 KB of the CU's 160 KB
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<PREC, SK>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<PREC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return -4;
     configured = true;
   }
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<PREC, SK>), dim3(grid), dim3(512), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<PREC>), dim3(grid), dim3(512), LDS_BYTES, st, a);
   return ZS3_LAUNCH_CHECK();
 }
 
 int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
   const int grid = ((a.M + 255) / 256) * ((a.ncols + 127) / 128);
-  return prec == 1 ? launch_dma_prec<1, false>(a, grid, st) : launch_dma_prec<3, false>(a, grid, st);
-}
-
-// ---- stream-K launches: per-stream workspace registered by the host (zs3_conv_streamk_attach)
-struct SkState {
-  float* ws;
-  unsigned* flags;
-  long ws_bytes;
-  unsigned epoch;
-};
-constexpr int SK_GRID = 256;                       // 8 XCDs x 32 persistent blocks, one per CU
-constexpr long SK_SLAB_BYTES = 256L * 128 * 4;     // one fp32 partial tile
-std::mutex sk_mutex;
-std::map<void*, SkState> sk_states;
-
-int launch_dma_sk(ConvArgs a, int prec, hipStream_t st) {
-  {
-    std::lock_guard<std::mutex> lock(sk_mutex);
-    auto itr = sk_states.find((void*)st);
-    if (itr == sk_states.end() || itr->second.ws_bytes < SK_GRID * SK_SLAB_BYTES) return -5;
-    {
-      const long tiles = (long)((a.M + 255) / 256) * ((a.ncols + 127) / 128);
-      const long kt = (long)a.KH * a.KW * (a.cin_pad / 32);
-      // a block's share spans at most two tiles, a tile at most five blocks, every block has work: anything else runs
-      // as a whole-tile launch
-      if (tiles > SK_GRID || tiles < 64 || tiles * kt < 8L * SK_GRID) return launch_dma(a, prec, st);
-    }
-    SkState& sk = itr->second;
-    if (++sk.epoch == 0u) sk.epoch = 1u;   // flags are zero-initialised: 0 never is a valid epoch
-    a.sk_ws = sk.ws;
-    a.sk_flags = sk.flags;
-    a.sk_epoch = sk.epoch;
-  }
-  return prec == 1 ? launch_dma_prec<1, true>(a, SK_GRID, st) : launch_dma_prec<3, true>(a, SK_GRID, st);
+  return prec == 1 ? launch_dma_prec<1>(a, grid, st) : launch_dma_prec<3>(a, grid, st);
 }
 
 template <int BM, int BN, int PIPE>
@@ -942,19 +767,6 @@ int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
 
 }  // namespace
 
-extern "C" long zs3_conv_streamk_workspace_bytes(void) { return SK_GRID * SK_SLAB_BYTES; }
-extern "C" int zs3_conv_streamk_flag_words(void) { return SK_GRID + 1; }
-extern "C" int zs3_conv_streamk_attach(void* stream, void* workspace, long workspace_bytes, void* flags) {
-  std::lock_guard<std::mutex> lock(sk_mutex);
-  if (!workspace || !flags) {
-    sk_states.erase(stream);
-    return 0;
-  }
-  if (workspace_bytes < SK_GRID * SK_SLAB_BYTES || ((uintptr_t)workspace & 15)) return -1;
-  sk_states[stream] = SkState{(float*)workspace, (unsigned*)flags, workspace_bytes, 0u};
-  return 0;
-}
-
 extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
   int bm = 128;
   if (tile_cfg == 0) {
@@ -963,7 +775,7 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
     if (blocks < 512) bm = 64;
   } else {
     int t = tile_cfg % 10;
-    bm = (tile_cfg == 31 || tile_cfg == 32 || tile_cfg == 41) ? 256
+    bm = (tile_cfg == 31 || tile_cfg == 41) ? 256
          : tile_cfg == 42 ? 192 : ((t == 3 || t == 4) ? 64 : 128);
   }
   return (M + bm - 1) / bm;
@@ -993,7 +805,6 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
   a.zero = (const float*)zero_page;
   a.bs_y = bs_y; a.bs_ldy = bs_ldy; a.bs_mean = bs_mean; a.bs_istd = bs_istd; a.bs_msc = bs_msc; a.bs_msh = bs_msh;
   a.bs_mbits = bs_mbits; a.bs_partial = bs_partial; a.res_mbits = res_mbits;
-  a.sk_ws = nullptr; a.sk_flags = nullptr; a.sk_epoch = 0u;
   a.stride_log2 = 0;
   while ((1 << a.stride_log2) < stride) ++a.stride_log2;
   if (a.M <= 0 || ncols <= 0) return 0;
@@ -1015,7 +826,6 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 13: return launch_cfg<64, 128, 2>(a, prec, st);
     case 14: return launch_cfg<64, 64, 2>(a, prec, st);
     case 31: return launch_dma(a, prec, st);
-    case 32: return launch_dma_sk(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);
   }

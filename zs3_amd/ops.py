@@ -18,39 +18,6 @@ PROFILE_CFGS = None   # optional set of tile_cfg values to restrict the recordin
 PROFILE_SAMPLE = None  # optional [stride, phase, counter]: record every stride-th eligible launch (an event pair costs host time)
 
 
-_streamk = {}
-
-
-def streamk_ready(device):
-    """Register (once per device and HIP stream) the workspace stream-K launches of the LDS-DMA kernel exchange partial
-    tiles through (zs3_conv_streamk_attach): 32 MB of slabs + one zeroed flag word per persistent workgroup."""
-    st = torch.cuda.current_stream(device)
-    key = (device.index, st.cuda_stream)
-    if key not in _streamk:
-        lib().zs3_conv_streamk_workspace_bytes.restype = ctypes.c_long
-        nbytes = lib().zs3_conv_streamk_workspace_bytes()
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-        flags = torch.zeros(lib().zs3_conv_streamk_flag_words(), dtype=torch.int32, device=device)   # zeroed on this stream
-        check(lib().zs3_conv_streamk_attach(ctypes.c_void_p(st.cuda_stream), P(ws), ctypes.c_long(nbytes), P(flags)),
-              "zs3_conv_streamk_attach")
-        _streamk[key] = (ws, flags, st)
-    return _streamk[key]
-
-
-def streamk_errors():
-    """Sum of the stream-K error latches (a workgroup gave up waiting for a partial tile): must be 0."""
-    return int(sum(int(f[-1].item()) for _, f, _ in _streamk.values()))
-
-
-# OFF by default.  Measured on MI355X (tools/probe/conv_bench.py 31,32; same-box A/B of bench.py): in isolation stream-K takes
-# the ASPP 3x3 2048->256 convolutions from 543 to 391-415 us (303 -> 397-439 TF) and the 3x3 256->256 of layer 3 from 96 to
-# 89 us, but inside the training step those launches are not alone -- the three ASPP branches run on three streams and every
-# dgrad runs next to the weight-gradient streams, so the CUs a 138-tile launch leaves idle are already used, and 256
-# persistent workgroups that wait for each other's partial tiles while sharing CUs cost more than they save:
-# 51.2 ms per step without, 51.7 ms with.  ZS3_STREAMK=1 enables the rule below.
-STREAMK = os.environ.get("ZS3_STREAMK", "0") == "1"
-
-
 WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"   # strip-resident weight gradient of the 3x3 stride-1 layers
 HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
 
@@ -103,15 +70,6 @@ def pick_tile(m, ncols, k=0):
     if ncols <= 64:
         return 14
     if m >= 8192 and k >= 512 and ncols >= 256:
-        # stream-K (tile_cfg 32) when whole 256x128 tiles leave > 12 % of the chip idle in the last round (138 tiles of the
-        # layer-3 convolutions and of the ASPP branches: 54 % of 256 CUs) and a tile has >= 72 K steps: every workgroup pays
-        # for ~3 partial-tile transfers of 128 KB (measured: -24 % on the ASPP 3x3 2048->256 with 576 K steps, -7 % on the
-        # 3x3 256->256 with 72, +23 % on the 1x1 1024->256 with 32); launches with more tiles than CUs (276 tiles of layer 4)
-        # would need more than two segments per workgroup: not built yet
-        tiles = ((m + 255) // 256) * ((ncols + 127) // 128)
-        rounds = (tiles + 255) // 256
-        if STREAMK and 64 <= tiles <= 256 and tiles / 256.0 < 0.88 and k // 32 >= 72:
-            return 32
         return 31
     if ncols >= 256 and 128 <= k <= 256:
         return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
@@ -212,7 +170,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     m = n * ho * wo
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
-        if HALO and tile_cfg in (31, 32) and kh * kw > 1:
+        if HALO and tile_cfg == 31 and kh * kw > 1:
             cand = pick_halo_tile(m, ncols, dgrad)
             if halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, cand):
                 tile_cfg = cand
@@ -222,11 +180,6 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     elif tile_cfg in (41, 42) and not halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil,
                                               dgrad, prec, tile_cfg):
         tile_cfg = 31              # not a stride-1 same-size multi-tap layer (or the strip does not fit)
-    if tile_cfg == 32:
-        if torch.cuda.is_current_stream_capturing():
-            tile_cfg = 31      # the workspace registration allocates: not inside a graph capture
-        else:
-            streamk_ready(x.device)
     stat = None
     if want_stats or bn_bwd is not None:
         mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
@@ -261,7 +214,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
         PROFILE.append(("conv_halo_kernel<%d, %d, %d>" % (prec, 256 if tile_cfg == 41 else 192, halo_ok(
                             x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg))
                         if tile_cfg in (41, 42) else
-                        "conv_igemm_dma<256,128,%d>" % prec if tile_cfg in (31, 32) else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
+                        "conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
 
