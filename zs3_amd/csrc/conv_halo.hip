@@ -280,11 +280,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
       a0n = (unsigned)(HALO_OFF_STRIP + (rc & 1) * strip_bytes + s0 * 64 + ((kh ^ ((s0 >> 2) & 3)) << 4));
       tbitn = rc < g.nch ? 1u << rt : 0u;   // the padding step of an odd K loop reads the zero row
     };
-    auto read_a = [&](int f) {
-      const unsigned addr = (vmask[f] & tbit) ? a0 + f * 2048 : zaddr;
-      a_hi[f] = *reinterpret_cast<const bf16x8*>(dsm + addr);
-      a_lo[f] = *reinterpret_cast<const bf16x8*>(dsm + (addr ^ 32u));
-    };
+    // A fragment f: its (masked) address is computed in one MFMA gap, its two reads are issued in two later gaps -- a gap
+    // hides ~32 cycles of issue (2 LDS reads or ~6 VALU); more in one gap delays the next MFMA
+    unsigned aaddr = 0u;
+    auto addr_a = [&](int f, unsigned base, unsigned bit) { aaddr = (vmask[f] & bit) ? base + f * 2048 : zaddr; };
+    auto read_a_hi = [&](int f) { a_hi[f] = *reinterpret_cast<const bf16x8*>(dsm + aaddr); };
+    auto read_a_lo = [&](int f) { a_lo[f] = *reinterpret_cast<const bf16x8*>(dsm + (aaddr ^ 32u)); };
     auto read_b = [&](int set, int slot, int j) {
       const unsigned addr = slot * HALO_BSLOT + boff + j * 2048;
       b_hi[set][j] = *reinterpret_cast<const bf16x8*>(dsm + addr);
@@ -322,11 +323,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? ah : al, pr == 0 ? b_hi[SET][j] : b_lo[SET][j],
                                                                 acc[i][j], 0, 0, 0);
-          if (m == 0) read_a((i + 2) % TM);
-          if (i == TM - 2 && m >= 1 && m <= TN) read_b(SET ^ 1, slot, m - 1);
-          if (i == 0 && m == 1) advance_read();
-          if (i == 0 && m == 2) next_window();
+          // fillers of this gap.  Sub-step i fetches fragment (i + 2) % TM (its address was computed a sub-step ago) and
+          // computes the address of fragment (i + 3) % TM; fragments fetched in sub-steps TM-2 and TM-1 belong to the next
+          // step, so sub-step TM-3 computes its address from the NEXT window (a0n / tbitn, ready since sub-step 0).
+          if (m == 0) read_a_hi((i + 2) % TM);
+          if (m == 1) read_a_lo((i + 2) % TM);
+          if (i == 0 && m == 2) advance_read();
+          if (i == 0 && m == NM - 1) next_window();
+          if (i == TM - 2 && m >= 2 && m < 2 + TN) read_b(SET ^ 1, slot, m - 2);
+          if (m == NM - 1 && i > 0) addr_a((i + 3) % TM, i == TM - 3 ? a0n : a0, i == TM - 3 ? tbitn : tbit);
           __builtin_amdgcn_sched_barrier(0);
+          if (m == NM - 1 && i == 0) {   // (after next_window(): TM = 3 needs the next window here)
+            addr_a(3 % TM, TM == 3 ? a0n : a0, TM == 3 ? tbitn : tbit);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
     };
@@ -336,10 +346,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     next_window();
     a0 = a0n;
     tbit = tbitn;
-    read_a(0);
-    read_a(1);
+    addr_a(0, a0, tbit);
+    read_a_hi(0);
+    read_a_lo(0);
+    addr_a(1, a0, tbit);
+    read_a_hi(1);
+    read_a_lo(1);
 #pragma unroll
     for (int j = 0; j < TN; ++j) read_b(0, 0, j);
+    addr_a(2 % TM, a0, tbit);   // what sub-step 0 fetches
     __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < NSR; s += 2) {
       step(std::integral_constant<int, 0>{});
