@@ -59,6 +59,15 @@ int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
  * Replaces the 3x3 nn.Conv2d of resnet.py:18-26, aspp.py:11-19 (atrous branches), decoder.py:15-24. */
 int zs3_conv_halo_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
                      int pad_h, int pad_w, int dil, int dgrad, int prec, int tile_cfg);
+/* Persistent pointwise convolution (csrc/conv_pw.hip, tile_cfg 51 = 256-row tiles, 52 = 128-row tiles) of the 1x1 stride-1
+ * layers and their input gradients: min(tiles, CUs) resident workgroups walk the output tiles; producer waves split the
+ * activations to bf16 hi/lo once and prefetch across tile boundaries, MFMA waves run the shared fused epilogue.
+ * zs3_conv_pw_ok: 1 when zs3_conv_igemm(..., tile_cfg 51 / 52) can run the layer (callers fall back to tile_cfg 31).
+ * zs3_conv_pw_set_wgs: resident workgroups per launch (default 256), returns the previous value.
+ * Replaces F.conv2d of the 1x1 nn.Conv2d at resnet.py:33-53, aspp.py:86-88. */
+int zs3_conv_pw_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
+                   int pad_h, int pad_w, int tile_cfg);
+int zs3_conv_pw_set_wgs(int wgs);
 /* zs3_conv_igemm (no affine / activation) with the two backward-pass epilogue fusions of the residual network:
  * (1) bn_partial != NULL: the epilogue also produces the BatchNorm-backward sums of the layer the output gradient belongs
  *     to: bn_partial[mtiles][2][ncols] = (sum dz, sum dz*xhat) per row tile, with dz = stored value * ReLU mask and
@@ -87,6 +96,15 @@ int zs3_conv_wgrad_strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int K
 int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int dil,
                          int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
                          const void* zero_page, void* stream);
+/* Pointwise weight gradient (csrc/conv_wgrad_strip.hip) of the stride-1 1x1 convolutions: dw[co][ci] = sum over the M = N*H*W
+ * positions of dy[p][co] * x[p][ci], with the strip kernel's division of labour (producer waves split both operands to bf16
+ * hi/lo once per (64 or 128)^2 tile and K step, MFMA waves read position-major fragments with ds_read_b64_tr_b16).
+ * zs3_conv_wgrad_pw_plan returns 1 when the layer is eligible (>= 64 channels on both sides) and the split-K factor /
+ * workspace floats of the launch, 0 otherwise (use zs3_conv_wgrad).  Channel arguments as zs3_conv_wgrad.
+ * Replaces convolution_backward(weight) of the 1x1 nn.Conv2d at resnet.py:33-53, aspp.py:11-19,86-88. */
+int zs3_conv_wgrad_pw_plan(long M, int co, int ci, int* splitk_out, long* workspace_floats);
+int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, float* workspace, long M, int co_read, int co_write,
+                      int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream);
 /* dw[co][kh][kw][ci] = sum_m dy[m][co] * x[gather(m,kh,kw)][ci]  (channels_last weight layout).
  * dy: [M][lddy] with co_read (multiple of 4) readable channels of which co_write rows are produced;
  * x likewise (ci_read / ci_write).  Split-K over pixels: call zs3_conv_wgrad_plan (same M = N*Ho*Wo, Wo, channel

@@ -666,6 +666,79 @@ def test_conv_halo_kernel_geometries(dev, geom, prec):
         assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5
 
 
+PW_CASES = [  # (n, h, w, cin, cout)
+    (2, 33, 33, 256, 1024), (2, 33, 33, 1024, 256), (1, 65, 65, 128, 512), (2, 17, 19, 64, 200), (1, 33, 33, 1280, 256),
+    (1, 129, 129, 64, 256), (3, 9, 11, 32, 128), (1, 33, 33, 304, 384),
+]
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("wgs", [256, 3])
+def test_conv_pointwise_persistent_kernel(dev, prec, wgs):
+    """csrc/conv_pw.hip (tile_cfg 51 / 52) against the round-2 kernels (same bf16 products, another summation order) and
+    fp64: forward with BN sums, fused affine + ReLU, plain dgrad, on row tails (M not a multiple of the tile), column tails
+    (200, 384 = 1.5 / 3 tiles), channel tails (304 -> 320) and short reductions (K = 32: one K step per tile).  wgs = 3 makes
+    every workgroup walk many tiles, so the cross-tile prefetch, the stage parity across tile boundaries and the barrier
+    bookkeeping are exercised at small sizes.  Epilogues that load per element (residual, accumulate, fused BN-backward
+    sums) are not this kernel's: ops.conv_igemm sends them to the other kernels even when tile_cfg 51 is asked for."""
+    from zs3_amd import ops
+    from zs3_amd._lib import I, lib
+    from zs3_amd.functional import _pad_channels
+    old = lib().zs3_conv_pw_set_wgs(I(wgs))
+    try:
+        for (n, h, w, ci, co) in PW_CASES:
+            g = torch.Generator().manual_seed(h * w + ci + co)
+            x = _pad_channels(torch.randn(n, h, w, ci, generator=g).to(dev), 32)
+            wt = (torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5).to(dev)
+            wp = ops.prep_weight(wt)
+            dy = _pad_channels(torch.randn(n, h, w, co, generator=g).to(dev), 32)
+            skip = torch.randn(n, h, w, ci, generator=g).to(dev)
+            sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
+            res = torch.randn(n, h, w, co, generator=g).to(dev)
+            base = 14
+            y0, st0 = ops.conv2d_fwd(x, wp, want_stats=True, tile_cfg=base, prec=prec)
+            z0, _ = ops.conv2d_fwd(x, wp, scale=sc, shift=sh, act=1, tile_cfg=base, prec=prec)
+            zr0, _ = ops.conv2d_fwd(x, wp, scale=sc, shift=sh, res=res, act=1, tile_cfg=base, prec=prec)
+            dx0 = ops.conv2d_dgrad(dy, wp, (h, w), tile_cfg=base, prec=prec)
+            da0 = ops.conv2d_dgrad(dy, wp, (h, w), tile_cfg=base, prec=prec, out=skip.clone(), accumulate=True)
+            ldx = ops._check_nhwc(x)
+            for cfg in (51, 52):
+                assert ops.pw_ok(x.shape, h, w, wp.cin_pad, min(ops._round_up(ci, 4), ldx), ldx, 1, 1, 1, 0, 0, cfg)
+                tag = (n, h, w, ci, co, cfg, wgs)
+                y, st = ops.conv2d_fwd(x, wp, want_stats=True, tile_cfg=cfg, prec=prec)
+                assert st.shape[0] == (n * h * w + (255 if cfg == 51 else 127)) // (256 if cfg == 51 else 128), (tag, "ran elsewhere")
+                assert rel(y, y0) < 2e-5, (tag, "fwd")
+                s0, s1 = st0.double().sum(0), st.double().sum(0)
+                assert ((s1 - s0).abs().max() / s0.abs().max()).item() < 1e-5, (tag, "bn sums")
+                z, _ = ops.conv2d_fwd(x, wp, scale=sc, shift=sh, act=1, tile_cfg=cfg, prec=prec)
+                assert rel(z, z0) < 2e-5, (tag, "affine + ReLU")
+                dx = ops.conv2d_dgrad(dy, wp, (h, w), tile_cfg=cfg, prec=prec)
+                assert rel(dx, dx0) < 2e-5, (tag, "dgrad")
+                # loading epilogues: served by the other kernels, same results
+                zr, _ = ops.conv2d_fwd(x, wp, scale=sc, shift=sh, res=res, act=1, tile_cfg=cfg, prec=prec)
+                assert rel(zr, zr0) < 2e-5, (tag, "residual epilogue")
+                da = ops.conv2d_dgrad(dy, wp, (h, w), tile_cfg=cfg, prec=prec, out=skip.clone(), accumulate=True)
+                assert rel(da, da0) < 2e-5, (tag, "accumulating dgrad")
+            if prec == 3 and n * h * w * ci * co <= 2 * 33 * 33 * 256 * 1024:
+                ref = F.conv2d(x[..., :ci].permute(0, 3, 1, 2).double().cpu(), wt.double().cpu())
+                y, _ = ops.conv2d_fwd(x, wp, tile_cfg=51, prec=3)
+                assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5
+    finally:
+        lib().zs3_conv_pw_set_wgs(I(old))
+    # a 3x3 or strided layer asked for tile_cfg 51 runs on the rule's kernel instead
+    assert not ops.pw_ok((1, 33, 33, 64), 33, 33, 64, 64, 64, 3, 3, 1, 1, 1, 51)
+    assert not ops.pw_ok((1, 33, 33, 64), 17, 17, 64, 64, 64, 1, 1, 2, 0, 0, 51)
+    # and the C ABI refuses the loading epilogues on tile_cfg 51 (-7) instead of computing them wrongly
+    from zs3_amd._lib import P, F as Fl, stream
+    x = torch.randn(1, 16, 16, 64, device=dev)
+    wp = ops.prep_weight(torch.randn(128, 64, 1, 1, device=dev))
+    out = torch.zeros(1, 16, 16, 128, device=dev)
+    rc = lib().zs3_conv_igemm(P(x), P(wp.f_pk), P(out), None, None, P(out), None, I(1), I(16), I(16), I(16), I(16), I(64), I(64),
+                              I(64), I(1), I(1), I(1), I(0), I(0), I(1), I(128), I(128), I(128), I(0), Fl(0.2), I(0), I(0), I(3),
+                              I(51), P(ops.zero_page(dev)), stream())
+    assert rc == -7
+
+
 # SURVEY.md section 8 a1: the 34 distinct convolution shapes of DeepLabv3+ (ResNet-101, output stride 16) at 513x513 --
 # (Cin, Cout, k, stride, dilation, input H = W).  The 7x7 stem has its own test below (it runs as a 7x1 conv over NHWC4 windows).
 NETWORK_CONV_SHAPES = [
@@ -739,6 +812,37 @@ def test_stem_conv_at_full_size(dev):
     assert rel(net.bn1.weight.grad, bn64.weight.grad) < 1e-4
     assert rel(net.bn1.bias.grad, bn64.bias.grad) < 1e-4
     assert rel(net.bn1.running_var, bn64.running_var) < 1e-5
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+def test_pointwise_wgrad_kernel(dev, prec):
+    """zs3_conv_wgrad_pw (1x1 stride-1 weight gradient: producer-split operands, transposing fragment reads) in all four tile
+    shapes (64/128 channels per side), with position tails (M not a multiple of 32, ranges past the end), channel tails
+    (1280 = 10 tiles, 192 = 1.5 tiles), operands that are channel slices of wider buffers, and split-K slabs -- against the
+    fp64 product (bf16x3) or the product of the bf16-rounded operands (prec 1)."""
+    from zs3_amd import ops
+    from zs3_amd._lib import I, lib
+    import ctypes
+    g = torch.Generator().manual_seed(5)
+    cases = [(2, 33, 33, 256, 1024, 0), (2, 33, 33, 1024, 256, 0), (1, 65, 65, 128, 64, 0), (1, 65, 65, 64, 128, 0),
+             (2, 33, 33, 64, 64, 0), (1, 33, 33, 1280, 256, 0), (3, 17, 19, 192, 320, 0), (1, 129, 129, 64, 256, 64)]
+    for (n, h, w, ci, co, extra) in cases:
+        sk, ws = ctypes.c_int(0), ctypes.c_long(0)
+        assert lib().zs3_conv_wgrad_pw_plan(I(n * h * w), I(co), I(ci), ctypes.byref(sk), ctypes.byref(ws)) == 1
+        xw = torch.randn(n, h, w, ci + extra, generator=g).to(dev)
+        dyw = torch.randn(n, h, w, co + extra, generator=g).to(dev)
+        x, dy = xw[..., extra // 2:extra // 2 + ci], dyw[..., :co]        # channel slices (ld > channels) when extra > 0
+        dw = ops.conv2d_wgrad(dy, x, co, ci, 1, 1, 1, 0, 0, 1, prec=prec)
+        a, b = dy.reshape(-1, co), x.reshape(-1, ci)
+        if prec == 1:
+            a, b = a.bfloat16(), b.bfloat16()
+        ref = a.double().t() @ b.double()
+        err = ((dw.view(co, ci).double() - ref).abs().max() / ref.abs().max()).item()
+        assert err < 2e-5, (n, h, w, ci, co, sk.value, err)
+    # not eligible: fewer than 64 channels on a side, or a handful of positions -> the round-2 kernels
+    assert lib().zs3_conv_wgrad_pw_plan(I(4356), I(48), I(256), None, None) == 0
+    assert lib().zs3_conv_wgrad_pw_plan(I(4356), I(256), I(21), None, None) == 0
+    assert lib().zs3_conv_wgrad_pw_plan(I(16), I(256), I(2048), None, None) == 0
 
 
 def test_wgrad_into_an_unaligned_bucket_slice(dev):

@@ -39,6 +39,9 @@ struct ConvArgs {
 // `bm` = 0 asks whether the launch is eligible at all (returns 1 / 0); otherwise launches and returns the HIP status.
 int halo_eligible(const ConvArgs& a, int bm, int prec);
 int launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st);
+// conv_pw.hip: persistent pointwise (1x1, stride 1) convolution, tile_cfg 51 (256-row tiles) / 52 (128-row tiles).
+int pw_eligible(const ConvArgs& a, int bm);
+int launch_pw(const ConvArgs& a, int bm, int prec, hipStream_t st);
 
 }  // namespace zs3conv
 using zs3conv::ConvArgs;

@@ -775,7 +775,7 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
     if (blocks < 512) bm = 64;
   } else {
     int t = tile_cfg % 10;
-    bm = (tile_cfg == 31 || tile_cfg == 41) ? 256
+    bm = (tile_cfg == 31 || tile_cfg == 41 || tile_cfg == 51) ? 256
          : tile_cfg == 42 ? 192 : ((t == 3 || t == 4) ? 64 : 128);
   }
   return (M + bm - 1) / bm;
@@ -828,6 +828,8 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 31: return launch_dma(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);
+    case 51: return zs3conv::launch_pw(a, 256, prec, st);     // -7: not a 1x1 stride-1 layer (zs3_conv_pw_ok)
+    case 52: return zs3conv::launch_pw(a, 128, prec, st);
   }
   return -3;
 }

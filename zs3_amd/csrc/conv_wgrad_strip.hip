@@ -269,6 +269,231 @@ __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1) weight gradient with the same division of labour:  dw[co, ci] = sum_p dy[p, co] * x[p, ci].
+//
+// conv_wgrad.hip's LDS-DMA kernel stages raw fp32 and lets every MFMA wave split its own fragments (6 VALU per MFMA, MFMA
+// pipe 18.5 % busy over the 1x1 layers).  Here four producer waves load a 32-position K step of both operands (plain loads,
+// three steps ahead), split to bf16 hi/lo once and write [position][channel] rows (the 320-byte rows of the strip kernel,
+// one array of rows per 64 channels); four consumer waves own (32 NCO) x (32 NCI) blocks of a (64 NCO) x (64 NCI) tile and
+// fetch position-major fragments with ds_read_b64_tr_b16.  Per 16-position sub-step a consumer issues 3 NCO NCI MFMAs
+// against 4 (NCO + NCI) transposing reads; the producers' VALU work per K step, (NCO + NCI) * 64 * 32 / 256 values per
+// lane, runs on the VALU pipe of the same SIMDs while the MFMA pipe multiplies.  One barrier per K step (two stages of LDS).
+// Replaces convolution_backward(weight) of the stride-1 1x1 nn.Conv2d of resnet.py:18-26,33-53, aspp.py:11-19,86-88.
+struct PwArgs {
+  const float* dy;
+  const float* x;
+  float* out;          // slab 0 (or dw itself when splitk == 1)
+  const float* zero;
+  long M;              // positions (N * H * W)
+  int co_read, co_write, ci_read, ci_write;
+  int lddy, ldx, ldw;
+  int steps_per_split; // 32-position K steps per range, multiple of 6
+  int tiles_co, tiles_ci;
+  long slab;
+};
+
+constexpr int PW_ARRAY = 32 * WS_ROW;   // one 64-channel array of a stage: 32 positions
+
+template <int PREC, int NCO, int NCI>
+__global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  constexpr int NARR = NCO + NCI;
+  constexpr int STAGE = NARR * PW_ARRAY;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntiles = p.tiles_co * p.tiles_ci;
+  const int split = b / ntiles;
+  b -= split * ntiles;
+  const int tco = b / p.tiles_ci, tci = b - tco * p.tiles_ci;
+  const int co0 = tco * 64 * NCO, ci0 = tci * 64 * NCI;
+  const int NSTEP = p.steps_per_split;
+  const long q_begin = (long)split * NSTEP * 32;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers (256 lanes: 16 rows x 16 channel quads)
+    const int prow = (tid - 256) >> 4, cq = tid & 15;
+    long q = q_begin + prow;    // position of this lane's next load (advances by 16 per half step)
+    bool cok[NARR];
+    const float* ptr[NARR];
+    long ld16[NARR];
+#pragma unroll
+    for (int a = 0; a < NARR; ++a) {
+      const bool isd = a < NCO;
+      const int c = (isd ? co0 + 64 * a : ci0 + 64 * (a - NCO)) + cq * 4;
+      const long ld = isd ? p.lddy : p.ldx;
+      cok[a] = c < (isd ? p.co_read : p.ci_read);
+      ptr[a] = (isd ? p.dy : p.x) + c + q * ld;
+      ld16[a] = 16 * ld;
+    }
+    f32x4 buf[3][2 * NARR];
+    auto load_step = [&](f32x4* dst) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool rok = q < p.M;
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) {
+          const float* src = rok && cok[a] ? ptr[a] : p.zero;
+          dst[h * NARR + a] = *reinterpret_cast<const f32x4*>(src);
+          ptr[a] += ld16[a];
+        }
+        q += 16;
+      }
+    };
+    auto conv_write = [&](const f32x4 v, unsigned char* row) {
+      u32x2 hi, lo;
+      unsigned h, l;
+      split_pair<PREC>(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
+      split_pair<PREC>(v[2], v[3], h, l); hi[1] = h; lo[1] = l;
+      *reinterpret_cast<u32x2*>(row + cq * 8) = hi;
+      if (PREC == 3) *reinterpret_cast<u32x2*>(row + 128 + cq * 8) = lo;
+    };
+    auto write_step = [&](const f32x4* src, int stage) {
+      unsigned char* s0 = dsm + (size_t)stage * STAGE + (size_t)prow * WS_ROW;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) conv_write(src[h * NARR + a], s0 + (size_t)a * PW_ARRAY + (size_t)h * 16 * WS_ROW);
+    };
+    // prologue: step 0 into stage 0; steps 1, 2, 3 requested into register sets 1, 2, 0
+    load_step(buf[0]);
+    write_step(buf[0], 0);
+    load_step(buf[1]);
+    load_step(buf[2]);
+    load_step(buf[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // B_0
+    // interval i (consumers multiply step i): write step i + 1 into the other stage, request step i + 4
+    for (int i0 = 0; i0 < NSTEP; i0 += 3) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        write_step(buf[(r + 1) % 3], (i0 + r + 1) & 1);
+        load_step(buf[(r + 1) % 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // B_{i+1}
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ consumers: transposing LDS reads + MFMA
+    f32x16 acc[NCO][NCI];
+#pragma unroll
+    for (int m = 0; m < NCO; ++m)
+#pragma unroll
+      for (int n = 0; n < NCI; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int bi = wave >> 1, bj = wave & 1;
+    const int cob = bi * 32 * NCO, cib = bj * 32 * NCI;       // this wave's channel offsets inside the tile
+    const int g = lane >> 4, l16 = lane & 15;
+    const unsigned lane_row = (unsigned)(8 * (g >> 1) + (l16 >> 2));
+    const unsigned lane_ch = (unsigned)(16 * (g & 1) + 4 * (l16 & 3));
+    // byte offset of block m's hi fragment inside a stage (sub-step 0): array, row, channel
+    unsigned a_off[NCO], b_off[NCI];
+#pragma unroll
+    for (int m = 0; m < NCO; ++m) {
+      const int c = cob + 32 * m;
+      a_off[m] = (unsigned)(c / 64) * PW_ARRAY + lane_row * WS_ROW + (unsigned)(c % 64 + lane_ch) * 2;
+    }
+#pragma unroll
+    for (int n = 0; n < NCI; ++n) {
+      const int c = cib + 32 * n;
+      b_off[n] = (unsigned)(NCO + c / 64) * PW_ARRAY + lane_row * WS_ROW + (unsigned)(c % 64 + lane_ch) * 2;
+    }
+    auto tr_pair = [&](const unsigned char* base, unsigned off) {
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off));
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off + 4 * WS_ROW));
+      return bf16x8{u[0], u[1], u[2], u[3], v[0], v[1], v[2], v[3]};
+    };
+    constexpr int NL = PREC == 3 ? 2 : 1;             // hi (and lo) planes
+    constexpr int NREAD = NL * NARR;                  // fragment reads per sub-step
+    bf16x8 fa[2][NCO][2], fb[2][NCI][2];              // [register set][block][hi, lo]
+    // read number k of a sub-step: dy blocks first (hi, lo), then x blocks
+    auto read_k = [&](auto setc, auto kc, const unsigned char* rows) {
+      constexpr int SET = decltype(setc)::value, K = decltype(kc)::value;
+      if constexpr (K < NREAD) {
+        constexpr int blk = K / NL, pl = K % NL;
+        if constexpr (blk < NCO)
+          fa[SET][blk][pl] = tr_pair(rows, a_off[blk] + 128 * pl);
+        else
+          fb[SET][blk - NCO][pl] = tr_pair(rows, b_off[blk - NCO] + 128 * pl);
+      }
+    };
+    // one 16-position sub-step on register set SET; the other set is filled from `rows` in the shadow of the MFMAs
+    auto substep = [&](auto setc, const unsigned char* rows) {
+      constexpr int SET = decltype(setc)::value;
+      constexpr int NMF = NCO * NCI * (PREC == 3 ? 3 : 1);
+      constexpr int PER = (NREAD + NMF - 1) / NMF;    // reads issued after each MFMA
+      auto reads_after = [&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, J * PER>{}, rows);
+        if constexpr (PER > 1) read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, J * PER + 1>{}, rows);
+        if constexpr (PER > 2) read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, J * PER + 2>{}, rows);
+        if constexpr (PER > 3) read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, J * PER + 3>{}, rows);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // product pl of block (m, n); consecutive MFMAs go to different accumulators (lo*hi, hi*lo, hi*hi over all blocks)
+      auto prod = [&](auto plc, auto mc, auto nc) {
+        constexpr int pl = decltype(plc)::value, m = decltype(mc)::value, n = decltype(nc)::value;
+        constexpr int j = pl * NCO * NCI + m * NCI + n;
+        constexpr int ia = PREC == 3 ? (pl == 0 ? 1 : 0) : 0, ib = PREC == 3 ? (pl == 1 ? 1 : 0) : 0;
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][m][ia], fb[SET][n][ib], acc[m][n], 0, 0, 0);
+        reads_after(std::integral_constant<int, j>{});
+      };
+      auto blocks = [&](auto plc) {
+        prod(plc, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if constexpr (NCI > 1) prod(plc, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        if constexpr (NCO > 1) {
+          prod(plc, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+          if constexpr (NCI > 1) prod(plc, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        }
+      };
+      blocks(std::integral_constant<int, 0>{});
+      if constexpr (PREC == 3) {
+        blocks(std::integral_constant<int, 1>{});
+        blocks(std::integral_constant<int, 2>{});
+      }
+    };
+    __builtin_amdgcn_s_barrier();   // B_0
+    asm volatile("" ::: "memory");
+    {
+      // sub-step 0 of step 0 into register set 0
+      const unsigned char* rows = dsm;
+#pragma unroll
+      for (int m = 0; m < NCO; ++m)
+#pragma unroll
+        for (int pl = 0; pl < NL; ++pl) fa[0][m][pl] = tr_pair(rows, a_off[m] + 128 * pl);
+#pragma unroll
+      for (int n = 0; n < NCI; ++n)
+#pragma unroll
+        for (int pl = 0; pl < NL; ++pl) fb[0][n][pl] = tr_pair(rows, b_off[n] + 128 * pl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NSTEP; ++i) {
+      const unsigned char* cur = dsm + (size_t)(i & 1) * STAGE;
+      const unsigned char* nxt = dsm + (size_t)((i + 1) & 1) * STAGE;
+      substep(std::integral_constant<int, 0>{}, cur + 16 * WS_ROW);   // multiply positions 0..15, fetch 16..31
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                   // B_{i+1}: the other stage holds step i + 1
+      asm volatile("" ::: "memory");
+      substep(std::integral_constant<int, 1>{}, nxt);                 // multiply positions 16..31, fetch step i + 1's 0..15
+    }
+    // ---- store this range's partial tile: out[split][co][ci]
+    float* out = p.out + (size_t)split * p.slab;
+#pragma unroll
+    for (int m = 0; m < NCO; ++m)
+#pragma unroll
+      for (int n = 0; n < NCI; ++n) {
+        const int ci = ci0 + cib + 32 * n + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + cob + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (co < p.co_write && ci < p.ci_write) out[(size_t)co * p.ldw + ci] = acc[m][n][r];
+        }
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void strip_reduce_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dw, long n4, int splitk,
                                                           long slab4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -338,7 +563,112 @@ StripPlan strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int st
   return s;
 }
 
+struct PwPlan {
+  int ok, nco, nci, splitk, steps_per_split, lds_bytes;
+  long workspace_floats;
+};
+
+PwPlan pw_plan(long M, int co, int ci) {
+  PwPlan s{};
+  static const int enabled = getenv("ZS3_WGRAD_PW") ? atoi(getenv("ZS3_WGRAD_PW")) : 1;
+  if (!enabled || co < 64 || ci < 64 || M < 32 * 12) return s;
+  s.nco = co >= 128 ? 2 : 1;
+  s.nci = ci >= 128 ? 2 : 1;
+  s.lds_bytes = 2 * (s.nco + s.nci) * PW_ARRAY;
+  const long steps = (M + 31) / 32;
+  const int tiles = ((co + 64 * s.nco - 1) / (64 * s.nco)) * ((ci + 64 * s.nci - 1) / (64 * s.nci));
+  // split-K: aim at ZS3_WGRAD_PW_WGS workgroups (one per CU: 512 threads, up to 80 KB of LDS), at least 12 K steps per range
+  static const int wgs = getenv("ZS3_WGRAD_PW_WGS") ? atoi(getenv("ZS3_WGRAD_PW_WGS")) : 256;
+  long want = (wgs + tiles - 1) / tiles;
+  long maxs = steps / 12;
+  if (maxs < 1) maxs = 1;
+  long sk = want < maxs ? want : maxs;
+  if (sk > 256) sk = 256;
+  long per = (steps + sk - 1) / sk;
+  per = (per + 5) / 6 * 6;
+  sk = (steps + per - 1) / per;
+  s.splitk = (int)sk;
+  s.steps_per_split = (int)per;
+  s.workspace_floats = sk > 1 ? sk * (long)co * ci : 0;
+  s.ok = 1;
+  return s;
+}
+
+template <int PREC, int NCO, int NCI>
+int launch_pw(const PwArgs& a, int grid, int lds, hipStream_t st) {
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pw_kernel<PREC, NCO, NCI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return -4;
+    configured = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_pw_kernel<PREC, NCO, NCI>), dim3(grid), dim3(512), lds, st, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+int reduce_slabs(const float* workspace, float* dw, long n, int splitk, hipStream_t st) {
+  if (((uintptr_t)dw & 15) == 0 && n % 4 == 0) {
+    const long n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(strip_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(workspace),
+                       reinterpret_cast<f32x4*>(dw), n4, splitk, n4);
+  } else {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(strip_reduce1_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, n, splitk, n);
+  }
+  return ZS3_LAUNCH_CHECK();
+}
+
 }  // namespace
+
+// Pointwise (1x1, stride 1, no padding) weight gradient: dw[co, ci] = sum over the M = N*H*W positions of dy[p, co] x[p, ci].
+// zs3_conv_wgrad_pw_plan returns 1 when the layer is eligible (>= 64 channels on both sides) with the split-K factor and the
+// workspace floats the launch needs, else 0 (use zs3_conv_wgrad).
+extern "C" int zs3_conv_wgrad_pw_plan(long M, int co, int ci, int* splitk_out, long* workspace_floats) {
+  const PwPlan s = pw_plan(M, co, ci);
+  if (splitk_out) *splitk_out = s.splitk;
+  if (workspace_floats) *workspace_floats = s.workspace_floats;
+  return s.ok;
+}
+
+extern "C" int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, float* workspace, long M, int co_read, int co_write,
+                                 int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream) {
+  if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 3)) return -2;
+  const PwPlan s = pw_plan(M, co_write, ci_write);
+  if (!s.ok) return -7;
+  if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
+  PwArgs a{};
+  a.dy = dy; a.x = x; a.zero = (const float*)zero_page;
+  a.M = M;
+  a.co_read = co_read; a.co_write = co_write; a.ci_read = ci_read; a.ci_write = ci_write;
+  a.lddy = lddy; a.ldx = ldx; a.ldw = ci_write;
+  a.steps_per_split = s.steps_per_split;
+  a.tiles_co = (co_write + 64 * s.nco - 1) / (64 * s.nco);
+  a.tiles_ci = (ci_write + 64 * s.nci - 1) / (64 * s.nci);
+  a.slab = (long)co_write * ci_write;
+  a.out = s.splitk > 1 ? workspace : dw;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = a.tiles_co * a.tiles_ci * s.splitk;
+  int rc;
+  const int key = (prec == 3 ? 4 : 0) + (s.nco == 2 ? 2 : 0) + (s.nci == 2 ? 1 : 0);
+  switch (key) {
+    case 0: rc = launch_pw<1, 1, 1>(a, grid, s.lds_bytes, st); break;
+    case 1: rc = launch_pw<1, 1, 2>(a, grid, s.lds_bytes, st); break;
+    case 2: rc = launch_pw<1, 2, 1>(a, grid, s.lds_bytes, st); break;
+    case 3: rc = launch_pw<1, 2, 2>(a, grid, s.lds_bytes, st); break;
+    case 4: rc = launch_pw<3, 1, 1>(a, grid, s.lds_bytes, st); break;
+    case 5: rc = launch_pw<3, 1, 2>(a, grid, s.lds_bytes, st); break;
+    case 6: rc = launch_pw<3, 2, 1>(a, grid, s.lds_bytes, st); break;
+    default: rc = launch_pw<3, 2, 2>(a, grid, s.lds_bytes, st); break;
+  }
+  if (rc) return rc;
+  if (s.splitk > 1) rc = reduce_slabs(workspace, dw, a.slab, s.splitk, st);
+  return rc;
+}
 
 // Eligibility + split-K plan of the strip-resident weight-gradient kernel: returns 1 and the workspace size (floats) when
 // zs3_conv_wgrad_strip can run the layer (3x3, stride 1, same size, pad = dilation, >= 64 channels on both sides, ring fits
@@ -386,19 +716,6 @@ extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, 
     hipLaunchKernelGGL((conv_wgrad_strip_kernel<3>), dim3(grid), dim3(512), s.lds_bytes, st, a);
   int rc = ZS3_LAUNCH_CHECK();
   if (rc) return rc;
-  if (s.splitk > 1) {
-    if (((uintptr_t)dw & 15) == 0 && a.slab % 4 == 0) {
-      const long n4 = a.slab / 4;
-      int blocks = (int)((n4 + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(strip_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(workspace),
-                         reinterpret_cast<f32x4*>(dw), n4, s.splitk, n4);
-    } else {
-      int blocks = (int)((a.slab + 255) / 256);
-      if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(strip_reduce1_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, a.slab, s.splitk, a.slab);
-    }
-    rc = ZS3_LAUNCH_CHECK();
-  }
+  if (s.splitk > 1) rc = reduce_slabs(workspace, dw, a.slab, s.splitk, st);
   return rc;
 }

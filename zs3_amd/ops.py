@@ -19,6 +19,9 @@ PROFILE_SAMPLE = None  # optional [stride, phase, counter]: record every stride-
 
 
 WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"   # strip-resident weight gradient of the 3x3 stride-1 layers
+PW = os.environ.get("ZS3_PW", "1") == "1"                      # persistent pointwise kernel for the 1x1 stride-1 layers
+PW_FORCE = int(os.environ.get("ZS3_PW_FORCE", "0"))           # 51 / 52: every eligible 1x1 layer on that tile (A/B runs)
+WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"         # producer-split weight gradient of the 1x1 stride-1 layers
 HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
 
 
@@ -74,6 +77,25 @@ def pick_tile(m, ncols, k=0):
     if ncols >= 256 and 128 <= k <= 256:
         return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
+
+
+def pick_pw_tile(m, ncols, k):
+    """Layers that go to the persistent pointwise kernel (tile_cfg 51: 256-row tiles, 52: 128-row tiles; csrc/conv_pw.hip),
+    0 = none (pick_tile's kernels)."""
+    if PW_FORCE:
+        return PW_FORCE
+    # forward table at B=16 (tools/probe/r3m.sh; rules' kernel / 51 / 52, us): 64->256 @129^2 125 / 86 / 80, 128->512 @65^2 75 / 68 / 62,
+    # 256->1024 @33^2 62 / 63 / 52, 512->2048 @33^2 159 / 142 / 144 -- the write-heavy short reductions, where the stores
+    # draining under the next tile pay; with K >= 1024 (1024->256: 52 / 60 / 64) the LDS-DMA kernel stays ahead
+    if ncols >= 256 and k <= 512 and m >= 8192:
+        return 52
+    return 0
+
+
+def pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, tile_cfg):
+    n, h, w_, _ = xshape
+    return bool(lib().zs3_conv_pw_ok(I(n), I(h), I(w_), I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw),
+                                     I(stride), I(pad_h), I(pad_w), I(tile_cfg)))
 
 
 _zero_pages = {}
@@ -168,6 +190,14 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     ldy = _check_nhwc(out)
     ldr = _check_nhwc(res) if res is not None else 0
     m = n * ho * wo
+    pw_epilogue = res is None and not accumulate and bn_bwd is None and res_mask_bits is None   # no per-element loads
+    if tile_cfg in (51, 52) and not (pw_epilogue and pw_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
+                                                           pad_w, tile_cfg)):
+        tile_cfg = 0               # not a 1x1 stride-1 layer, or an epilogue the persistent kernel leaves to the others
+    if tile_cfg == 0 and PW and kh * kw == 1 and pw_epilogue:
+        cand = pick_pw_tile(m, ncols, min(cin_pad, cin_valid))
+        if cand and pw_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, cand):
+            tile_cfg = cand
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
         if HALO and tile_cfg == 31 and kh * kw > 1:
@@ -214,6 +244,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
         PROFILE.append(("conv_halo_kernel<%d, %d, %d>" % (prec, 256 if tile_cfg == 41 else 192, halo_ok(
                             x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg))
                         if tile_cfg in (41, 42) else
+                        "conv_pw_kernel<%d, %d>" % (prec, 256 if tile_cfg == 51 else 128) if tile_cfg in (51, 52) else
                         "conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
     return out, stat
@@ -259,6 +290,13 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
         check(lib().zs3_conv_wgrad_strip(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(dil), I(co_read), I(cout),
                                          I(ci_read), I(cin), I(lddy), I(ldx), I(prec), P(zero_page(x.device)), stream()),
               "zs3_conv_wgrad_strip")
+        return dw
+    if WGRAD_PW and kh == 1 and kw == 1 and stride == 1 and pad_h == 0 and pad_w == 0 and (h, w_) == (ho, wo) and \
+            lib().zs3_conv_wgrad_pw_plan(I(n * h * w_), I(cout), I(cin), ctypes.byref(splitk), ctypes.byref(ws)):
+        # pointwise kernel (csrc/conv_wgrad_strip.hip): producer waves split both operands once, transposing fragment reads
+        work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
+        check(lib().zs3_conv_wgrad_pw(P(dy), P(x), P(dw), P(work), I(n * h * w_), I(co_read), I(cout), I(ci_read), I(cin),
+                                      I(lddy), I(ldx), I(prec), P(zero_page(x.device)), stream()), "zs3_conv_wgrad_pw")
         return dw
     lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
     work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
