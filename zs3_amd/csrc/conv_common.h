@@ -1,6 +1,8 @@
 // Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_halo.hip): the launch arguments and
 // the fused output-tile epilogue (affine / residual / activation / accumulate, BatchNorm partial sums).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace zs3conv {
@@ -143,6 +145,81 @@ __device__ __forceinline__ void finish_bwd_stats(const ConvArgs& p, float* red, 
       }
       dst[((size_t)mt * 2 + 0) * p.ncols + col] = ts;
       dst[((size_t)mt * 2 + 1) * p.ncols + col] = tq;
+    }
+  }
+}
+
+// Epilogues that only STORE (raw output, or affine + activation: the forward layers) can leave the accumulator registers
+// directly: in the 32x32 MFMA layout a lane holds one column (lane & 31) of 16 rows, so one store instruction writes two full
+// 128-byte row segments and the per-column scale / shift are per-lane scalars -- no LDS staging, no barrier, nothing waited
+// for.  Used by the persistent kernel (conv_pw.hip), whose four MFMA waves are alone on their CU: the staged path above cost them
+// ~14 us per 256x128 tile, this one ~5.  (conv_halo.hip's eight-wave staged epilogue gains nothing from it: 4.77 vs 4.76 ms over
+// the 3x3 forward layers, 46.5 vs 46.4 ms per step -- tools/probe/r3o.sh.)
+__host__ __device__ __forceinline__ bool direct_epilogue(const ConvArgs& p) {
+  return !p.res && !p.accumulate && !p.bs_partial && !p.res_mbits;
+}
+
+// Wave (wm, wn) of a 2x2 consumer grid holds rows wm*BM/2 + 32 i + .., columns wn*64 + 32 j + .. of the BM x BN tile at (m0, n0).
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void store_acc_direct(const ConvArgs& p, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                                 int lane) {
+  const int hh = lane >> 5, lr = lane & 31;
+  const bool full = m0 + BM <= p.M;              // no row tail in this tile (wave-uniform)
+  const bool affine = (p.scale != nullptr) || (p.shift != nullptr);
+  // element (i, j, r) of this lane: row m0 + lrow + 32 i + rofs(r), column n0 + lcol + 32 j; a uniform tile base plus a 32-bit
+  // lane offset
+  int opaque = 0;
+  asm volatile("" : "+v"(opaque));   // hipcc otherwise computes the 128 store addresses before the K loop and spills them
+  const int lrow = wm * (BM / 2) + 4 * hh + opaque, lcol = wn * 64 + lr;
+  float* const ybase = p.y + (size_t)m0 * p.ldy + n0;
+  // whole tiles (no row / column tail) in the three epilogue forms the network uses take the lean path: per element one v_add
+  // (uniform row offset + lane offset), optionally fma / max, one store -- mode tests per element cost 30 instructions
+  auto store_fast = [&](auto affc, auto reluc) {
+    constexpr bool AFF = decltype(affc)::value, RELU = decltype(reluc)::value;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + lcol + 32 * j;
+      const float sc = AFF && p.scale ? p.scale[col] : 1.f, sh = AFF && p.shift ? p.shift[col] : 0.f;
+      const unsigned lb = (unsigned)(lrow * p.ldy + lcol + 32 * j) * 4u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned ub = (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldy) * 4u;
+          float v = acc[i][j][r];
+          if (AFF) v = fmaf(v, sc, sh);
+          if (RELU) v = fmaxf(v, 0.f);
+          *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ybase) + (lb + ub)) = v;
+        }
+    }
+  };
+  const bool whole = full && n0 + BN <= p.ncols && (size_t)BM * p.ldy < (1u << 28);
+  if (whole && !affine && p.act == 0) {
+    store_fast(std::false_type{}, std::false_type{});
+  } else if (whole && affine && p.act == 1) {
+    store_fast(std::true_type{}, std::true_type{});
+  } else if (whole && affine && p.act == 0) {
+    store_fast(std::true_type{}, std::false_type{});
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + lcol + 32 * j;
+      const bool cok = col < p.ncols;
+      const int cc = cok ? col : 0;
+      const float sc = p.scale ? p.scale[cc] : 1.f, sh = p.shift ? p.shift[cc] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ro = lrow + 32 * i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = ro + (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r];
+          if (affine) v = fmaf(v, sc, sh);
+          if (p.act == 1) v = fmaxf(v, 0.f);
+          else if (p.act == 2) v = v > 0.f ? v : v * p.leak;
+          if (cok && (full || m0 + rr < p.M)) ybase[rr * p.ldy + lcol + 32 * j] = v;
+        }
+      }
     }
   }
 }

@@ -37,7 +37,7 @@ constexpr int PW_BN = 128;
 constexpr int PW_BSTAGE = 2 * 8192;                 // weights of a K step: two 16-channel sub-chunks x 128 columns x 64 B
 constexpr int PW_CTILE = 4 * PW_BN * 4;             // the epilogue's cross-wave column sums (BatchNorm partials)
 // -DZS3_PW_ABLATE=n builds (tools/probe/build_variant.sh; timing probes, wrong results): 1 = no epilogue work (barriers kept),
-// 2 = no MFMAs, 4 = no global loads, 8 = no split / LDS writes, 16 = output stores folded into 16 KB per tile
+// 2 = no MFMAs, 4 = no global loads, 8 = no split / LDS writes, 32 = no BatchNorm sums
 #ifndef ZS3_PW_ABLATE
 #define ZS3_PW_ABLATE 0
 #endif
@@ -232,7 +232,6 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     }
     __builtin_amdgcn_sched_barrier(0);
     float* const ctile = reinterpret_cast<float*>(dsm + OFF_CT);
-    const bool affine = (p.scale != nullptr) || (p.shift != nullptr);
     auto lds_barrier = [&]() {   // the epilogue's hazards are on the staging area only: do not drain the global stores
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -296,75 +295,14 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
           }
         }
       }
-      const int hh = lane >> 5;
-      const bool full = m0 + BM <= p.M;              // no row tail in this tile (wave-uniform)
-      // element (i, j, r) of this lane: row m0 + lrow + 32 i + rofs(r), column n0 + lcol + 32 j; a uniform tile base plus a
-      // 32-bit lane offset
-      int opaque = 0;
-      asm volatile("" : "+v"(opaque));   // hipcc otherwise computes the 128 store addresses before the K loop and spills them
-      const int lrow = wm * (BM / 2) + 4 * hh + opaque, lcol = wn * 64 + lr;
-      float* const ybase = p.y + (size_t)m0 * p.ldy + n0;
-      // whole tiles (no row / column tail) in the three epilogue forms the network uses take the lean path: per element one
-      // v_add (uniform row offset + lane offset), optionally fma / max, one store -- mode tests per element cost 30 instructions
-      auto store_fast = [&](auto affc, auto reluc) {
-        constexpr bool AFF = decltype(affc)::value, RELU = decltype(reluc)::value;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = n0 + lcol + 32 * j;
-          const float sc = AFF && p.scale ? p.scale[col] : 1.f, sh = AFF && p.shift ? p.shift[col] : 0.f;
-          const unsigned lb = (unsigned)(lrow * p.ldy + lcol + 32 * j) * 4u;
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const unsigned ub = (unsigned)((32 * i + (r & 3) + 8 * (r >> 2)) * p.ldy) * 4u;
-              float v = acc[i][j][r];
-              if (AFF) v = fmaf(v, sc, sh);
-              if (RELU) v = fmaxf(v, 0.f);
-              *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ybase) + ((ZS3_PW_ABLATE & 16) ? ((lb + ub) & 0x3FFCu) : lb + ub)) = v;
-            }
-        }
-      };
-      if (ZS3_PW_ABLATE & 64) {
-        if (m0 < 0) p.y[tid] = acc[0][0][0] + acc[TM - 1][1][5];
-        continue;
-      }
-      const bool whole = full && n0 + BN <= p.ncols && (size_t)BM * p.ldy < (1u << 28);
-      if (whole && !affine && p.act == 0) {
-        store_fast(std::false_type{}, std::false_type{});
-      } else if (whole && affine && p.act == 1) {
-        store_fast(std::true_type{}, std::true_type{});
-      } else if (whole && affine && p.act == 0) {
-        store_fast(std::true_type{}, std::false_type{});
-      } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = n0 + lcol + 32 * j;
-          const bool cok = col < p.ncols;
-          const int cc = cok ? col : 0;
-          const float sc = p.scale ? p.scale[cc] : 1.f, sh = p.shift ? p.shift[cc] : 0.f;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int ro = lrow + 32 * i;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int rr = ro + (r & 3) + 8 * (r >> 2);
-              float v = acc[i][j][r];
-              if (affine) v = fmaf(v, sc, sh);
-              if (p.act == 1) v = fmaxf(v, 0.f);
-              else if (p.act == 2) v = v > 0.f ? v : v * p.leak;
-              if (cok && (full || m0 + rr < p.M)) ybase[rr * p.ldy + lcol + 32 * j] = v;
-            }
-          }
-        }
-      }
+      store_acc_direct<TM, TN, BM, BN>(p, acc, m0, n0, wm, wn, lane);
     }
     for (int e = S; e < S3; ++e) __builtin_amdgcn_s_barrier();   // the producers' schedule is padded to a multiple of three
   }
 }
 
 bool pw_ok(const ConvArgs& a, int bm) {
-  if (a.res || a.accumulate || a.bs_partial || a.res_mbits) return false;   // epilogues that load per element
+  if (!direct_epilogue(a)) return false;   // epilogues that load per element
   if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad_h != 0 || a.pad_w != 0 || a.H != a.Ho || a.W != a.Wo) return false;
   if ((a.ldx & 3) || (a.cin_valid & 3) || (a.cin_pad & 31) || a.cin_pad < 32 || a.M <= 0) return false;
   return bm == 256 || bm == 128;
