@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16x3", "bf16"], default="bf16x3",
                     help="conv arithmetic: bf16x3 = fp32 semantics as three bf16 MFMA products (configs[1-3]); "
                          "bf16 = plain bf16 products, fp32 accumulate (configs[4])")
-    ap.add_argument("--sync-bn", type=int, default=0)
+    ap.add_argument("--sync-bn", type=int, default=-1,
+                    help="SynchronizedBatchNorm2d (cross-rank batch statistics, one fp64 all-reduce per layer and direction): "
+                         "-1 = the reference's rule, on iff more than one GPU (train_pascal.py:279); 0 / 1 force it")
     ap.add_argument("--gmmn-pipeline", type=int, default=1,
                     help="1: the next batch's feature pass overlaps the current batch's generator loop (GMMNStep.prefetch)")
     ap.add_argument("--ddp-selftest", action="store_true",
@@ -112,6 +114,8 @@ def main():
     from zs3_amd.utils.synthetic import make_batch
     from zs3_amd.gmmn_trainer import GMMNStep
 
+    if args.sync_bn < 0:
+        args.sync_bn = 1 if world > 1 else 0
     ops.PREC_DEFAULT = 1 if args.dtype == "bf16" else 3
     unseen = [10, 14]
     seen = [c for c in range(args.classes) if c not in unseen]

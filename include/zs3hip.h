@@ -131,6 +131,11 @@ int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, cons
 /* num_batches_tracked (nullable): BatchNorm's int64 step counter, incremented by the kernel.
    count_dev (nullable): device-resident sample count that overrides `count` (cross-rank SyncBN: the count is
    all-reduced together with the sums and never visits the host) */
+/* chunks == -1 (both finalize calls): `partial` is a SyncBN exchange buffer of zs3_bn_sync_pack -- fp64 [sum x C | sum of
+   squares (or second backward sum) x C | count] after its all-reduce; pass count_dev = the buffer's element 2C. */
+/* SyncBN (sync_batchnorm/batchnorm.py:60-67,101-122): this rank's per-channel fp64 totals of the [chunks][2][C] partial sums and
+   its sample count, written as the 2C+1 doubles ONE all-reduce carries across ranks. */
+int zs3_bn_sync_pack(const float* partial, int chunks, int C, double count, double* totals, void* stream);
 int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                         float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,

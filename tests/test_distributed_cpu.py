@@ -126,14 +126,14 @@ def _worker(rank, world, port, q):
         _zero_copy_and_global_ce(rank, world)
         # SyncBN statistics: global sums / count from per-rank chunk partials
         part = torch.arange(2 * 2 * 4, dtype=torch.float32).reshape(2, 2, 4) * (rank + 1)
-        tot, cnt = combine_bn_partials(part, 10 * (rank + 1))
-        # -> fp32 hi/lo "chunks" of the fp64 global sums + a 1-element fp64 count tensor
-        assert cnt.dtype == torch.float64 and cnt.item() == 30.0 and tot.shape == (2, 2, 4)
-        assert torch.equal(tot.double().sum(0), (torch.arange(16.).reshape(2, 2, 4).sum(0).double()) * 3)
+        buf, cnt = combine_bn_partials(part, 10 * (rank + 1))
+        # -> the fp64 exchange buffer [global sums (2 x C) | global count]; the count travels inside it
+        assert cnt is None and buf.dtype == torch.float64 and buf.shape == (2 * 4 + 1,) and buf[8].item() == 30.0
+        assert torch.equal(buf[:8].view(2, 4), (torch.arange(16.).reshape(2, 2, 4).sum(0).double()) * 3)
         big = torch.full((3, 2, 4), 1e8 / 3 + rank, dtype=torch.float32)     # sums that fp32 cannot hold exactly
-        tot, _ = combine_bn_partials(big, 1)
+        buf, _ = combine_bn_partials(big, 1)
         other = torch.full((3, 2, 4), 1e8 / 3 + (1 - rank), dtype=torch.float32)
-        assert torch.equal(tot.double().sum(0), big.double().sum(0) + other.double().sum(0))
+        assert torch.equal(buf[:8].view(2, 4), big.double().sum(0) + other.double().sum(0)) and buf[8].item() == 2.0
         # the GMMN step's exchange: several small tensors (one of them channels_last, one a transposed view) in ONE
         # collective, mean or sum, written back in place
         from zs3_amd.parallel import all_reduce_tensors

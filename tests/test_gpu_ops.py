@@ -666,6 +666,34 @@ def test_conv_halo_kernel_geometries(dev, geom, prec):
         assert rel(y.permute(0, 3, 1, 2), ref) < 5e-5
 
 
+def test_syncbn_exchange_buffer_finalize(dev):
+    """zs3_bn_sync_pack + the finalize kernels' chunks = -1 mode (the SyncBN path: pack -> all-reduce -> finalize) give exactly
+    what the finalize kernels compute from the partial sums themselves when nothing is added by other ranks, for the short and
+    the tall partial-sum shapes; with the buffer doubled (two identical ranks) the statistics are those of the doubled batch."""
+    from zs3_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for chunks, c in ((5, 64), (1100, 256), (69, 2048)):
+        part = torch.randn(chunks, 2, c, generator=g).to(dev)
+        part[:, 1].abs_().add_(1.0).mul_(50.0)
+        count = 37.0 * chunks
+        gamma, beta = torch.rand(c, generator=g).to(dev) + 0.5, torch.randn(c, generator=g).to(dev)
+        rm0, rv0 = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        rm1, rv1 = rm0.clone(), rv0.clone()
+        ref = ops.bn_fwd_finalize(part, count, gamma, beta, 1e-5, 0.1, rm0, rv0)
+        buf = ops.bn_sync_pack(part, count)
+        assert buf.dtype == torch.float64 and buf.shape == (2 * c + 1,) and buf[2 * c].item() == count
+        assert torch.equal(buf[:2 * c].view(2, c), part.double().sum(0)) or \
+            ((buf[:2 * c].view(2, c) - part.double().sum(0)).abs().max() / part.double().sum(0).abs().max()).item() < 1e-14
+        got = ops.bn_fwd_finalize(buf, None, gamma, beta, 1e-5, 0.1, rm1, rv1)
+        assert torch.equal(got, ref) and torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+        rb, gb = ops.bn_bwd_finalize(part, count, True), ops.bn_bwd_finalize(buf, None, True)
+        for a, b in zip(rb, gb):
+            assert torch.equal(a, b)
+        two = ops.bn_bwd_finalize(buf * 2, None, True)       # "two ranks": sums and count double, c1 / c2 (ratios) stay
+        assert torch.allclose(two[2], rb[2], rtol=1e-6, atol=0) and torch.allclose(two[3], rb[3], rtol=1e-6, atol=0)
+        assert torch.allclose(two[0], 2 * rb[0], rtol=1e-6) and torch.allclose(two[1], 2 * rb[1], rtol=1e-6)
+
+
 PW_CASES = [  # (n, h, w, cin, cout)
     (2, 33, 33, 256, 1024), (2, 33, 33, 1024, 256), (1, 65, 65, 128, 512), (2, 17, 19, 64, 200), (1, 33, 33, 1280, 256),
     (1, 129, 129, 64, 256), (3, 9, 11, 32, 128), (1, 33, 33, 304, 384),

@@ -136,6 +136,13 @@ __device__ __forceinline__ bool combine_partials(const float* partial, int chunk
   __shared__ double red[2][FIN_GROUPS][FIN_CH];
   const int tx = threadIdx.x & (FIN_CH - 1), ty = threadIdx.x / FIN_CH;
   c = blockIdx.x * FIN_CH + tx;
+  if (chunks < 0) {   // `partial` is the SyncBN exchange buffer: fp64 totals [sum x C | sum-of-squares x C | count] (zs3_bn_sync_pack)
+    if (ty != 0 || c >= C) return false;
+    const double* tot = reinterpret_cast<const double*>(partial);
+    s = tot[c];
+    q = tot[C + c];
+    return true;
+  }
   double ls = 0.0, lq = 0.0;
   if (c < C) {
 #pragma unroll 8
@@ -186,6 +193,21 @@ __global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_fwd_finalize_kernel(co
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
   }
+}
+
+// SyncBN: this rank's fp64 totals and sample count in the layout the all-reduce carries (one launch instead of a cast, a
+// reduction, a fill and two splits on the host side of the exchange)
+template <int FIN_CH, int FIN_GROUPS>
+__global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_sync_pack_kernel(const float* partial, int chunks, int C, double count,
+                                                                          double* out) {
+  int c;
+  double s, q;
+  const bool owner = combine_partials<FIN_CH, FIN_GROUPS>(partial, chunks, C, c, s, q);
+  if (owner) {
+    out[c] = s;
+    out[C + c] = q;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * C] = count;
 }
 
 // eval-mode affine from running statistics
@@ -482,6 +504,17 @@ extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, in
   int chunks;
   zs3_colstats_plan(M, C, &chunks, &a.rows_per_block);
   hipLaunchKernelGGL(colstats_kernel<1>, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_bn_sync_pack(const float* partial, int chunks, int C, double count, double* totals, void* stream) {
+  if (chunks <= 0 || C <= 0 || !totals) return -1;
+  if (chunks >= fin_tall_rows())
+    hipLaunchKernelGGL((bn_sync_pack_kernel<8, 128>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, chunks, C,
+                       count, totals);
+  else
+    hipLaunchKernelGGL((bn_sync_pack_kernel<32, 8>), dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+                       count, totals);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -334,11 +334,28 @@ def _count_args(count):
     return ctypes.c_double(count), P(None)
 
 
-def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None):
-    c = partial.shape[2]
+def _partial_args(partial, count):
+    """(pointer, chunks, C, host count, device count) of a finalize call: `partial` is the [chunks][2][C] fp32 partial sums, or
+    the fp64 SyncBN exchange buffer [2C + 1] (bn_sync_pack + all-reduce: chunks = -1, the count is its last element)."""
+    if partial.dtype == torch.float64:
+        c = (partial.numel() - 1) // 2
+        return partial, -1, c, ctypes.c_double(0.0), P(partial[2 * c:])
     chost, cdev = _count_args(count)
+    return partial, partial.shape[0], partial.shape[2], chost, cdev
+
+
+def bn_sync_pack(partial, count):
+    """-> fp64 [sum | second sum | count] (2C + 1) of this rank, the payload of the SyncBN all-reduce."""
+    c = partial.shape[2]
+    out = torch.empty(2 * c + 1, dtype=torch.float64, device=partial.device)
+    check(lib().zs3_bn_sync_pack(P(partial), I(partial.shape[0]), I(c), F(float(count)), P(out), stream()), "zs3_bn_sync_pack")
+    return out
+
+
+def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+    partial, chunks, c, chost, cdev = _partial_args(partial, count)
     out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # mean, invstd, scale, shift
-    check(lib().zs3_bn_fwd_finalize(P(partial), I(partial.shape[0]), I(c), chost, cdev, P(gamma), P(beta),
+    check(lib().zs3_bn_fwd_finalize(P(partial), I(chunks), I(c), chost, cdev, P(gamma), P(beta),
                                     F(eps), F(momentum), P(running_mean), P(running_var), P(out[0]), P(out[1]),
                                     P(out[2]), P(out[3]), P(num_batches_tracked), stream()), "zs3_bn_fwd_finalize")
     return out
@@ -391,13 +408,12 @@ def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None, m
 def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True):
     """-> (dgamma, dbeta, c1, c2).  dgamma / dbeta own their storage so that autograd can adopt them as .grad
     without a copy."""
-    c = partial.shape[2]
+    partial, chunks, c, chost, cdev = _partial_args(partial, count)
     dev = partial.device
     dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     cc = torch.empty((2, c), dtype=torch.float32, device=dev)
-    chost, cdev = _count_args(count)
-    check(lib().zs3_bn_bwd_finalize(P(partial), I(partial.shape[0]), I(c), chost, cdev, P(dgamma), P(dbeta),
+    check(lib().zs3_bn_bwd_finalize(P(partial), I(chunks), I(c), chost, cdev, P(dgamma), P(dbeta),
                                     P(cc[0]), P(cc[1]), I(int(use_batch_stats)), stream()), "zs3_bn_bwd_finalize")
     return dgamma, dbeta, cc[0], cc[1]
 

@@ -206,23 +206,24 @@ def all_reduce_tensors(tensors, group=None, average=False, force=False):
 
 
 def combine_bn_partials(partial, count, group=None):
-    """SyncBN statistics (batchnorm.py:60-67,101-122 of the vendored module: sum / sum-of-squares reduced
-    over replicas).  The per-chunk partial sums [chunks,2,C] are collapsed in fp64, the local sample count is
-    appended, and ONE fp64 all-reduce carries both; nothing visits the host.  Returns (partial', count') for
-    zs3_bn_*_finalize: partial' is the fp64 totals as an fp32 hi/lo pair of "chunks" [2,2,C] (the finalize
-    kernel re-adds them in fp64), count' a 1-element fp64 device tensor."""
+    """SyncBN statistics (batchnorm.py:60-67,101-122 of the vendored module: sum / sum-of-squares reduced over replicas).
+    One launch collapses the per-chunk partial sums [chunks,2,C] to fp64 totals and appends the local sample count
+    (zs3_bn_sync_pack), ONE fp64 all-reduce carries both, and zs3_bn_*_finalize read the reduced buffer directly -- two kernels
+    and a collective per layer and direction, nothing visits the host.  Returns (buffer, None): the fp64 exchange buffer
+    [2C + 1] that ops.bn_fwd_finalize / bn_bwd_finalize accept in place of the partial sums (the count travels inside it)."""
     if not FORCE_COLLECTIVES and (not dist.is_initialized() or dist.get_world_size(group) == 1):
         return partial, count
-    c = partial.shape[2]
-    buf = torch.empty(2 * c + 1, dtype=torch.float64, device=partial.device)
-    torch.sum(partial.double(), dim=0, out=buf[:2 * c].view(2, c))
-    buf[2 * c] = float(count)
+    if not partial.is_cuda:   # gloo tests on CPU tensors: same arithmetic, spelled in torch
+        c = partial.shape[2]
+        buf = torch.empty(2 * c + 1, dtype=torch.float64, device=partial.device)
+        torch.sum(partial.double(), dim=0, out=buf[:2 * c].view(2, c))
+        buf[2 * c] = float(count)
+    else:
+        from . import ops
+        buf = ops.bn_sync_pack(partial, count)
     if dist.is_initialized():
         dist.all_reduce(buf, group=group)
-    tot = buf[:2 * c].view(2, c)
-    hi = tot.float()
-    lo = (tot - hi.double()).float()
-    return torch.stack((hi, lo), 0), buf[2 * c:]
+    return buf, None
 
 
 def enable_sync_bn(module, group=None, enabled=True):
