@@ -577,8 +577,10 @@ PwPlan pw_plan(long M, int co, int ci) {
   s.lds_bytes = 2 * (s.nco + s.nci) * PW_ARRAY;
   const long steps = (M + 31) / 32;
   const int tiles = ((co + 64 * s.nco - 1) / (64 * s.nco)) * ((ci + 64 * s.nci - 1) / (64 * s.nci));
-  // split-K: aim at ZS3_WGRAD_PW_WGS workgroups (one per CU: 512 threads, up to 80 KB of LDS), at least 12 K steps per range
-  static const int wgs = getenv("ZS3_WGRAD_PW_WGS") ? atoi(getenv("ZS3_WGRAD_PW_WGS")) : 256;
+  // split-K: aim at ZS3_WGRAD_PW_WGS workgroups (512 threads, up to 80 KB of LDS: one per CU), at least 12 K steps per range.
+  // Inside the training step (same box, ms per step, tools/probe/ab_env.sh): 128 -> 46.12 / 46.06, 160 -> 46.43 / 46.37,
+  // 192 -> 47.59 / 47.56, 224 -> 47.55 / 47.52, 256 -> 46.35 / 46.16; alone 256 is the fastest (the whole pass 12.9 ms).
+  static const int wgs = getenv("ZS3_WGRAD_PW_WGS") ? atoi(getenv("ZS3_WGRAD_PW_WGS")) : 128;
   long want = (wgs + tiles - 1) / tiles;
   long maxs = steps / 12;
   if (maxs < 1) maxs = 1;
