@@ -33,4 +33,4 @@ class SynchronizedBatchNorm2d(BatchNorm2d):
             return self.sync_group if self.sync_group is not None else True
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.sync_group) < 2:
             return None
-        return self.sync_group if self.sync_group is not None else True
+        return self.sync_group if self.sync_group is not None else parallel.bn_group()

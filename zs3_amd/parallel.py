@@ -205,6 +205,23 @@ def all_reduce_tensors(tensors, group=None, average=False, force=False):
     return flat.numel() * flat.element_size()
 
 
+_bn_group = None
+
+
+def bn_group():
+    """The process group of the SyncBN statistics: a communicator of its own over all ranks (created once, collectively, by the
+    first synchronised BatchNorm forward).  The 208 tiny latency-critical all-reduces of a step sit on the main stream's
+    dependent chain; on the default group they would queue on the same RCCL stream behind the 60 MB gradient buckets that
+    GradSync launches from the weight-gradient stream while backward is still running.  `ZS3_BN_GROUP=0`: the default group."""
+    global _bn_group
+    import os
+    if os.environ.get("ZS3_BN_GROUP", "1") != "1" or not dist.is_initialized() or dist.get_world_size() < 2:
+        return True
+    if _bn_group is None:
+        _bn_group = dist.new_group()
+    return _bn_group
+
+
 def combine_bn_partials(partial, count, group=None):
     """SyncBN statistics (batchnorm.py:60-67,101-122 of the vendored module: sum / sum-of-squares reduced over replicas).
     One launch collapses the per-chunk partial sums [chunks,2,C] to fp64 totals and appends the local sample count
