@@ -174,6 +174,34 @@ def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
+_TILE_CHOICE, _MTILES = {}, {}
+
+
+def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec,
+                 pw_epilogue):
+    """tile_cfg of a conv launch: the caller's explicit choice where that kernel can run the launch, else the rules."""
+    if tile_cfg in (51, 52) and not (pw_epilogue and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
+                                                           pad_w, tile_cfg)):
+        tile_cfg = 0               # not a 1x1 stride-1 layer, or an epilogue the persistent kernel leaves to the others
+    if tile_cfg == 0 and PW and kh * kw == 1 and pw_epilogue:
+        cand = pick_pw_tile(m, ncols, min(cin_pad, cin_valid))
+        if cand and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, cand):
+            tile_cfg = cand
+    if tile_cfg == 0:
+        tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
+        if HALO and tile_cfg == 31 and kh * kw > 1:
+            cand = pick_halo_tile(m, ncols, dgrad)
+            if halo_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, cand):
+                tile_cfg = cand
+            elif cand == 41 and halo_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad,
+                                        prec, 42):
+                tile_cfg = 42      # the strip of a 256-row tile does not fit the LDS (ASPP, dilation 12): 192 rows do
+    elif tile_cfg in (41, 42) and not halo_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil,
+                                              dgrad, prec, tile_cfg):
+        tile_cfg = 31              # not a stride-1 same-size multi-tap layer (or the strip does not fit)
+    return tile_cfg
+
+
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
                scale=None, shift=None, res=None, want_stats=False, act=0, leak=0.2, accumulate=False, dgrad=False,
                prec=None, tile_cfg=0, bn_bwd=None, res_mask_bits=None):
@@ -191,28 +219,22 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     ldr = _check_nhwc(res) if res is not None else 0
     m = n * ho * wo
     pw_epilogue = res is None and not accumulate and bn_bwd is None and res_mask_bits is None   # no per-element loads
-    if tile_cfg in (51, 52) and not (pw_epilogue and pw_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
-                                                           pad_w, tile_cfg)):
-        tile_cfg = 0               # not a 1x1 stride-1 layer, or an epilogue the persistent kernel leaves to the others
-    if tile_cfg == 0 and PW and kh * kw == 1 and pw_epilogue:
-        cand = pick_pw_tile(m, ncols, min(cin_pad, cin_valid))
-        if cand and pw_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, cand):
-            tile_cfg = cand
-    if tile_cfg == 0:
-        tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
-        if HALO and tile_cfg == 31 and kh * kw > 1:
-            cand = pick_halo_tile(m, ncols, dgrad)
-            if halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, cand):
-                tile_cfg = cand
-            elif cand == 41 and halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad,
-                                        prec, 42):
-                tile_cfg = 42      # the strip of a 256-row tile does not fit the LDS (ASPP, dilation 12): 192 rows do
-    elif tile_cfg in (41, 42) and not halo_ok(x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil,
-                                              dgrad, prec, tile_cfg):
-        tile_cfg = 31              # not a stride-1 same-size multi-tap layer (or the strip does not fit)
+    # the kernel / tile choice depends on the launch geometry only: decided once per distinct launch (a training step repeats
+    # ~60 geometries 230 times; the eligibility questions below are C calls)
+    key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
+           HALO, HALO_BM, PW, PW_FORCE)
+    cached = _TILE_CHOICE.get(key)
+    if cached is not None:
+        tile_cfg = cached
+    else:
+        tile_cfg = _TILE_CHOICE[key] = _choose_tile(tile_cfg, x.shape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
+                                                    pad_w, dil, ncols, dgrad, prec, pw_epilogue)
     stat = None
     if want_stats or bn_bwd is not None:
-        mt = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
+        mkey = (m, ncols, tile_cfg)
+        mt = _MTILES.get(mkey)
+        if mt is None:
+            mt = _MTILES[mkey] = lib().zs3_conv_igemm_mtiles(I(m), I(ncols), I(tile_cfg))
         stat = torch.empty((mt, 2, ncols), dtype=torch.float32, device=x.device)
     prof = PROFILE is not None and (PROFILE_CFGS is None or tile_cfg in PROFILE_CFGS)
     if prof and PROFILE_SAMPLE is not None:
@@ -269,6 +291,9 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
     return (out, part) if kw.get("bn_bwd") is not None else out
 
 
+_WGRAD_PLAN = {}
+
+
 def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1, prec=None, ci_read=None, out=None):
     """dy: NHWC [N,Ho,Wo,>=cout]; x: NHWC [N,H,W,>=cin] -> dw [cout, kh, kw, cin] (channels_last weight storage)."""
     require_gpu(dy, x)
@@ -281,28 +306,37 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
     ci_read = ci_read or min(_round_up(cin, 4), ldx)
     dw = out if out is not None else torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == cout * kh * kw * cin
-    splitk, ws = ctypes.c_int(0), ctypes.c_long(0)
-    if WGRAD_STRIP and kh == 3 and kw == 3 and lib().zs3_conv_wgrad_strip_plan(
-            I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride), I(pad_h), I(pad_w), I(dil), I(cout), I(cin),
-            ctypes.byref(splitk), ctypes.byref(ws)):
+    # which kernel and how much split-K workspace: a function of the geometry, asked of the library once per distinct layer
+    key = (n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, WGRAD_STRIP, WGRAD_PW)
+    plan = _WGRAD_PLAN.get(key)
+    if plan is None:
+        splitk, ws = ctypes.c_int(0), ctypes.c_long(0)
+        if WGRAD_STRIP and kh == 3 and kw == 3 and lib().zs3_conv_wgrad_strip_plan(
+                I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride), I(pad_h), I(pad_w), I(dil), I(cout), I(cin),
+                ctypes.byref(splitk), ctypes.byref(ws)):
+            plan = ("strip", ws.value)
+        elif WGRAD_PW and kh == 1 and kw == 1 and stride == 1 and pad_h == 0 and pad_w == 0 and (h, w_) == (ho, wo) and \
+                lib().zs3_conv_wgrad_pw_plan(I(n * h * w_), I(cout), I(cin), ctypes.byref(splitk), ctypes.byref(ws)):
+            plan = ("pw", ws.value)
+        else:
+            lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
+            plan = ("gemm", ws.value)
+        _WGRAD_PLAN[key] = plan
+    kind, nws = plan
+    work = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    if kind == "strip":
         # strip-resident kernel (csrc/conv_wgrad_strip.hip): all nine taps from one LDS-resident strip of x
-        work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
         check(lib().zs3_conv_wgrad_strip(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(dil), I(co_read), I(cout),
                                          I(ci_read), I(cin), I(lddy), I(ldx), I(prec), P(zero_page(x.device)), stream()),
               "zs3_conv_wgrad_strip")
-        return dw
-    if WGRAD_PW and kh == 1 and kw == 1 and stride == 1 and pad_h == 0 and pad_w == 0 and (h, w_) == (ho, wo) and \
-            lib().zs3_conv_wgrad_pw_plan(I(n * h * w_), I(cout), I(cin), ctypes.byref(splitk), ctypes.byref(ws)):
+    elif kind == "pw":
         # pointwise kernel (csrc/conv_wgrad_strip.hip): producer waves split both operands once, transposing fragment reads
-        work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
         check(lib().zs3_conv_wgrad_pw(P(dy), P(x), P(dw), P(work), I(n * h * w_), I(co_read), I(cout), I(ci_read), I(cin),
                                       I(lddy), I(ldx), I(prec), P(zero_page(x.device)), stream()), "zs3_conv_wgrad_pw")
-        return dw
-    lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
-    work = torch.empty(ws.value, dtype=torch.float32, device=x.device) if ws.value else None
-    check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
-                               I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
-                               I(prec), P(zero_page(x.device)), stream()), "zs3_conv_wgrad")
+    else:
+        check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
+                                   I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
+                                   I(prec), P(zero_page(x.device)), stream()), "zs3_conv_wgrad")
     return dw
 
 
