@@ -69,7 +69,15 @@ def P(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device, as an integer.  Asked ~1000 times per training step: the raw
+    accessors cost 0.3 us, `torch.cuda.current_stream().cuda_stream` 10 us (3.4 + 3 ms of host time per step, forward + backward)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
