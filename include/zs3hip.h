@@ -57,6 +57,9 @@ int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
  * these arguments can run on tile_cfg 41 / 42 (the value is the kernel instantiation's strip-passes-per-step template argument;
  * 0: zs3_conv_igemm returns -7 for them, use tile_cfg 31).
  * Replaces the 3x3 nn.Conv2d of resnet.py:18-26, aspp.py:11-19 (atrous branches), decoder.py:15-24. */
+/* tile_cfg 141 / 142: the same kernel reading x STORED AS BF16 ([pixel][channel], ldx in bf16 elements, 8-channel granularity;
+ * prec = 1 only): the producers copy instead of converting -- half the input bytes, no conversion VALU (kernel-level result of
+ * round 3; the network's tensors are fp32). */
 int zs3_conv_halo_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
                      int pad_h, int pad_w, int dil, int dgrad, int prec, int tile_cfg);
 /* Persistent pointwise convolution (csrc/conv_pw.hip, tile_cfg 51 = 256-row tiles, 52 = 128-row tiles) of the 1x1 stride-1

@@ -209,3 +209,46 @@ def test_gcn_context_step_60_classes_bf16(dev, bf16_mode):
     print("bf16 gcn-context 60 classes:", (gl, gl_r), (gcl, gcl_r), (cl, cl_r))
     assert out.shape == (4, classes, 65, 65) and step.last_num_clusters > 100
     assert abs(gl - gl_r) < 3e-2 * abs(gl_r) and abs(gcl - gcl_r) < 3e-2 * abs(gcl_r) and abs(cl - cl_r) < 3e-2 * abs(cl_r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(2, 33, 33, 256, 256, 1), (1, 65, 65, 128, 128, 1), (1, 33, 33, 512, 512, 2), (1, 33, 33, 304, 256, 1),
+                                  (1, 129, 129, 64, 64, 1)])
+def test_strip_kernel_reads_bf16_stored_input(geom):
+    """tile_cfg 141 / 142: the strip-resident kernel with its input STORED as bf16 (the producers copy instead of converting).
+    The fp32-input kernel in plain-bf16 mode rounds the same values to the same bf16 operands and multiplies them in the same
+    order, so on bf16-representable inputs the two must agree bit for bit -- forward with BN sums and the fused epilogue, and the
+    data gradient with accumulation.  Anything else (fp32 storage, bf16x3, a layer the strip kernel does not serve) is refused."""
+    from zs3_amd import ops
+    from zs3_amd.functional import _pad_channels
+    dev = torch.device("cuda:0")
+    n, h, w, ci, co, d = geom
+    g = torch.Generator().manual_seed(h + ci + d)
+    xb = _pad_channels(torch.randn(n, h, w, ci, generator=g).to(dev), 32).bfloat16()
+    xb = xb if xb.shape[-1] == ci else xb[..., :ci]
+    wt = (torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).to(dev)
+    wp = ops.prep_weight(wt)
+    dyb = _pad_channels(torch.randn(n, h, w, co, generator=g).to(dev), 32).bfloat16()
+    sc, sh = (torch.rand(co, generator=g) + 0.5).to(dev), torch.randn(co, generator=g).to(dev)
+    res = torch.randn(n, h, w, co, generator=g).to(dev)
+    skip = torch.randn(n, h, w, ci, generator=g).to(dev)
+    ran = 0
+    for cfg in (41, 42):
+        if not ops.halo_ok(xb.shape, h, w, wp.cin_pad, min(ops._round_up(ci, 4), ops._check_nhwc(xb)), ops._check_nhwc(xb), 3, 3, 1, d, d,
+                           d, False, 1, cfg):
+            continue
+        ran += 1
+        y0, st0 = ops.conv2d_fwd(xb.float(), wp, 1, d, d, want_stats=True, tile_cfg=cfg, prec=1)
+        y1, st1 = ops.conv2d_fwd(xb, wp, 1, d, d, want_stats=True, tile_cfg=cfg + 100, prec=1)
+        assert torch.equal(y0, y1) and torch.equal(st0, st1), (cfg, "forward")
+        z0, _ = ops.conv2d_fwd(xb.float(), wp, 1, d, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=cfg, prec=1)
+        z1, _ = ops.conv2d_fwd(xb, wp, 1, d, d, scale=sc, shift=sh, res=res, act=1, tile_cfg=cfg + 100, prec=1)
+        assert torch.equal(z0, z1), (cfg, "fused epilogue")
+        dx0 = ops.conv2d_dgrad(dyb.float(), wp, (h, w), 1, d, d, tile_cfg=cfg, prec=1, out=skip.clone(), accumulate=True)
+        dx1 = ops.conv2d_dgrad(dyb, wp, (h, w), 1, d, d, tile_cfg=cfg + 100, prec=1, out=skip.clone(), accumulate=True)
+        assert torch.equal(dx0, dx1), (cfg, "dgrad")
+    assert ran >= 1
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(xb, wp, 1, d, d, tile_cfg=141, prec=3)          # bf16x3 needs the fp32 values
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(xb, wp, 1, d, d, tile_cfg=41, prec=1)           # the fp32-input kernels do not read bf16 storage

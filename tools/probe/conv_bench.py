@@ -28,6 +28,7 @@ tot = {c: 0.0 for c in cfgs}; totfl = 0.0
 for (cnt, h, ci, co, k, s, d) in SHAPES:
     x = torch.randn(B, h, h, ci, device=dev); wt = torch.randn(co, ci, k, k, device=dev) * 0.02
     wp = ops.prep_weight(wt); pad = d * (k // 2)
+    if os.environ.get("ZS3_A16") == "1": x = x.bfloat16()      # bf16-stored input (tile_cfg 141 / 142, ZS3_PREC=1)
     ho = ops.conv_out_size(h, k, s, pad, d)
     fl = 2.0 * B * ho * ho * co * ci * k * k
     dy = torch.randn(B, ho, ho, (co + 7) // 8 * 8, device=dev)[..., :co]

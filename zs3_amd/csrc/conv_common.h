@@ -21,6 +21,7 @@ struct ConvArgs {
   int KH, KW, stride, pad_h, pad_w, dil;
   int ncols, ldw, ldy, ldr, M;
   int act, accumulate, dgrad, stride_log2;
+  int x_bf16;   // x is stored as bf16 (strip-resident kernel, tile_cfg 141 / 142); ldx then counts bf16 elements
   float leak;
   // optional BatchNorm-backward statistics of the layer whose output gradient this launch produces (dgrad epilogue):
   // bs_partial[mtile][2][ncols] = (sum dz, sum dz*xhat) with dz = stored value * ReLU mask, xhat = (bs_y - mean) * istd

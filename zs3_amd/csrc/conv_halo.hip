@@ -67,8 +67,11 @@ constexpr int HALO_MAXP = 3;
 #define HT_STORE(w)
 #endif
 
-template <int PREC, int BM, int NPG>
+// A16: the input tensor is stored as bf16 ([pixel][channel], ldx in elements) -- plain-bf16 arithmetic only (PREC = 1): the producers
+// copy 16 bytes per lane and row from L2 into the strip, no conversion, half the bytes.
+template <int PREC, int BM, int NPG, bool A16 = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const HaloGeom g) {
+  static_assert(!A16 || PREC == 1, "bf16-stored input: plain bf16 products only");
   constexpr int BN = 128, TM = BM / 64, TN = 2, CH = PREC == 3 ? 16 : 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
@@ -111,11 +114,17 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
       long q = q0 + pass * 64 + prow;
       q = q < 0 ? 0 : (q >= Mtot ? Mtot - 1 : q);
       const int ch0 = c * CH + cq * (CH / 4);
-      const float* src = p.x + q * p.ldx + ch0;
+      if constexpr (A16) {   // 8 bf16 channels = 16 bytes per lane
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(p.x) + q * p.ldx + ch0;
+        const void* s = ch0 < p.cin_valid ? static_cast<const void*>(src) : static_cast<const void*>(p.zero);
+        dstv[0] = *reinterpret_cast<const f32x4*>(s);
+      } else {
+        const float* src = p.x + q * p.ldx + ch0;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const float* s = ch0 + 4 * v < p.cin_valid ? src + 4 * v : p.zero;
-        dstv[v] = *reinterpret_cast<const f32x4*>(s);
+        for (int v = 0; v < NV; ++v) {
+          const float* s = ch0 + 4 * v < p.cin_valid ? src + 4 * v : p.zero;
+          dstv[v] = *reinterpret_cast<const f32x4*>(s);
+        }
       }
     };
     auto write_pass = [&](const f32x4 (&srcv)[NV], int pass, int sb) {
@@ -130,6 +139,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
         const int o = (((cq >> 1) ^ sw) << 4) + (cq & 1) * 8;
         *reinterpret_cast<u32x2*>(row + o) = hi;
         *reinterpret_cast<u32x2*>(row + (o ^ 32)) = lo;
+      } else if constexpr (A16) {
+        u32x4 hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = __float_as_uint(srcv[0][e]);
+        *reinterpret_cast<u32x4*>(row + ((cq ^ sw) << 4)) = hi;
       } else {
         u32x4 hi;
         hi[0] = cvt_pk_bf16(srcv[0][0], srcv[0][1]);
@@ -468,25 +482,25 @@ bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   return true;
 }
 
-template <int PREC, int BM, int NPG>
+template <int PREC, int BM, int NPG, bool A16 = false>
 int launch_halo_n(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<PREC, BM, NPG>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<PREC, BM, NPG, A16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return -4;
     configured = true;
   }
   const int grid = ((a.M + BM - 1) / BM) * ((a.ncols + 127) / 128);
-  hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG>), dim3(grid), dim3(512), g.lds_bytes, st, a, g);
+  hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG, A16>), dim3(grid), dim3(512), g.lds_bytes, st, a, g);
   return ZS3_LAUNCH_CHECK();
 }
-template <int PREC, int BM>
+template <int PREC, int BM, bool A16 = false>
 int launch_halo_t(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
   switch (g.npg) {
-    case 1: return launch_halo_n<PREC, BM, 1>(a, g, st);
-    case 2: return launch_halo_n<PREC, BM, 2>(a, g, st);
-    case 3: return launch_halo_n<PREC, BM, 3>(a, g, st);
+    case 1: return launch_halo_n<PREC, BM, 1, A16>(a, g, st);
+    case 2: return launch_halo_n<PREC, BM, 2, A16>(a, g, st);
+    case 3: return launch_halo_n<PREC, BM, 3, A16>(a, g, st);
   }
   return -7;
 }
@@ -501,6 +515,10 @@ int zs3conv::halo_eligible(const ConvArgs& a, int bm, int prec) {   // 0: not el
 int zs3conv::launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   HaloGeom g;
   if (!halo_geometry(a, bm, prec, &g)) return -7;
+  if (a.x_bf16) {   // bf16-stored input (tile_cfg 141 / 142): plain-bf16 products, 8-channel granularity
+    if (prec != 1 || (a.ldx & 7) || (a.cin_valid & 7)) return -7;
+    return bm == 256 ? launch_halo_t<1, 256, true>(a, g, st) : launch_halo_t<1, 192, true>(a, g, st);
+  }
   if (bm == 256) return prec == 1 ? launch_halo_t<1, 256>(a, g, st) : launch_halo_t<3, 256>(a, g, st);
   return prec == 1 ? launch_halo_t<1, 192>(a, g, st) : launch_halo_t<3, 192>(a, g, st);
 }

@@ -775,8 +775,8 @@ extern "C" int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg) {
     if (blocks < 512) bm = 64;
   } else {
     int t = tile_cfg % 10;
-    bm = (tile_cfg == 31 || tile_cfg == 41 || tile_cfg == 51) ? 256
-         : tile_cfg == 42 ? 192 : ((t == 3 || t == 4) ? 64 : 128);
+    bm = (tile_cfg == 31 || tile_cfg == 41 || tile_cfg == 51 || tile_cfg == 141) ? 256
+         : (tile_cfg == 42 || tile_cfg == 142) ? 192 : ((t == 3 || t == 4) ? 64 : 128);
   }
   return (M + bm - 1) / bm;
 }
@@ -805,6 +805,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
   a.zero = (const float*)zero_page;
   a.bs_y = bs_y; a.bs_ldy = bs_ldy; a.bs_mean = bs_mean; a.bs_istd = bs_istd; a.bs_msc = bs_msc; a.bs_msh = bs_msh;
   a.bs_mbits = bs_mbits; a.bs_partial = bs_partial; a.res_mbits = res_mbits;
+  a.x_bf16 = 0;
   a.stride_log2 = 0;
   while ((1 << a.stride_log2) < stride) ++a.stride_log2;
   if (a.M <= 0 || ncols <= 0) return 0;
@@ -828,6 +829,8 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 31: return launch_dma(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);
+    case 141: a.x_bf16 = 1; return zs3conv::launch_halo(a, 256, prec, st);   // x stored as bf16 (prec 1 only)
+    case 142: a.x_bf16 = 1; return zs3conv::launch_halo(a, 192, prec, st);
     case 51: return zs3conv::launch_pw(a, 256, prec, st);     // -7: not a 1x1 stride-1 layer (zs3_conv_pw_ok)
     case 52: return zs3conv::launch_pw(a, 128, prec, st);
   }

@@ -224,7 +224,12 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
            HALO, HALO_BM, PW, PW_FORCE)
     cached = _TILE_CHOICE.get(key)
-    if cached is not None:
+    if tile_cfg in (141, 142) or x.dtype == torch.bfloat16:
+        # bf16-STORED input (round-3 kernel-level experiment, csrc/conv_halo.hip A16): strip-resident kernel, plain bf16 only
+        if tile_cfg not in (141, 142) or x.dtype != torch.bfloat16 or prec != 1 or not halo_ok(
+                x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg - 100):
+            raise ValueError("a bf16-stored input needs tile_cfg 141 / 142, prec = 1 and a layer the strip-resident kernel serves")
+    elif cached is not None:
         tile_cfg = cached
     else:
         tile_cfg = _TILE_CHOICE[key] = _choose_tile(tile_cfg, x.shape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
@@ -265,7 +270,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
         e1.record()
         PROFILE.append(("conv_halo_kernel<%d, %d, %d>" % (prec, 256 if tile_cfg == 41 else 192, halo_ok(
                             x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg))
-                        if tile_cfg in (41, 42) else
+                        if tile_cfg in (41, 42) else "conv_halo_kernel<1, %d, bf16 in>" % (256 if tile_cfg == 141 else 192) if tile_cfg in (141, 142) else
                         "conv_pw_kernel<%d, %d>" % (prec, 256 if tile_cfg == 51 else 128) if tile_cfg in (51, 52) else
                         "conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
