@@ -49,6 +49,15 @@ int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scal
                    int ncols, int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec,
                    int tile_cfg, const void* zero_page, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
+/* zs3_conv_igemm whose input is read through x' = max(x * in_scale[c] + in_shift[c], 0) by the producer waves of the strip-resident and
+ * persistent pointwise kernels (tile_cfg 41 / 42 / 51 / 52; -7 for any other kernel): BatchNorm-apply + ReLU of the layer that produced
+ * x in the consumer's operand path -- that layer's activation tensor is never stored (resnet.py:33-53: bn1 -> relu -> conv2,
+ * bn2 -> relu -> conv3).  in_scale / in_shift: >= cin_valid floats, 16-byte aligned. */
+int zs3_conv_igemm_in(const float* x, const void* w_pk, float* y, const float* scale, const float* shift, const float* res,
+                      float* stat_partial, int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW,
+                      int stride, int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int act, float leak, int accumulate,
+                      int dgrad, int prec, int tile_cfg, const void* zero_page, const float* in_scale, const float* in_shift,
+                      void* stream);
 /* tile_cfg 31: wave-specialised 256x128 LDS-DMA kernel, one tile per workgroup. */
 /* tile_cfg 41 / 42 (csrc/conv_halo.hip): strip-resident kernel for stride-1, same-size multi-tap (3x3, dilated 3x3)
  * convolutions and their data gradients, 256- / 192-row tiles.  The input strip of a tile (tile rows + the halo the taps
@@ -94,11 +103,14 @@ int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const flo
  * their position-major fragments with ds_read_b64_tr_b16.  zs3_conv_wgrad_strip_plan returns 1 when the layer is eligible
  * (and the split-K factor / workspace floats the launch needs), 0 otherwise (use zs3_conv_wgrad).  Arguments as zs3_conv_wgrad;
  * dw: [co_write][3][3][ci_write].  Replaces convolution_backward(weight) at resnet.py:18-26, aspp.py:11-19, decoder.py:15-24. */
+/* x_scale / x_shift (both kernels below; nullable, 16-byte aligned, >= ci_read floats): the producer waves read x through
+ * x' = max(x * x_scale[c] + x_shift[c], 0) -- the BatchNorm-apply + ReLU of the layer that produced x, whose activation tensor is then
+ * never stored (resnet.py:33-53: bn1 -> relu -> conv2, bn2 -> relu -> conv3); pad positions and rows past M stay zero. */
 int zs3_conv_wgrad_strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil,
                               int co, int ci, int* splitk_out, long* workspace_floats);
 int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int dil,
                          int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
-                         const void* zero_page, void* stream);
+                         const void* zero_page, const float* x_scale, const float* x_shift, void* stream);
 /* Pointwise weight gradient (csrc/conv_wgrad_strip.hip) of the stride-1 1x1 convolutions: dw[co][ci] = sum over the M = N*H*W
  * positions of dy[p][co] * x[p][ci], with the strip kernel's division of labour (producer waves split both operands to bf16
  * hi/lo once per (64 or 128)^2 tile and K step, MFMA waves read position-major fragments with ds_read_b64_tr_b16).
@@ -107,7 +119,8 @@ int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* work
  * Replaces convolution_backward(weight) of the 1x1 nn.Conv2d at resnet.py:33-53, aspp.py:11-19,86-88. */
 int zs3_conv_wgrad_pw_plan(long M, int co, int ci, int* splitk_out, long* workspace_floats);
 int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, float* workspace, long M, int co_read, int co_write,
-                      int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream);
+                      int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page, const float* x_scale,
+                      const float* x_shift, void* stream);
 /* dw[co][kh][kw][ci] = sum_m dy[m][co] * x[gather(m,kh,kw)][ci]  (channels_last weight layout).
  * dy: [M][lddy] with co_read (multiple of 4) readable channels of which co_write rows are produced;
  * x likewise (ci_read / ci_write).  Split-K over pixels: call zs3_conv_wgrad_plan (same M = N*Ho*Wo, Wo, channel

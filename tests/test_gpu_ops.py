@@ -694,6 +694,53 @@ def test_syncbn_exchange_buffer_finalize(dev):
         assert torch.allclose(two[0], 2 * rb[0], rtol=1e-6) and torch.allclose(two[1], 2 * rb[1], rtol=1e-6)
 
 
+@pytest.mark.parametrize("prec", [3, 1])
+def test_bn_apply_in_the_consumers_operand_path(dev, prec):
+    """`in_affine` / `x_affine`: the strip-resident and pointwise kernels (forward and weight gradient) read their input through
+    max(x * scale + shift, 0) in their producer waves -- the BatchNorm-apply + ReLU of the producing layer, so that its
+    activation is never stored.  Against the same kernels fed the materialised activation (zs3_affine_act), on geometries with
+    image borders (3x3 padding must stay zero AFTER the transform), row tails (rows past M must not contribute relu(shift) to
+    the BN sums or the weight gradient) and channel tails (304 -> 320: pad channels get scale = shift = 0)."""
+    from zs3_amd import ops
+    from zs3_amd.functional import _pad_channels
+    g = torch.Generator().manual_seed(21)
+    # plain bf16: a last-bit difference between the two BN-apply spellings can move an operand across a bf16 rounding boundary
+    tol = 2e-5 if prec == 3 else 3e-3
+    # (batches large enough for ops' rules to put the layer on the producer-converting kernels: >= 8192 output pixels)
+    cases = [(8, 33, 33, 256, 256, 3, 1), (1, 129, 129, 256, 256, 3, 1), (8, 33, 33, 512, 512, 3, 2), (8, 33, 33, 304, 256, 3, 1),
+             (8, 33, 33, 256, 1024, 1, 1), (1, 129, 129, 64, 256, 1, 1), (9, 31, 31, 128, 512, 1, 1)]
+    for (n, h, w, ci, co, k, d) in cases:
+        y_prev = _pad_channels(torch.randn(n, h, w, ci, generator=g).to(dev), 32)          # raw conv output of the producing layer
+        ldx = ops._check_nhwc(y_prev)
+        sc = torch.zeros(ldx, device=dev); sh = torch.zeros(ldx, device=dev)
+        sc[:ci] = (torch.rand(ci, generator=g) + 0.5).to(dev); sh[:ci] = (torch.randn(ci, generator=g) * 0.5).to(dev)
+        a = _pad_channels(ops.affine_act(y_prev, sc[:ci], sh[:ci], act=1), 32)                # what the producing layer would store
+        wt = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(dev)
+        wp = ops.prep_weight(wt)
+        pad = d * (k // 2)
+        assert ops.consumer_applies_bn(y_prev.shape, ldx, wp, 1, pad, d, prec), (n, h, w, ci, co, k, d)
+        tag = (n, h, w, ci, co, k, d)
+        y0, st0 = ops.conv2d_fwd(a, wp, 1, pad, d, want_stats=True, prec=prec)
+        y1, st1 = ops.conv2d_fwd(y_prev, wp, 1, pad, d, want_stats=True, prec=prec, in_affine=(sc, sh))
+        assert rel(y1, y0) < tol, (tag, "forward")
+        s0, s1 = st0.double().sum(0), st1.double().sum(0)
+        assert ((s1 - s0).abs().max() / s0.abs().max()).item() < tol, (tag, "bn sums")
+        dy = _pad_channels(torch.randn(n, h, w, co, generator=g).to(dev), 8)
+        dw0 = ops.conv2d_wgrad(dy, a, co, ci, k, k, 1, pad, pad, d, prec=prec)
+        dw1 = ops.conv2d_wgrad(dy, y_prev, co, ci, k, k, 1, pad, pad, d, prec=prec, x_affine=(sc, sh))
+        assert rel(dw1, dw0) < tol, (tag, "weight gradient")
+    # a layer whose forward or weight gradient runs elsewhere (stride 2, 48 output channels) is not offered the hand-over ...
+    wp = ops.prep_weight(torch.randn(128, 128, 3, 3, device=dev))
+    assert not ops.consumer_applies_bn((2, 65, 65, 128), 128, wp, 2, 1, 1, prec)
+    wp = ops.prep_weight(torch.randn(48, 256, 1, 1, device=dev))
+    assert not ops.consumer_applies_bn((1, 129, 129, 256), 256, wp, 1, 0, 1, prec)
+    # ... and asking anyway fails loudly instead of computing the convolution of the un-normalised tensor
+    x = torch.randn(2, 65, 65, 128, device=dev)
+    z = torch.zeros(128, device=dev)
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(x, ops.prep_weight(torch.randn(128, 128, 3, 3, device=dev)), 2, 1, 1, in_affine=(z, z))
+
+
 PW_CASES = [  # (n, h, w, cin, cout)
     (2, 33, 33, 256, 1024), (2, 33, 33, 1024, 256), (1, 65, 65, 128, 512), (2, 17, 19, 64, 200), (1, 33, 33, 1280, 256),
     (1, 129, 129, 64, 256), (3, 9, 11, 32, 128), (1, 33, 33, 304, 384),

@@ -21,6 +21,10 @@ struct ConvArgs {
   int KH, KW, stride, pad_h, pad_w, dil;
   int ncols, ldw, ldy, ldr, M;
   int act, accumulate, dgrad, stride_log2;
+  // optional transform of the input on its way into LDS (the producing layer's BatchNorm-apply + ReLU, so that its activation
+  // tensor is never stored): x' = max(x * in_scale[c] + in_shift[c], 0).  Strip-resident and persistent pointwise kernels only.
+  const float* in_scale;
+  const float* in_shift;
   int x_bf16;   // x is stored as bf16 (strip-resident kernel, tile_cfg 141 / 142); ldx then counts bf16 elements
   float leak;
   // optional BatchNorm-backward statistics of the layer whose output gradient this launch produces (dgrad epilogue):

@@ -69,9 +69,13 @@ constexpr int HALO_MAXP = 3;
 
 // A16: the input tensor is stored as bf16 ([pixel][channel], ldx in elements) -- plain-bf16 arithmetic only (PREC = 1): the producers
 // copy 16 bytes per lane and row from L2 into the strip, no conversion, half the bytes.
-template <int PREC, int BM, int NPG, bool A16 = false>
+// INAFF: the producers apply x' = max(x * in_scale[c] + in_shift[c], 0) before the split -- the BatchNorm-apply + ReLU of the layer
+// that produced x, whose activation tensor then never exists in memory (two VALU operations per element in waves that have
+// the slack; an instantiation of its own, so the plain kernel's code is untouched).
+template <int PREC, int BM, int NPG, bool A16 = false, bool INAFF = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const HaloGeom g) {
   static_assert(!A16 || PREC == 1, "bf16-stored input: plain bf16 products only");
+  static_assert(!(A16 && INAFF), "the input transform reads fp32 storage");
   constexpr int BN = 128, TM = BM / 64, TN = 2, CH = PREC == 3 ? 16 : 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
@@ -127,10 +131,32 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
         }
       }
     };
-    auto write_pass = [&](const f32x4 (&srcv)[NV], int pass, int sb) {
+    // (INAFF) scale / shift of this lane's channels in the chunk whose strip is being written; channels past cin_valid get 0 / 0
+    f32x4 aff_sc[NV], aff_sh[NV];
+    auto load_aff = [&](int c) {
+      if constexpr (INAFF) {
+        const int ch0 = c * CH + cq * (CH / 4);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const bool ok = ch0 + 4 * v < p.cin_valid;
+          aff_sc[v] = *reinterpret_cast<const f32x4*>(ok ? p.in_scale + ch0 + 4 * v : p.zero);
+          aff_sh[v] = *reinterpret_cast<const f32x4*>(ok ? p.in_shift + ch0 + 4 * v : p.zero);
+        }
+      }
+    };
+    auto write_pass = [&](const f32x4 (&srcv0)[NV], int pass, int sb) {
       pass = pass < g.npass ? pass : g.npass - 1;
       const int s = pass * 64 + prow, sw = (s >> 2) & 3;
       unsigned char* row = dsm + HALO_OFF_STRIP + sb * strip_bytes + s * 64;
+      f32x4 srcv[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        srcv[v] = srcv0[v];
+        if constexpr (INAFF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) srcv[v][e] = fmaxf(fmaf(srcv[v][e], aff_sc[v][e], aff_sh[v][e]), 0.f);
+        }
+      }
       if (PREC == 3) {
         u32x2 hi, lo;
         unsigned h, l;
@@ -183,6 +209,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     };
     if (pl < 16) *reinterpret_cast<u32x4*>(dsm + HALO_OFF_ZERO + pl * 16) = u32x4{0u, 0u, 0u, 0u};
     // ---- prologue: weight tiles 0..3 requested, strip 0 and tile 0 in LDS (NS >= 9: the four tiles exist)
+    load_aff(0);
     load_w(wbuf[0], 0, 0);
     load_w(wbuf[1], 0, 1);
     load_w(wbuf[2], 0, 2);
@@ -208,6 +235,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     //      convert strip group t-3 of chunk c+1, request group t
     for (int c = 0; c + 1 < g.nch; ++c) {
       const int sb = (c + 1) & 1;
+      load_aff(c + 1);   // every strip write of this iteration belongs to chunk c + 1
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         write_w(wbuf[(t + 1) % 3], (c + t + 1) & 1);
@@ -482,25 +510,25 @@ bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   return true;
 }
 
-template <int PREC, int BM, int NPG, bool A16 = false>
+template <int PREC, int BM, int NPG, bool A16 = false, bool INAFF = false>
 int launch_halo_n(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<PREC, BM, NPG, A16>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<PREC, BM, NPG, A16, INAFF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return -4;
     configured = true;
   }
   const int grid = ((a.M + BM - 1) / BM) * ((a.ncols + 127) / 128);
-  hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG, A16>), dim3(grid), dim3(512), g.lds_bytes, st, a, g);
+  hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG, A16, INAFF>), dim3(grid), dim3(512), g.lds_bytes, st, a, g);
   return ZS3_LAUNCH_CHECK();
 }
-template <int PREC, int BM, bool A16 = false>
+template <int PREC, int BM, bool A16 = false, bool INAFF = false>
 int launch_halo_t(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
   switch (g.npg) {
-    case 1: return launch_halo_n<PREC, BM, 1, A16>(a, g, st);
-    case 2: return launch_halo_n<PREC, BM, 2, A16>(a, g, st);
-    case 3: return launch_halo_n<PREC, BM, 3, A16>(a, g, st);
+    case 1: return launch_halo_n<PREC, BM, 1, A16, INAFF>(a, g, st);
+    case 2: return launch_halo_n<PREC, BM, 2, A16, INAFF>(a, g, st);
+    case 3: return launch_halo_n<PREC, BM, 3, A16, INAFF>(a, g, st);
   }
   return -7;
 }
@@ -516,8 +544,13 @@ int zs3conv::launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   HaloGeom g;
   if (!halo_geometry(a, bm, prec, &g)) return -7;
   if (a.x_bf16) {   // bf16-stored input (tile_cfg 141 / 142): plain-bf16 products, 8-channel granularity
-    if (prec != 1 || (a.ldx & 7) || (a.cin_valid & 7)) return -7;
+    if (prec != 1 || (a.ldx & 7) || (a.cin_valid & 7) || a.in_scale) return -7;
     return bm == 256 ? launch_halo_t<1, 256, true>(a, g, st) : launch_halo_t<1, 192, true>(a, g, st);
+  }
+  if (a.in_scale) {   // input transform (the producing layer's BatchNorm-apply + ReLU) in the producer waves
+    if (!a.in_shift) return -1;
+    if (bm == 256) return prec == 1 ? launch_halo_t<1, 256, false, true>(a, g, st) : launch_halo_t<3, 256, false, true>(a, g, st);
+    return prec == 1 ? launch_halo_t<1, 192, false, true>(a, g, st) : launch_halo_t<3, 192, false, true>(a, g, st);
   }
   if (bm == 256) return prec == 1 ? launch_halo_t<1, 256>(a, g, st) : launch_halo_t<3, 256>(a, g, st);
   return prec == 1 ? launch_halo_t<1, 192>(a, g, st) : launch_halo_t<3, 192>(a, g, st);

@@ -787,7 +787,8 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
                            int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec, int tile_cfg,
                            const void* zero_page, void* stream, const float* bs_y, int bs_ldy, const float* bs_mean,
                            const float* bs_istd, const float* bs_msc, const float* bs_msh,
-                           const unsigned char* bs_mbits, float* bs_partial, const unsigned char* res_mbits) {
+                           const unsigned char* bs_mbits, float* bs_partial, const unsigned char* res_mbits,
+                           const float* in_scale = nullptr, const float* in_shift = nullptr) {
   if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 1 && prec != 3)) return -1;
   if (stride < 1 || (stride & (stride - 1)) != 0 || zero_page == nullptr) return -1;
   if (((uintptr_t)x & 15) || ((uintptr_t)w_pk & 15) || ((uintptr_t)zero_page & 15)) return -2;
@@ -806,6 +807,8 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
   a.bs_y = bs_y; a.bs_ldy = bs_ldy; a.bs_mean = bs_mean; a.bs_istd = bs_istd; a.bs_msc = bs_msc; a.bs_msh = bs_msh;
   a.bs_mbits = bs_mbits; a.bs_partial = bs_partial; a.res_mbits = res_mbits;
   a.x_bf16 = 0;
+  a.in_scale = in_scale; a.in_shift = in_shift;
+  if ((in_scale == nullptr) != (in_shift == nullptr) || ((uintptr_t)in_scale & 15) || ((uintptr_t)in_shift & 15)) return -1;
   a.stride_log2 = 0;
   while ((1 << a.stride_log2) < stride) ++a.stride_log2;
   if (a.M <= 0 || ncols <= 0) return 0;
@@ -817,6 +820,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     bool small = blocks < 512;
     cfg = bn == 128 ? (small ? 3 : 1) : (small ? 4 : 2);
   }
+  if (in_scale && cfg != 41 && cfg != 42 && cfg != 51 && cfg != 52) return -7;   // only the producer-converting kernels transform x
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 1>(a, prec, st);
     case 2: return launch_cfg<128, 64, 1>(a, prec, st);
@@ -845,6 +849,20 @@ extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const 
   return conv_igemm_impl(x, w_pk, y, scale, shift, res, stat_partial, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
                          stride, pad_h, pad_w, dil, ncols, ldy, ldr, act, leak, accumulate, dgrad, prec, tile_cfg,
                          zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// zs3_conv_igemm with the input read through x' = max(x * in_scale[c] + in_shift[c], 0) (tile_cfg 41 / 42 / 51 / 52 only, -7 otherwise):
+// the BatchNorm-apply + ReLU of the producing layer happens in the consumer's operand path and its activation is never stored.
+extern "C" int zs3_conv_igemm_in(const float* x, const void* w_pk, float* y, const float* scale, const float* shift,
+                                 const float* res, float* stat_partial, int N, int H, int W, int Ho, int Wo, int cin_pad,
+                                 int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int ncols,
+                                 int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec, int tile_cfg,
+                                 const void* zero_page, const float* in_scale, const float* in_shift, void* stream) {
+  if (!in_scale || !in_shift) return -1;
+  return conv_igemm_impl(x, w_pk, y, scale, shift, res, stat_partial, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
+                         stride, pad_h, pad_w, dil, ncols, ldy, ldr, act, leak, accumulate, dgrad, prec, tile_cfg,
+                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, in_scale,
+                         in_shift);
 }
 
 extern "C" int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const float* res,

@@ -43,7 +43,8 @@ constexpr int PW_CTILE = 4 * PW_BN * 4;             // the epilogue's cross-wave
 #endif
 int g_pw_wgs = 256;                                 // persistent workgroups per launch (zs3_conv_pw_set_wgs)
 
-template <int PREC, int BM>
+// INAFF: the producers apply x' = max(x * in_scale[c] + in_shift[c], 0) before the split (conv_common.h: ConvArgs::in_scale).
+template <int PREC, int BM, bool INAFF = false>
 __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const int ntiles, const int ntn) {
   constexpr int BN = PW_BN, TM = BM / 64, TN = 2;
   constexpr int ASUB = BM * 64;                     // one 16-channel sub-chunk of the activation rows
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     struct StepRegs {
       f32x4 a[NRA];
       u32x4 w[2][2];
+      f32x4 sc, sh;      // (INAFF) scale / shift of this lane's four channels in this K step
+      unsigned rows;     // (INAFF) which of the lane's rows are inside the tensor: rows past M stay zero
     };
     StepRegs buf[3];
     auto load_step = [&](StepRegs& d) {
@@ -114,6 +117,11 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
 #pragma unroll
           for (int s = 0; s < 2; ++s)
             d.w[e][s] = *reinterpret_cast<const u32x4*>(wptr[e] + (size_t)(lk * 128 + s * 32) * wstep[e]);
+        if constexpr (INAFF) {
+          d.sc = *reinterpret_cast<const f32x4*>(cok ? p.in_scale + lk * 32 + c8 * 4 : p.zero);
+          d.sh = *reinterpret_cast<const f32x4*>(cok ? p.in_shift + lk * 32 + c8 * 4 : p.zero);
+          d.rows = rowmask;
+        }
       }
       if (++lk == NK) {
         lk = 0;
@@ -129,8 +137,14 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         const int row = prow + 32 * r, sw = (row >> 2) & 3;
         u32x2 hi, lo;
         unsigned h, l;
-        split_pair<PREC>(s.a[r][0], s.a[r][1], h, l); hi[0] = h; lo[0] = l;
-        split_pair<PREC>(s.a[r][2], s.a[r][3], h, l); hi[1] = h; lo[1] = l;
+        f32x4 v = s.a[r];
+        if constexpr (INAFF) {
+          const bool in = (s.rows >> r) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf(fmaf(v[e], s.sc[e], s.sh[e]), 0.f) : 0.f;
+        }
+        split_pair<PREC>(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
+        split_pair<PREC>(v[2], v[3], h, l); hi[1] = h; lo[1] = l;
         const int o = (((cq >> 1) ^ sw) << 4) + (cq & 1) * 8;
         *reinterpret_cast<u32x2*>(sa + row * 64 + o) = hi;
         if (PREC == 3) *reinterpret_cast<u32x2*>(sa + row * 64 + (o ^ 32)) = lo;
@@ -308,12 +322,12 @@ bool pw_ok(const ConvArgs& a, int bm) {
   return bm == 256 || bm == 128;
 }
 
-template <int PREC, int BM>
+template <int PREC, int BM, bool INAFF = false>
 int launch_pw_t(const ConvArgs& a, hipStream_t st) {
   static bool configured = false;
   constexpr int LDS = 2 * (2 * BM * 64 + PW_BSTAGE) + PW_CTILE;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<PREC, BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<PREC, BM, INAFF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return -4;
     configured = true;
@@ -321,7 +335,7 @@ int launch_pw_t(const ConvArgs& a, hipStream_t st) {
   const int ntn = (a.ncols + PW_BN - 1) / PW_BN;
   const int ntiles = ((a.M + BM - 1) / BM) * ntn;
   const int grid = ntiles < g_pw_wgs ? ntiles : g_pw_wgs;
-  hipLaunchKernelGGL((conv_pw_kernel<PREC, BM>), dim3(grid), dim3(512), LDS, st, a, ntiles, ntn);
+  hipLaunchKernelGGL((conv_pw_kernel<PREC, BM, INAFF>), dim3(grid), dim3(512), LDS, st, a, ntiles, ntn);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -331,6 +345,11 @@ int zs3conv::pw_eligible(const ConvArgs& a, int bm) { return pw_ok(a, bm) ? 1 : 
 
 int zs3conv::launch_pw(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   if (!pw_ok(a, bm)) return -7;
+  if (a.in_scale) {   // input transform (the producing layer's BatchNorm-apply + ReLU) in the producer waves
+    if (!a.in_shift) return -1;
+    if (bm == 256) return prec == 1 ? launch_pw_t<1, 256, true>(a, st) : launch_pw_t<3, 256, true>(a, st);
+    return prec == 1 ? launch_pw_t<1, 128, true>(a, st) : launch_pw_t<3, 128, true>(a, st);
+  }
   if (bm == 256) return prec == 1 ? launch_pw_t<1, 256>(a, st) : launch_pw_t<3, 256>(a, st);
   return prec == 1 ? launch_pw_t<1, 128>(a, st) : launch_pw_t<3, 128>(a, st);
 }

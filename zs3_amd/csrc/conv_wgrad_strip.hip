@@ -56,6 +56,10 @@ struct StripArgs {
   int tiles_co, tiles_ci;
   long slab;           // elements per split-K slab
   int toff[9];         // tap offsets in padded positions
+  // optional transform of x on its way into LDS: x' = max(x * x_scale[c] + x_shift[c], 0) at real positions (pad positions stay 0)
+  // -- the BatchNorm-apply + ReLU of the layer that produced x, whose activation tensor is then never stored
+  const float* x_scale;
+  const float* x_shift;
 };
 
 constexpr int WS_ROW = 320;            // bytes per LDS row: 64 ch hi | 64 ch lo | 64 B pad
@@ -65,7 +69,7 @@ struct Pos {           // a lane's position in a padded stream: q and its coordi
   int n, yp, xp;
 };
 
-template <int PREC>
+template <int PREC, bool XAFF = false>
 __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -114,11 +118,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p
         }
       }
     };
-    auto fetch = [&](const Pos& s, const float* base, int ld, int c0, bool cok) {
+    f32x4 xsc = {0.f, 0.f, 0.f, 0.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (XAFF) {
+      xsc = *reinterpret_cast<const f32x4*>(x_cok ? p.x_scale + ci0 + cq * 4 : p.zero);
+      xsh = *reinterpret_cast<const f32x4*>(x_cok ? p.x_shift + ci0 + cq * 4 : p.zero);
+    }
+    auto fetch = [&](const Pos& s, const float* base, int ld, int c0, bool cok, bool transform = false) {
       const bool real = s.q >= 0 && s.q < p.Q && s.yp < p.H && s.xp < p.W && cok;
       const long pix = ((long)s.n * p.H + s.yp) * p.W + s.xp;
       const float* src = real ? base + pix * ld + c0 + cq * 4 : p.zero;
-      return *reinterpret_cast<const f32x4*>(src);
+      f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      if constexpr (XAFF) {
+        if (transform) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = real ? fmaxf(fmaf(v[e], xsc[e], xsh[e]), 0.f) : 0.f;
+        }
+      }
+      return v;
     };
     auto conv_write = [&](const f32x4 v, unsigned char* row) {
       u32x2 hi, lo;
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p
       xslot = xslot + 1 == p.ring_steps ? 0 : xslot + 1;
     };
     auto load_x = [&]() {
-      const f32x4 v = fetch(xs, p.x, p.ldx, ci0, x_cok);
+      const f32x4 v = fetch(xs, p.x, p.ldx, ci0, x_cok, true);
       advance(xs);
       return v;
     };
@@ -291,11 +307,13 @@ struct PwArgs {
   int steps_per_split; // 32-position K steps per range, multiple of 6
   int tiles_co, tiles_ci;
   long slab;
+  const float* x_scale;   // optional x' = max(x * x_scale[c] + x_shift[c], 0) (as StripArgs)
+  const float* x_shift;
 };
 
 constexpr int PW_ARRAY = 32 * WS_ROW;   // one 64-channel array of a stage: 32 positions
 
-template <int PREC, int NCO, int NCI>
+template <int PREC, int NCO, int NCI, bool XAFF = false>
 __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   constexpr int NARR = NCO + NCI;
@@ -327,6 +345,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
       ptr[a] = (isd ? p.dy : p.x) + c + q * ld;
       ld16[a] = 16 * ld;
     }
+    f32x4 xsc[NCI], xsh[NCI];      // (XAFF) scale / shift of this lane's four channels in each x array
+    if constexpr (XAFF) {
+#pragma unroll
+      for (int a = 0; a < NCI; ++a) {
+        const int c = ci0 + 64 * a + cq * 4;
+        xsc[a] = *reinterpret_cast<const f32x4*>(cok[NCO + a] ? p.x_scale + c : p.zero);
+        xsh[a] = *reinterpret_cast<const f32x4*>(cok[NCO + a] ? p.x_shift + c : p.zero);
+      }
+    }
     f32x4 buf[3][2 * NARR];
     auto load_step = [&](f32x4* dst) {
 #pragma unroll
@@ -341,6 +368,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
         q += 16;
       }
     };
+    long qw = q_begin + prow;      // (XAFF) position of the rows being written: rows past M stay zero after the transform
     auto conv_write = [&](const f32x4 v, unsigned char* row) {
       u32x2 hi, lo;
       unsigned h, l;
@@ -352,9 +380,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
     auto write_step = [&](const f32x4* src, int stage) {
       unsigned char* s0 = dsm + (size_t)stage * STAGE + (size_t)prow * WS_ROW;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int a = 0; a < NARR; ++a) conv_write(src[h * NARR + a], s0 + (size_t)a * PW_ARRAY + (size_t)h * 16 * WS_ROW);
+        for (int a = 0; a < NARR; ++a) {
+          f32x4 v = src[h * NARR + a];
+          if constexpr (XAFF) {
+            if (a >= NCO) {
+              const bool in = qw < p.M;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf(fmaf(v[e], xsc[a - NCO][e], xsh[a - NCO][e]), 0.f) : 0.f;
+            }
+          }
+          conv_write(v, s0 + (size_t)a * PW_ARRAY + (size_t)h * 16 * WS_ROW);
+        }
+        qw += 16;
+      }
     };
     // prologue: step 0 into stage 0; steps 1, 2, 3 requested into register sets 1, 2, 0
     load_step(buf[0]);
@@ -596,17 +636,21 @@ PwPlan pw_plan(long M, int co, int ci) {
   return s;
 }
 
-template <int PREC, int NCO, int NCI>
-int launch_pw(const PwArgs& a, int grid, int lds, hipStream_t st) {
+template <int PREC, int NCO, int NCI, bool XAFF>
+int launch_pw_x(const PwArgs& a, int grid, int lds, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pw_kernel<PREC, NCO, NCI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pw_kernel<PREC, NCO, NCI, XAFF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return -4;
     configured = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_pw_kernel<PREC, NCO, NCI>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_wgrad_pw_kernel<PREC, NCO, NCI, XAFF>), dim3(grid), dim3(512), lds, st, a);
   return ZS3_LAUNCH_CHECK();
+}
+template <int PREC, int NCO, int NCI>
+int launch_pw(const PwArgs& a, int grid, int lds, hipStream_t st) {
+  return a.x_scale ? launch_pw_x<PREC, NCO, NCI, true>(a, grid, lds, st) : launch_pw_x<PREC, NCO, NCI, false>(a, grid, lds, st);
 }
 
 int reduce_slabs(const float* workspace, float* dw, long n, int splitk, hipStream_t st) {
@@ -637,14 +681,17 @@ extern "C" int zs3_conv_wgrad_pw_plan(long M, int co, int ci, int* splitk_out, l
 }
 
 extern "C" int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, float* workspace, long M, int co_read, int co_write,
-                                 int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream) {
+                                 int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page,
+                                 const float* x_scale, const float* x_shift, void* stream) {
   if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 3)) return -2;
+  if ((x_scale == nullptr) != (x_shift == nullptr) || ((uintptr_t)x_scale & 15) || ((uintptr_t)x_shift & 15)) return -1;
   const PwPlan s = pw_plan(M, co_write, ci_write);
   if (!s.ok) return -7;
   if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
   PwArgs a{};
   a.dy = dy; a.x = x; a.zero = (const float*)zero_page;
+  a.x_scale = x_scale; a.x_shift = x_shift;
   a.M = M;
   a.co_read = co_read; a.co_write = co_write; a.ci_read = ci_read; a.ci_write = ci_write;
   a.lddy = lddy; a.ldx = ldx; a.ldw = ci_write;
@@ -685,14 +732,16 @@ extern "C" int zs3_conv_wgrad_strip_plan(int N, int H, int W, int Ho, int Wo, in
 
 extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int dil,
                                     int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
-                                    const void* zero_page, void* stream) {
+                                    const void* zero_page, const float* x_scale, const float* x_shift, void* stream) {
   if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 3)) return -2;
+  if ((x_scale == nullptr) != (x_shift == nullptr) || ((uintptr_t)x_scale & 15) || ((uintptr_t)x_shift & 15)) return -1;
   const StripPlan s = strip_plan(N, H, W, H, W, 3, 3, 1, dil, dil, dil, co_write, ci_write);
   if (!s.ok) return -7;
   if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
   StripArgs a{};
   a.dy = dy; a.x = x; a.zero = (const float*)zero_page;
+  a.x_scale = x_scale; a.x_shift = x_shift;
   a.N = N; a.H = H; a.W = W;
   a.co_read = co_read; a.co_write = co_write; a.ci_read = ci_read; a.ci_write = ci_write;
   a.lddy = lddy; a.ldx = ldx; a.cin_w = ci_write; a.ldw = 9 * ci_write;
@@ -704,18 +753,22 @@ extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, 
   for (int t = 0; t < 9; ++t) a.toff[t] = (t / 3 - 1) * dil * a.Wd + (t % 3 - 1) * dil;
   hipStream_t st = (hipStream_t)stream;
   const int grid = a.tiles_co * a.tiles_ci * s.splitk;
-  static bool configured[2] = {false, false};
-  const int pi = prec == 1 ? 0 : 1;
+  static bool configured[4] = {false, false, false, false};
+  const int pi = (prec == 1 ? 0 : 1) + (x_scale ? 2 : 0);
+  const void* fns[4] = {reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1, false>),
+                        reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<3, false>),
+                        reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1, true>),
+                        reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<3, true>)};
   if (!configured[pi]) {
-    const void* fn = prec == 1 ? reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1>)
-                               : reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<3>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -4;
+    if (hipFuncSetAttribute(fns[pi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -4;
     configured[pi] = true;
   }
-  if (prec == 1)
-    hipLaunchKernelGGL((conv_wgrad_strip_kernel<1>), dim3(grid), dim3(512), s.lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL((conv_wgrad_strip_kernel<3>), dim3(grid), dim3(512), s.lds_bytes, st, a);
+  switch (pi) {
+    case 0: hipLaunchKernelGGL((conv_wgrad_strip_kernel<1, false>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
+    case 1: hipLaunchKernelGGL((conv_wgrad_strip_kernel<3, false>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
+    case 2: hipLaunchKernelGGL((conv_wgrad_strip_kernel<1, true>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
+    default: hipLaunchKernelGGL((conv_wgrad_strip_kernel<3, true>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
+  }
   int rc = ZS3_LAUNCH_CHECK();
   if (rc) return rc;
   if (s.splitk > 1) rc = reduce_slabs(workspace, dw, a.slab, s.splitk, st);

@@ -204,11 +204,13 @@ def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, s
 
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
                scale=None, shift=None, res=None, want_stats=False, act=0, leak=0.2, accumulate=False, dgrad=False,
-               prec=None, tile_cfg=0, bn_bwd=None, res_mask_bits=None):
+               prec=None, tile_cfg=0, bn_bwd=None, res_mask_bits=None, in_affine=None):
     """Raw launcher.  x: NHWC [N,H,W,*]; returns (y [N,ho,wo,ncols] or `out`, stat_partial or None).
     bn_bwd = (y, mean, invstd, mask_scale, mask_shift, mask_bits): also return the BatchNorm-backward partial sums
     (sum dz, sum dz*xhat per row tile) of the layer the output gradient belongs to (zs3_conv_igemm_bnstats).
-    res_mask_bits: `res` is added through a ReLU mask given as sign bytes (the residual block's skip gradient)."""
+    res_mask_bits: `res` is added through a ReLU mask given as sign bytes (the residual block's skip gradient).
+    in_affine = (scale, shift): x is read through max(x * scale + shift, 0) by the kernel's producer waves (the BatchNorm-apply +
+    ReLU of the layer that produced x; only the strip-resident / persistent pointwise kernels: ask `consumer_applies_bn` first)."""
     require_gpu(x, w_pk, out, scale, shift, res)
     prec = prec or PREC_DEFAULT
     n, h, w_, _ = x.shape
@@ -248,7 +250,16 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if bn_bwd is not None or res_mask_bits is not None:
+    if in_affine is not None:
+        assert bn_bwd is None and res_mask_bits is None
+        if tile_cfg not in (41, 42, 51, 52):
+            raise ValueError(f"in_affine needs a producer-converting kernel; this launch runs on tile_cfg {tile_cfg}")
+        check(lib().zs3_conv_igemm_in(P(x), P(w_pk), P(out), P(scale), P(shift), P(res), P(stat), I(n), I(h), I(w_),
+                                      I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h),
+                                      I(pad_w), I(dil), I(ncols), I(ldy), I(ldr), I(act), F(leak), I(int(accumulate)),
+                                      I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), P(in_affine[0]),
+                                      P(in_affine[1]), stream()), "zs3_conv_igemm_in")
+    elif bn_bwd is not None or res_mask_bits is not None:
         assert scale is None and shift is None and act == 0 and not want_stats
         by, bmean, bistd, bmsc, bmsh, bbits = bn_bwd if bn_bwd is not None else (None,) * 6
         require_gpu(by, bmean, bistd, bmsc, bmsh, bbits, res_mask_bits)
@@ -299,19 +310,9 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
 _WGRAD_PLAN = {}
 
 
-def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1, prec=None, ci_read=None, out=None):
-    """dy: NHWC [N,Ho,Wo,>=cout]; x: NHWC [N,H,W,>=cin] -> dw [cout, kh, kw, cin] (channels_last weight storage)."""
-    require_gpu(dy, x)
-    prec = prec or PREC_DEFAULT
-    pad_w = pad_h if pad_w is None else pad_w
-    n, ho, wo, _ = dy.shape
-    _, h, w_, _ = x.shape
-    lddy, ldx = _check_nhwc(dy), _check_nhwc(x)
-    co_read = min(_round_up(cout, 4), lddy)
-    ci_read = ci_read or min(_round_up(cin, 4), ldx)
-    dw = out if out is not None else torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
-    assert dw.is_contiguous() and dw.numel() == cout * kh * kw * cin
-    # which kernel and how much split-K workspace: a function of the geometry, asked of the library once per distinct layer
+def _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin):
+    """(kernel kind, split-K workspace floats) of a weight-gradient launch: a function of the geometry, asked of the library once
+    per distinct layer.  kind: "strip" (3x3 strip-resident), "pw" (pointwise), "gemm" (the round-2 kernels)."""
     key = (n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, WGRAD_STRIP, WGRAD_PW)
     plan = _WGRAD_PLAN.get(key)
     if plan is None:
@@ -327,17 +328,54 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
             lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
             plan = ("gemm", ws.value)
         _WGRAD_PLAN[key] = plan
+    return plan
+
+
+def consumer_applies_bn(xshape, ldx, wp, stride, pad, dil, prec=None):
+    """Can the conv that consumes x (NHWC shape `xshape`, row stride ldx) apply the BatchNorm + ReLU of the layer that produced x
+    in its own operand path -- forward AND weight gradient on kernels whose producer waves convert the operand (strip-resident /
+    pointwise)?  Then the producing layer skips its BN-apply pass and hands over its raw conv output (functional._ConvBnAct)."""
+    prec = prec or PREC_DEFAULT
+    n, h, w_, _ = xshape
+    ho, wo = conv_out_size(h, wp.kh, stride, pad, dil), conv_out_size(w_, wp.kw, stride, pad, dil)
+    cin_valid = min(_round_up(wp.cin, 4), ldx)
+    if wp.cin % 4 or ldx % 4:
+        return False
+    tile = _choose_tile(0, xshape, n * ho * wo, ho, wo, wp.cin_pad, cin_valid, ldx, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout,
+                        False, prec, True)
+    if tile not in (41, 42, 51, 52):
+        return False
+    return _wgrad_plan(n, h, w_, ho, wo, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout, wp.cin)[0] in ("strip", "pw")
+
+
+def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1, prec=None, ci_read=None, out=None, x_affine=None):
+    """dy: NHWC [N,Ho,Wo,>=cout]; x: NHWC [N,H,W,>=cin] -> dw [cout, kh, kw, cin] (channels_last weight storage).
+    x_affine = (scale, shift): x is read through max(x * scale + shift, 0) (strip-resident / pointwise kernels only)."""
+    require_gpu(dy, x)
+    prec = prec or PREC_DEFAULT
+    pad_w = pad_h if pad_w is None else pad_w
+    n, ho, wo, _ = dy.shape
+    _, h, w_, _ = x.shape
+    lddy, ldx = _check_nhwc(dy), _check_nhwc(x)
+    co_read = min(_round_up(cout, 4), lddy)
+    ci_read = ci_read or min(_round_up(cin, 4), ldx)
+    dw = out if out is not None else torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
+    assert dw.is_contiguous() and dw.numel() == cout * kh * kw * cin
+    plan = _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin)
     kind, nws = plan
+    xs, xh = x_affine if x_affine is not None else (None, None)
+    if x_affine is not None and kind == "gemm":
+        raise ValueError("x_affine needs the strip-resident or the pointwise weight-gradient kernel")
     work = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     if kind == "strip":
         # strip-resident kernel (csrc/conv_wgrad_strip.hip): all nine taps from one LDS-resident strip of x
         check(lib().zs3_conv_wgrad_strip(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(dil), I(co_read), I(cout),
-                                         I(ci_read), I(cin), I(lddy), I(ldx), I(prec), P(zero_page(x.device)), stream()),
-              "zs3_conv_wgrad_strip")
+                                         I(ci_read), I(cin), I(lddy), I(ldx), I(prec), P(zero_page(x.device)), P(xs), P(xh),
+                                         stream()), "zs3_conv_wgrad_strip")
     elif kind == "pw":
         # pointwise kernel (csrc/conv_wgrad_strip.hip): producer waves split both operands once, transposing fragment reads
         check(lib().zs3_conv_wgrad_pw(P(dy), P(x), P(dw), P(work), I(n * h * w_), I(co_read), I(cout), I(ci_read), I(cin),
-                                      I(lddy), I(ldx), I(prec), P(zero_page(x.device)), stream()), "zs3_conv_wgrad_pw")
+                                      I(lddy), I(ldx), I(prec), P(zero_page(x.device)), P(xs), P(xh), stream()), "zs3_conv_wgrad_pw")
     else:
         check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
                                    I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
