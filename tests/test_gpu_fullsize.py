@@ -157,3 +157,57 @@ def test_gmmn_step_device_noise_full_path(dev):
     torch.manual_seed(1)
     ref_gen = GMMNnetwork(300, 300, 256, 256)
     assert not torch.equal(g1[0].cpu(), next(ref_gen.parameters()).detach())   # the generator was trained
+
+
+def test_bn_apply_handed_to_the_consumer_in_a_residual_stage(dev):
+    """layer 3's geometry (B = 16, 33 x 33, 1024 -> 256 -> 256 -> 1024) through three bottleneck blocks in train mode: with
+    functional.DEFER_BN_APPLY the activations behind bn1 and bn2 are never stored (conv2 / conv3 apply BatchNorm + ReLU in their
+    producer waves, forward and weight gradient) -- output, input gradient, every parameter gradient and the running statistics
+    must match the run that stores them (same kernels otherwise; the two BN-apply spellings differ in the last bit)."""
+    import copy
+    from zs3_amd import functional as Fz
+    from zs3_amd import ops
+    from zs3_amd.modeling.backbone.resnet import Bottleneck
+    from zs3_amd.modeling.layers import to_channels_last_
+    torch.manual_seed(5)
+    blocks = torch.nn.Sequential(*[Bottleneck(1024, 256) for _ in range(3)])
+    for b in blocks:
+        torch.nn.init.constant_(b.bn3.weight, 0.2)
+    to_channels_last_(blocks)
+    blocks = blocks.to(dev).train()
+    x0 = torch.randn(16, 33, 33, 1024, device=dev)
+    up = torch.randn(16, 33, 33, 1024, device=dev)
+
+    def run(defer):
+        m = copy.deepcopy(blocks)
+        old, Fz.DEFER_BN_APPLY = Fz.DEFER_BN_APPLY, defer
+        calls = [0]
+        real = ops.affine_act
+        def counted(*a, **k):
+            calls[0] += 1
+            return real(*a, **k)
+        ops.affine_act = counted
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = x
+            for b in m:
+                y = b.forward_nhwc(y)
+            (y * up).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            Fz.DEFER_BN_APPLY, ops.affine_act = old, real
+        return y.detach(), x.grad, {k: p.grad for k, p in m.named_parameters()}, dict(m.named_buffers()), calls[0]
+
+    y0, dx0, g0, buf0, n0 = run(False)
+    y1, dx1, g1, buf1, n1 = run(True)
+    assert n0 == 9 and n1 == 3, (n0, n1)          # bn1 / bn2 of every block handed over, bn3 (+ residual) still a pass of its own
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    # forward: last-bit differences.  Gradients: a 2e-6 difference in a conv output flips the ReLU mask of the handful of
+    # activations (of 4.7 million per layer) that sit within 2e-6 of zero, and every flip moves a gradient element by its whole
+    # value -- sqrt(5 / 4.7e6) ~ 1e-3 in relative L2 (the kink effect of DESIGN.md section 5), not an error of either path
+    assert rel(y1, y0) < 1e-5 and rel(dx1, dx0) < 5e-3
+    for k in g0:
+        assert rel(g1[k], g0[k]) < 5e-3, k
+    for k in buf0:
+        if buf0[k].dtype.is_floating_point:
+            assert rel(buf1[k], buf0[k]) < 1e-6, k

@@ -40,6 +40,15 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
   }
 }
 
+// max(v * sc + sh, 0) on four values: two packed fp32 FMAs (v_pk_fma_f32) + four v_max -- the BatchNorm-apply + ReLU that the conv
+// producers perform on their operand (ConvArgs::in_scale)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x4 affine_relu4(f32x4 v, f32x4 sc, f32x4 sh) {
+  const f32x2 lo = __builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
+  const f32x2 hi = __builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
+  return f32x4{fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f), fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   unsigned u = __float_as_uint(f);

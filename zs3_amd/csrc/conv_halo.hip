@@ -152,10 +152,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         srcv[v] = srcv0[v];
-        if constexpr (INAFF) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) srcv[v][e] = fmaxf(fmaf(srcv[v][e], aff_sc[v][e], aff_sh[v][e]), 0.f);
-        }
+        if constexpr (INAFF) srcv[v] = affine_relu4(srcv[v], aff_sc[v], aff_sh[v]);
       }
       if (PREC == 3) {
         u32x2 hi, lo;

@@ -139,9 +139,10 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         unsigned h, l;
         f32x4 v = s.a[r];
         if constexpr (INAFF) {
-          const bool in = (s.rows >> r) & 1u;
+          v = affine_relu4(v, s.sc, s.sh);
+          const bool in = (s.rows >> r) & 1u;   // (branch-free: a branch between the loads and their use makes hipcc wait vmcnt(0))
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf(fmaf(v[e], s.sc[e], s.sh[e]), 0.f) : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = in ? v[e] : 0.f;
         }
         split_pair<PREC>(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
         split_pair<PREC>(v[2], v[3], h, l); hi[1] = h; lo[1] = l;

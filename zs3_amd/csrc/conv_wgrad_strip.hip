@@ -130,8 +130,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p
       f32x4 v = *reinterpret_cast<const f32x4*>(src);
       if constexpr (XAFF) {
         if (transform) {
+          v = affine_relu4(v, xsc, xsh);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = real ? fmaxf(fmaf(v[e], xsc[e], xsh[e]), 0.f) : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] = real ? v[e] : 0.f;
         }
       }
       return v;
@@ -386,9 +387,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
           f32x4 v = src[h * NARR + a];
           if constexpr (XAFF) {
             if (a >= NCO) {
+              v = affine_relu4(v, xsc[a - NCO], xsh[a - NCO]);
               const bool in = qw < p.M;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf(fmaf(v[e], xsc[a - NCO][e], xsh[a - NCO][e]), 0.f) : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] = in ? v[e] : 0.f;
             }
           }
           conv_write(v, s0 + (size_t)a * PW_ARRAY + (size_t)h * 16 * WS_ROW);

@@ -24,6 +24,9 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 WGRAD_SIDE_STREAM = True
 FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
 DROPOUT_FUSED = os.environ.get("ZS3_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind conv+BN+ReLU inside the BN-apply pass
+# BN-apply + ReLU in the sole consumer's operand path (conv_bn_act: next_conv).  Same-box A/B, ms per step: off 46.64 / 46.87, on
+# 46.51 / 46.47, on for 3x3 consumers only 46.68 / 46.67 (tools/probe/ab_env.sh; per layer: tools/probe/defer_bench.py)
+DEFER_BN_APPLY = os.environ.get("ZS3_DEFER_BN", "1") == "1"
 LAZY_SKIP_GRAD = True      # identity blocks: the skip gradient dA*mask is applied by conv1's dgrad epilogue, never stored
 _lazy_skip = {}            # data_ptr of a block-output gradient -> (tensor, sign bits) it still has to be masked with
 # The layers' weight gradients are independent of each other: with WGRAD_STREAMS > 1 they go round-robin over a small pool
@@ -248,8 +251,10 @@ class _ConvBnAct(torch.autograd.Function):
         prec = cfg.get("prec")
         drop = cfg.get("drop")   # (p, seed): nn.Dropout behind this layer's activation, fused into affine_act / bn_act_bwd
         y = a = st = mbits = None
-        conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, **k)) if geom is None else (
+        in_aff = cfg.get("in_affine")   # x is the RAW conv output of the producing layer: its BN-apply + ReLU runs in our producers
+        conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, in_affine=in_aff, **k)) if geom is None else (
             lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, **geom, **k))
+        defer = bool(cfg.get("defer_out"))
         if bn is not None and bn["training"]:
             y, part = conv(want_stats=True)
             count = y.shape[0] * y.shape[1] * y.shape[2]
@@ -261,8 +266,13 @@ class _ConvBnAct(torch.autograd.Function):
                 part, count = combine_bn_partials(part, count, None if bn["sync"] is True else bn["sync"])
             st = ops.bn_fwd_finalize(part, count, gamma, beta, bn["eps"], bn["momentum"], bn["running_mean"],
                                      bn["running_var"], bn.get("nbt"))
-            mbits = _mask_bits_for(y, act, residual, need_grad)
-            a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits, drop=drop)
+            if defer:
+                # the one consumer of this layer applies scale / shift / ReLU in its own operand path (forward and weight
+                # gradient): no BN-apply pass, no activation tensor -- the raw conv output is what travels on
+                a = y
+            else:
+                mbits = _mask_bits_for(y, act, residual, need_grad)
+                a = ops.affine_act(y, st[2], st[3], res=residual, out=out, act=act, leak=leak, mask_out=mbits, drop=drop)
         elif bn is not None:
             st = ops.bn_eval_affine(gamma, beta, bn["running_mean"], bn["running_var"], bn["eps"])
             if need_grad:
@@ -289,6 +299,9 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.mask_from_y = bool(bn is not None and y is not None and act == ACT_RELU and residual is None)
         keep_a = act != ACT_NONE and not ctx.mask_from_y and mbits is None
         ctx.save_for_backward(x, weight, gamma, y, a if keep_a else None, st, mbits)
+        ctx.x_affine = in_aff
+        if defer:
+            cfg["deferred"] = (st[2], st[3])
         ctx.pass_through = bool(cfg.get("pass_through"))
         link = cfg.get("out_link")
         if link is not None and ctx.bn_training and need_grad and act in (ACT_NONE, ACT_RELU) and bn.get("sync") is None:
@@ -420,7 +433,7 @@ class _ConvBnAct(torch.autograd.Function):
                 x.record_stream(side)
                 with torch.cuda.stream(side):
                     dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec,
-                                          out=_bucket_out(weight, wp))
+                                          out=_bucket_out(weight, wp), x_affine=ctx.x_affine)
                 dw.record_stream(main)
                 if not (weight.is_leaf and weight.grad is None):
                     # the gradient is READ inside this backward pass -- accumulated into an existing .grad (a second
@@ -432,7 +445,7 @@ class _ConvBnAct(torch.autograd.Function):
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
             elif geom is None:
                 dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec,
-                                      out=_bucket_out(weight, wp))
+                                      out=_bucket_out(weight, wp), x_affine=ctx.x_affine)
             if geom is None:
                 dw = dw.permute(0, 3, 1, 2)  # logical OIHW, channels_last memory like the parameter
                 if weight.dim() == 2:
@@ -459,11 +472,35 @@ def _act_grad(a, act, leak):
     return torch.where(a > 0, torch.ones_like(a), torch.full_like(a, leak))
 
 
+_defer_choice = {}
+
+
+def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
+    """Does `next_conv` (the one consumer of this layer's output) run forward and weight gradient on producer-converting kernels
+    that can apply this layer's BatchNorm + ReLU themselves?  Decided once per (output geometry, consumer)."""
+    n, h, w_, _ = x.shape
+    cout, _, kh, kw = weight.shape if weight.dim() == 4 else (*weight.shape, 1, 1)
+    oshape = (n, ops.conv_out_size(h, kh, stride, pad, dil), ops.conv_out_size(w_, kw, stride, pad, dil), cout)
+    key = (oshape, id(next_conv), tuple(next_conv.weight.shape), prec, ops.PREC_DEFAULT, ops.HALO, ops.PW, ops.WGRAD_STRIP, ops.WGRAD_PW)
+    hit = _defer_choice.get(key)
+    if hit is None:
+        nw = next_conv.weight
+        hit = _defer_choice[key] = bool(
+            nw.dim() == 4 and next_conv.bias is None and nw.shape[1] == cout and cout % 4 == 0 and
+            ops.consumer_applies_bn(oshape, cout, weight_planes(nw, need_t=True), next_conv.stride[0], next_conv.padding[0],
+                                    next_conv.dilation[0], prec))
+    return hit
+
+
 def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
-                leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False, dropout=None):
+                leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False, dropout=None,
+                next_conv=None):
     """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None.
     input_has_one_consumer: promise that `x` feeds nothing but this layer (and, with pass_through, the skip tensor this
-    layer hands back), which lets this layer's dgrad produce the BN-backward sums of the layer that made `x` (BnLink)."""
+    layer hands back), which lets this layer's dgrad produce the BN-backward sums of the layer that made `x` (BnLink).
+    next_conv: the conv module that is the ONLY consumer of this layer's output.  When that conv's forward and weight gradient
+    run on kernels whose producer waves convert the operand (ops.consumer_applies_bn), this layer hands over its raw conv
+    output tagged with the BatchNorm scale / shift, and the consumer applies BN + ReLU on the way into LDS (DEFER_BN_APPLY)."""
     # dropout: (p, training) of an nn.Dropout that follows this layer's activation.  conv + BN + ReLU layers without a residual
     # (every dropout of the network sits behind one: aspp.py:100, decoder.py:19,23) take it into the BN-apply pass and its
     # backward (same mask as the stand-alone kernel, same position in the seed stream); anything else gets the separate pass.
@@ -483,10 +520,19 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
            "out_link": BnLink() if (bn is not None and out is None and FUSE_BN_BWD_STATS and drop is None) else None,
            "need_grad": torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
                                                         (x, weight, bias, residual, getattr(bn, "weight", None)))}
+    x_defer = getattr(x, "_zs3_defer", None)
+    if x_defer is not None:
+        if geom is not None or not input_has_one_consumer:
+            raise RuntimeError("a deferred BatchNorm output reached a layer that does not apply it")
+        cfg["in_affine"] = x_defer
     gamma = beta = None
     if bn is not None:
         gamma, beta = bn.weight, bn.bias
         use_batch = bn.training or bn.running_mean is None
+        cfg["defer_out"] = bool(
+            DEFER_BN_APPLY and next_conv is not None and use_batch and act == ACT_RELU and residual is None and out is None and
+            drop is None and drop_after is None and geom is None and x.is_cuda and
+            _consumer_applies(x, weight, stride, pad, dil, prec, next_conv))
         mom = bn.momentum
         nbt = None
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -500,6 +546,8 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
                      "running_mean": bn.running_mean if (bn.training and bn.track_running_stats) or not use_batch else None,
                      "running_var": bn.running_var if (bn.training and bn.track_running_stats) or not use_batch else None}
     res = _ConvBnAct.apply(x, weight, gamma, beta, bias, residual, cfg)
+    if cfg.get("deferred") is not None:
+        (res[0] if pass_through else res)._zs3_defer = cfg["deferred"]
     if cfg.get("out_link") is not None:
         (res[0] if pass_through else res)._zs3_bn_link = cfg["out_link"]
     if pass_through:

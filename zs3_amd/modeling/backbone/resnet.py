@@ -37,10 +37,14 @@ class Bottleneck(nn.Module):
         # backward for the identity blocks, and none for the projection blocks either (the downsample conv's dgrad is the
         # incoming skip gradient there).  Being the only consumer of x this way, conv1's dgrad also sums the previous
         # block's bn3 backward statistics.
-        y, skip = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU, pass_through=True, input_has_one_consumer=True)
+        # bn1 -> relu -> conv2 and bn2 -> relu -> conv3 (resnet.py:39-46): where the consuming conv runs on kernels whose producer
+        # waves convert the operand, it applies the BatchNorm scale / shift and the ReLU itself and the activation is never stored
+        # (`next_conv`; functional.conv_bn_act decides per layer geometry)
+        y, skip = self.conv1.forward_nhwc(x, self.bn1, act=Fz.ACT_RELU, pass_through=True, input_has_one_consumer=True,
+                                          next_conv=self.conv2)
         if self.downsample is not None:
             skip = self.downsample[0].forward_nhwc(skip, self.downsample[1])
-        y = self.conv2.forward_nhwc(y, self.bn2, act=Fz.ACT_RELU, input_has_one_consumer=True)
+        y = self.conv2.forward_nhwc(y, self.bn2, act=Fz.ACT_RELU, input_has_one_consumer=True, next_conv=self.conv3)
         return self.conv3.forward_nhwc(y, self.bn3, residual=skip, act=Fz.ACT_RELU,   # bn3 + add + relu in one pass
                                        input_has_one_consumer=True)
 
