@@ -100,7 +100,6 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
       f32x4 a[NRA];
       u32x4 w[2][2];
       f32x4 sc, sh;      // (INAFF) scale / shift of this lane's four channels in this K step
-      unsigned rows;     // (INAFF) which of the lane's rows are inside the tensor: rows past M stay zero
     };
     StepRegs buf[3];
     auto load_step = [&](StepRegs& d) {
@@ -120,7 +119,6 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         if constexpr (INAFF) {
           d.sc = *reinterpret_cast<const f32x4*>(cok ? p.in_scale + lk * 32 + c8 * 4 : p.zero);
           d.sh = *reinterpret_cast<const f32x4*>(cok ? p.in_shift + lk * 32 + c8 * 4 : p.zero);
-          d.rows = rowmask;
         }
       }
       if (++lk == NK) {
@@ -139,10 +137,9 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         unsigned h, l;
         f32x4 v = s.a[r];
         if constexpr (INAFF) {
+          // (rows past M are loaded as zeros and become relu(shift) here: their outputs are never stored, and the BatchNorm sums of
+          // the one partial tile skip them in the epilogue -- cheaper than four selects per row in every tile)
           v = affine_relu4(v, s.sc, s.sh);
-          const bool in = (s.rows >> r) & 1u;   // (branch-free: a branch between the loads and their use makes hipcc wait vmcnt(0))
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = in ? v[e] : 0.f;
         }
         split_pair<PREC>(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
         split_pair<PREC>(v[2], v[3], h, l); hi[1] = h; lo[1] = l;
@@ -290,7 +287,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float v = acc[i][j][r];
+              float v = acc[i][j][r];
+              if (INAFF && m0 + BM > p.M && m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) >= p.M) v = 0.f;
               s += v;
               q2 = fmaf(v, v, q2);
             }

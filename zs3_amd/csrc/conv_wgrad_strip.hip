@@ -369,7 +369,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
         q += 16;
       }
     };
-    long qw = q_begin + prow;      // (XAFF) position of the rows being written: rows past M stay zero after the transform
     auto conv_write = [&](const f32x4 v, unsigned char* row) {
       u32x2 hi, lo;
       unsigned h, l;
@@ -387,15 +386,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
           f32x4 v = src[h * NARR + a];
           if constexpr (XAFF) {
             if (a >= NCO) {
-              v = affine_relu4(v, xsc[a - NCO], xsh[a - NCO]);
-              const bool in = qw < p.M;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = in ? v[e] : 0.f;
+              v = affine_relu4(v, xsc[a - NCO], xsh[a - NCO]);   // (rows past M become relu(shift): they multiply dy rows that are zero)
             }
           }
           conv_write(v, s0 + (size_t)a * PW_ARRAY + (size_t)h * 16 * WS_ROW);
         }
-        qw += 16;
       }
     };
     // prologue: step 0 into stage 0; steps 1, 2, 3 requested into register sets 1, 2, 0
