@@ -25,8 +25,8 @@ step(); n[0] = 0; l = step(); torch.cuda.synchronize()
 print("affine_act launches per step:", n[0], " loss", l.item())
 yes = [k for k, v in Fz._defer_choice.items() if v]; no = [k for k, v in Fz._defer_choice.items() if not v]
 print("deferred layer geometries:", len(yes), " not deferred:", len(no))
-for k in yes: print("  defer", k[0], k[2])
-for k in no: print("  keep ", k[0], k[2])
+for k in yes: print("  defer", k[0], k[1])
+for k in no: print("  keep ", k[0], k[1])
 for _ in range(3): step()
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): step()

@@ -481,7 +481,8 @@ def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
     n, h, w_, _ = x.shape
     cout, _, kh, kw = weight.shape if weight.dim() == 4 else (*weight.shape, 1, 1)
     oshape = (n, ops.conv_out_size(h, kh, stride, pad, dil), ops.conv_out_size(w_, kw, stride, pad, dil), cout)
-    key = (oshape, id(next_conv), tuple(next_conv.weight.shape), prec, ops.PREC_DEFAULT, ops.HALO, ops.PW, ops.WGRAD_STRIP, ops.WGRAD_PW)
+    key = (oshape, tuple(next_conv.weight.shape), next_conv.stride[0], next_conv.padding[0], next_conv.dilation[0],
+           next_conv.bias is None, prec, ops.PREC_DEFAULT, ops.HALO, ops.PW, ops.WGRAD_STRIP, ops.WGRAD_PW)
     hit = _defer_choice.get(key)
     if hit is None:
         nw = next_conv.weight
