@@ -130,6 +130,12 @@ def _worker(rank, world, port, q):
         # -> the fp64 exchange buffer [global sums (2 x C) | global count]; the count travels inside it
         assert cnt is None and buf.dtype == torch.float64 and buf.shape == (2 * 4 + 1,) and buf[8].item() == 30.0
         assert torch.equal(buf[:8].view(2, 4), (torch.arange(16.).reshape(2, 2, 4).sum(0).double()) * 3)
+        # the statistics travel on a process group of their own (never queued behind gradient buckets): created once, collectively
+        from zs3_amd.parallel import bn_group
+        grp = bn_group()
+        assert grp is not True and bn_group() is grp and dist.get_world_size(grp) == world
+        buf2, _ = combine_bn_partials(part, 10 * (rank + 1), grp)
+        assert torch.equal(buf2, buf)
         big = torch.full((3, 2, 4), 1e8 / 3 + rank, dtype=torch.float32)     # sums that fp32 cannot hold exactly
         buf, _ = combine_bn_partials(big, 1)
         other = torch.full((3, 2, 4), 1e8 / 3 + (1 - rank), dtype=torch.float32)
