@@ -22,6 +22,13 @@ extern "C" {
  * reference (cuDNN consumed fp32 weights directly). */
 int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
                     void* stream);
+/* Exact-fp32 operands for prec = 0 of zs3_conv_igemm (test mode: every product on v_mfma_f32_32x32x2_f32, the arithmetic of the
+ * reference's own fp32 convolutions; register-staged kernels only, ~1/16 of the bf16 rate): the same two planes as plain fp32
+ * [row][K] rows with the same zero padding and the same byte sizes (a {hi,lo} bf16 pair and a float are both 4 bytes).
+ * Exists so that a parity gap can be attributed to bf16x3 arithmetic rather than structure: tests/test_gpu_model.py runs the
+ * reference's default-init train-mode goldens through it. */
+int zs3_prep_weight_f32(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
+                        void* stream);
 /* the same for many weights in ONE launch (after an optimizer step): table[e] = {w, f_pk, t_pk, cout, taps, cin, cin_pad,
  * cout_pad} as 8 int64 (device memory), blockmap[b] = {entry, chunk} as 2 int32 with chunk in
  * [0, zs3_prep_chunks(cout_pad, taps, cin_pad)) (one tap x 32 output channels x <= 256 input channels each). */
@@ -38,7 +45,8 @@ int zs3_nchw3_to_nhwc4(const float* img, float* out, int N, int H, int W, int Wp
  * sums of squares of the raw conv output (BatchNorm batch statistics), mtiles = zs3_conv_igemm_mtiles.
  * dgrad=1: rows are input-gradient pixels (N x Ho x Wo = the conv's input extent), x is dy (N x H x W
  * = the conv's output extent), w_pk is the t_pk operand.
- * act: 0 none, 1 ReLU, 2 LeakyReLU(leak).  prec: 3 = bf16x3 split (fp32-class), 1 = plain bf16.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(leak).  prec: 3 = bf16x3 split (fp32-class), 1 = plain bf16, 0 = exact fp32 (test mode:
+ * w_pk from zs3_prep_weight_f32, tile_cfg 1-4 / 11-14 only, -7 otherwise).
  * tile_cfg: 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64 (+10: two-deep register prefetch).  zero_page: >= 256 bytes of
  * device zeros (16-byte aligned) that masked loads are redirected to; stride must be a power of two.
  * Replaces nn.Conv2d fwd / convolution_backward(input) at resnet.py:16-28,79,125-131; aspp.py:11-19,
@@ -131,6 +139,10 @@ int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out
 int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int Ho, int Wo,
                    int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read, int co_write, int ci_read,
                    int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream);
+/* Kernel choice of zs3_conv_wgrad / zs3_conv_wgrad_plan: 0 = the library's rules, 1 = the register-staged kernel for every layer
+ * (required before prec = 0, which exists on that kernel only: -7 otherwise), 2 = the LDS-DMA kernel wherever the channel counts
+ * allow.  Returns the previous setting; plans made under another setting are stale. */
+int zs3_conv_wgrad_set_kernel(int kernel);
 
 /* ---- BatchNorm / ReLU / residual (bn.hip) ---------------------------------------------------- */
 /* Replaces native_batch_norm fwd/bwd, relu_, threshold_backward, residual add_ at resnet.py:33-53,

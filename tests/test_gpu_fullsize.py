@@ -18,10 +18,10 @@ def dot(a, b):
     return (a.double() * b.double()).sum().item()
 
 
-FULL_SHAPES = [  # N, H, Cin, Cout, k, stride, dil   (layer shapes of DeepLabv3+ at 513x513, B=16)
-    (16, 129, 304, 256, 3, 1, 1), (16, 33, 2048, 256, 3, 1, 18), (16, 129, 64, 256, 1, 1, 1), (16, 129, 128, 128, 3, 2, 1),
-    (16, 33, 1024, 256, 1, 1, 1), (16, 33, 512, 512, 3, 1, 4), (16, 129, 256, 21, 1, 1, 1), (16, 65, 256, 256, 3, 2, 1),
-]
+from test_gpu_ops import NETWORK_CONV_SHAPES   # (Cin, Cout, k, stride, dil, H): the 33 distinct conv shapes behind the stem
+
+# N, H, Cin, Cout, k, stride, dil: EVERY layer shape of DeepLabv3+ at 513x513, B=16 (round 3 checked 8 of them here)
+FULL_SHAPES = [(16, h, ci, co, k, s, d) for ci, co, k, s, d, h in NETWORK_CONV_SHAPES]
 
 
 @pytest.mark.parametrize("shape", FULL_SHAPES)
@@ -211,3 +211,77 @@ def test_bn_apply_handed_to_the_consumer_in_a_residual_stage(dev):
     for k in buf0:
         if buf0[k].dtype.is_floating_point:
             assert rel(buf1[k], buf0[k]) < 1e-6, k
+
+
+def _sampled_reference(x, w, dy, n, h, ci, co, k, s, d, pad, ho, rows, gen):
+    """fp64 values of `rows` sampled output pixels (forward) and input pixels (data gradient), and the whole weight gradient, from
+    gathered patches and fp64 matrix products on the device -- the definition of the convolution, none of the library's kernels."""
+    dev = x.device
+    x64, dy64, w64 = x.double(), dy.double(), w.double()     # [n,h,h,ci], [n,ho,ho,co], [co,ci,k,k]
+    mo = torch.randint(0, n * ho * ho, (rows,), device=dev, generator=gen)
+    mi = torch.randint(0, n * h * h, (rows,), device=dev, generator=gen)
+    on, oh, ow = mo // (ho * ho), (mo // ho) % ho, mo % ho
+    inn, ih, iw = mi // (h * h), (mi // h) % h, mi % h
+    y_ref = torch.zeros(rows, co, dtype=torch.float64, device=dev)
+    dx_ref = torch.zeros(rows, ci, dtype=torch.float64, device=dev)
+    dw_ref = torch.empty(co, k, k, ci, dtype=torch.float64, device=dev)
+    # every output pixel's coordinates, for the weight gradient
+    an = torch.arange(n, device=dev)[:, None, None]
+    ah = torch.arange(ho, device=dev)[None, :, None]
+    aw = torch.arange(ho, device=dev)[None, None, :]
+    dyf = dy64.reshape(-1, co)
+    for a in range(k):
+        for b in range(k):
+            wt = w64[:, :, a, b]                                              # [co, ci]
+            hi, wi = oh * s - pad + a * d, ow * s - pad + b * d
+            ok = (hi >= 0) & (hi < h) & (wi >= 0) & (wi < h)
+            patch = x64[on, hi.clamp(0, h - 1), wi.clamp(0, h - 1)] * ok[:, None]
+            y_ref += patch @ wt.t()
+            th, tw = ih + pad - a * d, iw + pad - b * d
+            ok = (th >= 0) & (tw >= 0) & (th % s == 0) & (tw % s == 0) & (th // s < ho) & (tw // s < ho)
+            g = dy64[inn, (th // s).clamp(0, ho - 1), (tw // s).clamp(0, ho - 1)] * ok[:, None]
+            dx_ref += g @ wt
+            hi, wi = ah * s - pad + a * d, aw * s - pad + b * d
+            ok = ((hi >= 0) & (hi < h) & (wi >= 0) & (wi < h)).expand(n, ho, ho)
+            full = x64[an.expand(n, ho, ho), hi.clamp(0, h - 1).expand(n, ho, ho), wi.clamp(0, h - 1).expand(n, ho, ho)]
+            dw_ref[:, a, b, :] = dyf.t() @ (full * ok[..., None]).reshape(-1, ci)
+    return mo, mi, y_ref, dx_ref, dw_ref
+
+
+@pytest.mark.parametrize("shape", NETWORK_CONV_SHAPES, ids=lambda s: "%dto%d_k%d_s%d_d%d_at%d" % s)
+def test_every_conv_shape_at_batch_16_against_fp64_samples(dev, shape):
+    """the tile / kernel choices the B = 16 step actually makes (ops.pick_tile, pick_pw_tile, pick_halo_tile and
+    the weight-gradient plans depend on M = 17 424 / 67 600 / 266 256 rows) compared with fp64 -- 4096 sampled output rows of the
+    forward, 4096 sampled rows of the data gradient and the WHOLE weight gradient per shape, through the product's own autograd
+    node.  The fp64 side is gathered patches times the weight matrix on the device (no library kernel involved)."""
+    from zs3_amd import functional as Fz
+    ci, co, k, s, d, h = shape
+    if h == 1:
+        pytest.skip("the pooled branch's 1x1 map has 16 rows at B = 16: covered by test_every_network_conv_shape")
+    n = 16
+    gen = torch.Generator(device=dev).manual_seed(ci * 7 + co + k + d + h)
+    pad = d * (k // 2)
+    ho = (h + 2 * pad - d * (k - 1) - 1) // s + 1
+    x = torch.randn(n, h, h, ci, device=dev, generator=gen)
+    w = torch.randn(co, ci, k, k, device=dev, generator=gen) / (ci * k * k) ** 0.5
+    bias = torch.randn(co, device=dev, generator=gen) if co == 21 else None
+    dy = torch.randn(n, ho, ho, co, device=dev, generator=gen)
+    xg = x.clone().requires_grad_(True)
+    wg = w.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = bias.clone().requires_grad_(True) if bias is not None else None
+    y = Fz.conv_bn_act(xg, wg, bias=bg, stride=s, pad=pad, dil=d)
+    assert tuple(y.shape) == (n, ho, ho, co)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    mo, mi, y_ref, dx_ref, dw_ref = _sampled_reference(x, w, dy, n, h, ci, co, k, s, d, pad, ho, 4096, gen)
+    if bias is not None:
+        y_ref += bias.double()
+    def relerr(a, b):
+        return ((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    e_y = relerr(y.reshape(-1, co)[mo], y_ref)
+    e_dx = relerr(xg.grad.reshape(-1, ci)[mi], dx_ref)
+    e_dw = relerr(wg.grad.permute(0, 2, 3, 1), dw_ref)
+    print(f"[B=16 {shape}] forward {e_y:.1e} dgrad {e_dx:.1e} wgrad {e_dw:.1e}")
+    assert e_y < 5e-5 and e_dx < 5e-5 and e_dw < 5e-5
+    if bias is not None:
+        assert relerr(bg.grad, dy.double().sum((0, 1, 2))) < 5e-5

@@ -435,20 +435,10 @@ def test_gradient_accumulation_over_two_backwards(dev):
         assert torch.equal(p.grad, g1 + g2), name
 
 
-def test_default_init_train_step_vs_reference_goldens(dev, golden):
-    """The reference's OWN train-mode outputs for the default-initialised network (seed 1, no taming, dropout off, 65x65, B=2;
-    tests/golden/deeplab_forward.npz, written by tools/make_goldens.py from /root/reference): logits, loss, the classifier
-    and stem weight gradients and the 226 BatchNorm running statistics -- the goldens no other GPU test touches.
-
-    This configuration is ill-conditioned: batch statistics over 2 x 5 x 5 positions in 101 layers amplify a rounding
-    difference ~1e4-fold (the reference's own fp32 result sits 1.7e-3 (logits) to several 1e-2 (early-layer gradients) away
-    from its fp64 evaluation -- measured below, not assumed).  bf16x3 products carry 2^-16..2^-18 instead of fp32's 2^-24, so
-    the same amplification gives a few 1e-2.  Two kinds of assertion, both with the tolerance written next to them:
-    (1) against the reference's goldens, 3x what the kernels deliver (delivered: logits 3.6e-2, loss 3.6e-4, classifier
-        gradient 3.5e-2, running statistics 2.5e-3; the stem gradient -- the end of the longest chain -- 0.36);
-    (2) against the fp64 oracle, the error measured in units of the reference's own fp32 error: at most 64x for the logits and
-        the classifier gradient (2^8 = 256 would be the pure round-off ratio).
-    The well-conditioned variants of this step (bn3 gains 0.1, as in a trained ResNet) are held to 1e-3 / 2e-3 above."""
+def _default_init_train_step(dev, golden):
+    """One train-mode step of the default-initialised network (seed 1, no taming, dropout off, 65x65, B=2) on the GPU, measured
+    (a) against the reference's own fp32 outputs (tests/golden/deeplab_forward.npz, written by tools/make_goldens.py from
+    /root/reference) and (b) against the fp64 oracle, next to the reference's own fp32-vs-fp64 error."""
     import zs3_oracle as zo
     from zs3_amd.utils.loss import SegmentationLosses
     g = golden("deeplab_forward.npz")
@@ -466,32 +456,75 @@ def test_default_init_train_step_vs_reference_goldens(dev, golden):
     zo.SegmentationLosses(weight=w.double()).build_loss("ce")(r64, b["label"]).backward()
     gold = torch.from_numpy(g["train_logits"])
     gp, gs = torch.from_numpy(g["grad_pred_w"]), torch.from_numpy(g["grad_stem_w"])
-    # (1) against the reference's own fp32 outputs
-    e_logits = rel(out, gold)
-    e_loss = abs(loss.item() - float(g["train_loss"])) / abs(float(g["train_loss"]))
-    e_pred = rel(m.decoder.pred_conv.weight.grad, gp)
-    e_stem = rel(m.backbone.conv1.weight.grad[:8], gs)
+    e = {"logits": rel(out, gold), "loss": abs(loss.item() - float(g["train_loss"])) / abs(float(g["train_loss"])),
+         "pred": rel(m.decoder.pred_conv.weight.grad, gp), "stem": rel(m.backbone.conv1.weight.grad[:8], gs)}
     sd = m.state_dict()
-    worst_run, worst_key = 0.0, None
+    e["run"], e["run_key"] = 0.0, None
     for k, r in zip(g["run_names"], g["run_stats"]):
         t = sd[str(k)].double().cpu().reshape(-1)
-        e = abs(t.abs().sum().item() - r[1]) / max(abs(r[1]), 1e-30)
-        if e > worst_run:
-            worst_run, worst_key = e, str(k)
-    # (2) against fp64, in units of the reference's fp32 error
-    ref_logits32, ref_pred32 = rel(gold, r64), rel(gp, ref64.decoder.pred_conv.weight.grad)
-    ref_stem32 = rel(gs, ref64.backbone.conv1.weight.grad[:8])
-    our_logits, our_pred = rel(out, r64), rel(m.decoder.pred_conv.weight.grad, ref64.decoder.pred_conv.weight.grad)
-    our_stem = rel(m.backbone.conv1.weight.grad[:8], ref64.backbone.conv1.weight.grad[:8])
-    print(f"[default-init train] vs reference goldens: logits {e_logits:.2e} loss {e_loss:.2e} grad_pred_w {e_pred:.2e} "
-          f"grad_stem_w {e_stem:.2e} running stats {worst_run:.2e} ({worst_key}); vs fp64: logits {our_logits:.2e} "
-          f"(reference fp32: {ref_logits32:.2e}), grad_pred_w {our_pred:.2e} ({ref_pred32:.2e}), grad_stem_w {our_stem:.2e} "
-          f"({ref_stem32:.2e})")
-    assert e_logits < 0.11        # 3 x delivered (3.6e-2)
-    assert e_loss < 1.1e-3        # 3 x delivered (3.6e-4); the north-star 1e-3 is met
-    assert e_pred < 0.11          # 3 x delivered (3.5e-2)
-    assert worst_run < 7.5e-3     # 3 x delivered (2.5e-3)
-    assert e_stem < 1.1           # 3 x delivered (0.36): a sanity bound only, see (2)
-    assert our_logits < 64 * ref_logits32
-    assert our_pred < 64 * ref_pred32
-    assert our_stem < 64 * ref_stem32
+        d = abs(t.abs().sum().item() - r[1]) / max(abs(r[1]), 1e-30)
+        if d > e["run"]:
+            e["run"], e["run_key"] = d, str(k)
+    # against fp64: ours, and the reference's own fp32 result
+    e["ref_logits"], e["ref_pred"] = rel(gold, r64), rel(gp, ref64.decoder.pred_conv.weight.grad)
+    e["ref_stem"] = rel(gs, ref64.backbone.conv1.weight.grad[:8])
+    e["our_logits"], e["our_pred"] = rel(out, r64), rel(m.decoder.pred_conv.weight.grad, ref64.decoder.pred_conv.weight.grad)
+    e["our_stem"] = rel(m.backbone.conv1.weight.grad[:8], ref64.backbone.conv1.weight.grad[:8])
+    return e
+
+
+def _report(tag, e):
+    print(f"[default-init train, {tag}] vs reference goldens: logits {e['logits']:.2e} loss {e['loss']:.2e} grad_pred_w "
+          f"{e['pred']:.2e} grad_stem_w {e['stem']:.2e} running stats {e['run']:.2e} ({e['run_key']}); vs fp64: logits "
+          f"{e['our_logits']:.2e} (reference fp32: {e['ref_logits']:.2e} -> {e['our_logits'] / e['ref_logits']:.1f}x), grad_pred_w "
+          f"{e['our_pred']:.2e} ({e['ref_pred']:.2e} -> {e['our_pred'] / e['ref_pred']:.1f}x), grad_stem_w {e['our_stem']:.2e} "
+          f"({e['ref_stem']:.2e} -> {e['our_stem'] / e['ref_stem']:.1f}x)")
+
+
+def test_default_init_train_step_vs_reference_goldens(dev, golden):
+    """The reference's OWN train-mode outputs for the default-initialised network: logits, loss, the classifier and stem weight
+    gradients and the 226 BatchNorm running statistics -- the goldens no other GPU test touches.
+
+    This configuration is ill-conditioned: batch statistics over 2 x 5 x 5 positions in 101 layers amplify a rounding
+    difference ~1e4-fold (the reference's own fp32 result sits 1.7e-3 (logits) to several 1e-2 (early-layer gradients) away
+    from its fp64 evaluation -- measured below, not assumed).  bf16x3 products carry 2^-16..2^-18 instead of fp32's 2^-24, so
+    the same amplification gives a few 1e-2.  That the gap IS arithmetic and not structure is what the next test shows: the same
+    step with every product on the exact-fp32 MFMA lands at the reference's own distance from fp64.  Assertions here:
+    (1) against the reference's goldens, 3x what the kernels deliver (delivered: logits 3.6e-2, loss 3.6e-4, classifier
+        gradient 3.5e-2, running statistics 2.5e-3);
+    (2) against the fp64 oracle, every error in units of the reference's own fp32 error: at most 64x for the logits and the
+        classifier gradient (2^8 = 256 would be the pure round-off ratio; delivered 22x / 31x), at most 16x for the stem
+        gradient (delivered 5.6x; the stem bound of earlier rounds against the goldens, 1.1, bounded nothing and is gone).
+    The well-conditioned variants of this step (bn3 gains 0.1, as in a trained ResNet) are held to 1e-3 / 2e-3 above."""
+    e = _default_init_train_step(dev, golden)
+    _report("bf16x3", e)
+    assert e["logits"] < 0.11        # 3 x delivered (3.6e-2)
+    assert e["loss"] < 1.1e-3        # 3 x delivered (3.6e-4); the north-star 1e-3 is met
+    assert e["pred"] < 0.11          # 3 x delivered (3.5e-2)
+    assert e["run"] < 7.5e-3         # 3 x delivered (2.5e-3)
+    assert e["our_logits"] < 64 * e["ref_logits"]
+    assert e["our_pred"] < 64 * e["ref_pred"]
+    assert e["our_stem"] < 16 * e["ref_stem"]
+
+
+def test_default_init_train_step_in_exact_fp32_matches_the_references_own_error(dev, golden):
+    """VERDICT r3 #3a: the same ill-conditioned step with every convolution product on v_mfma_f32_32x32x2_f32
+    (ops.set_exact_fp32: prec = 0 of the register-staged conv / wgrad kernels, fp32 weight planes; everything else -- BatchNorm
+    kernels, epilogues, pooling, resize, loss, autograd wiring -- is the product path unchanged).  If the 3.6e-2 of the bf16x3
+    run were a structural error it would survive the change of arithmetic; it does not: the result sits where the reference's
+    own fp32 run sits relative to fp64 (the two differ in summation order only).  Bounds: 4x the reference's own fp32 error
+    against fp64 for logits and both gradients; against the goldens 4x that error as well (two fp32 evaluations of a chaotic map
+    are each ~1 such error from fp64)."""
+    from zs3_amd import ops
+    ops.set_exact_fp32(True)
+    try:
+        e = _default_init_train_step(dev, golden)
+    finally:
+        ops.set_exact_fp32(False)
+    _report("exact fp32", e)
+    assert e["our_logits"] < 4 * e["ref_logits"]
+    assert e["our_pred"] < 4 * e["ref_pred"]
+    assert e["our_stem"] < 4 * e["ref_stem"]
+    assert e["logits"] < 4 * e["ref_logits"]
+    assert e["pred"] < 4 * e["ref_pred"]
+    assert e["loss"] < 1e-4

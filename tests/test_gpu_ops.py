@@ -55,6 +55,38 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 5e-5
 
 
+@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[3], CONV_CASES[5], CONV_CASES[6], CONV_CASES[8]])
+def test_conv_exact_fp32_mode(dev, case):
+    """prec = 0 (ops.set_exact_fp32; VERDICT r3 #3a): forward, data gradient and weight gradient of the register-staged kernels on
+    v_mfma_f32_32x32x2_f32 with fp32 weight planes -- plain fp32 products, so the result is within fp32 summation error of fp64
+    (asserted: 2e-6 of the output scale; bf16x3 delivers 7-9e-6 on the same cases)."""
+    from zs3_amd import ops
+    from zs3_amd.functional import _pad_channels
+    n, h, w, ci, co, k, s, d = case
+    g = torch.Generator().manual_seed(n * h + ci + co)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    pad = d * (k // 2)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=s, padding=pad, dilation=d)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    ops.set_exact_fp32(True)
+    try:
+        xg = x.to(dev).permute(0, 2, 3, 1).contiguous()
+        wp = ops.prep_weight(wt.to(dev))
+        y, st = ops.conv2d_fwd(xg, wp, s, pad, d, want_stats=True)
+        dyg = _pad_channels(dy.to(dev).permute(0, 2, 3, 1).contiguous(), 8)
+        dx = ops.conv2d_dgrad(dyg, wp, (h, w), s, pad, d)
+        dw = ops.conv2d_wgrad(dyg, xg, co, ci, k, k, s, pad, pad, d)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_exact_fp32(False)
+    errs = (rel(y.permute(0, 3, 1, 2), ref), rel(dx.permute(0, 3, 1, 2), xr.grad), rel(dw.permute(0, 3, 1, 2), wr.grad))
+    print(f"[exact fp32 {case}] forward {errs[0]:.1e} dgrad {errs[1]:.1e} wgrad {errs[2]:.1e}")
+    assert max(errs) < 2e-6
+
+
 @pytest.mark.parametrize("cfg", [11, 12, 13, 14, 31, 41, 42])
 def test_conv_every_tile_config(dev, cfg):
     """every kernel variant behind zs3_conv_igemm (register-staged tiles, wave-specialised, LDS-DMA) on ragged shapes:

@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     unsigned short* Bs = As + BM * ROW;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
+      if constexpr (PREC == 0) {   // exact fp32 (test mode): the row holds the 32 raw floats of the K step
+        *reinterpret_cast<f32x4*>(As + (srow + 32 * i) * ROW + q * 8) = S.areg[i];
+        continue;
+      }
       u32x2 hi, lo;
       unsigned h, l;
       split_pair<PREC>(S.areg[i][0], S.areg[i][1], h, l); hi[0] = h; lo[0] = l;
@@ -158,6 +162,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int stage) {
+    if constexpr (PREC == 0) {
+      // v_mfma_f32_32x32x2_f32: lanes 0-31 supply k = 0, lanes 32-63 k = 1 of each instruction.  The reduction order inside a
+      // K step is free as long as A and B agree: instruction t of sub-step kk multiplies k = 16 kk + 8 (lane >> 5) + t, so a
+      // lane reads 8 consecutive floats (two ds_read_b128) of its row per sub-step.
+      const unsigned short* A0 = smem + stage * STAGE + (wm * (BM / 2) + (lane & 31)) * ROW + (lane >> 5) * 16;
+      const unsigned short* B0 = smem + stage * STAGE + BM * ROW + (wn * (BN / 2) + (lane & 31)) * ROW + (lane >> 5) * 16;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f32x4 a[TM][2], b[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) a[i][h] = *reinterpret_cast<const f32x4*>(A0 + i * 32 * ROW + kk * 32 + h * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) b[j][h] = *reinterpret_cast<const f32x4*>(B0 + j * 32 * ROW + kk * 32 + h * 8);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t >> 2][t & 3], b[j][t >> 2][t & 3], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     const unsigned short* As = smem + stage * STAGE + (wm * (BM / 2) + (lane & 31)) * ROW + (lane >> 5) * 8;
     const unsigned short* Bs = smem + stage * STAGE + BM * ROW + (wn * (BN / 2) + (lane & 31)) * ROW + (lane >> 5) * 8;
 #pragma unroll
@@ -760,6 +791,8 @@ int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   dim3 grid(mt * nt), block(256);
   if (prec == 1)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, PIPE>), grid, block, 0, st, a);
+  else if (prec == 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 0, PIPE>), grid, block, 0, st, a);   // exact fp32 (w_pk from zs3_prep_weight_f32)
   else
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 3, PIPE>), grid, block, 0, st, a);
   return ZS3_LAUNCH_CHECK();
@@ -789,7 +822,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
                            const float* bs_istd, const float* bs_msc, const float* bs_msh,
                            const unsigned char* bs_mbits, float* bs_partial, const unsigned char* res_mbits,
                            const float* in_scale = nullptr, const float* in_shift = nullptr) {
-  if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 1 && prec != 3)) return -1;
+  if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 0 && prec != 1 && prec != 3)) return -1;
   if (stride < 1 || (stride & (stride - 1)) != 0 || zero_page == nullptr) return -1;
   if (((uintptr_t)x & 15) || ((uintptr_t)w_pk & 15) || ((uintptr_t)zero_page & 15)) return -2;
   if (bs_partial && (!bs_y || !bs_mean || !bs_istd || (bs_ldy & 3) || (ncols & 3) || (ldy & 3) || (res && (ldr & 3))))
@@ -821,6 +854,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     cfg = bn == 128 ? (small ? 3 : 1) : (small ? 4 : 2);
   }
   if (in_scale && cfg != 41 && cfg != 42 && cfg != 51 && cfg != 52) return -7;   // only the producer-converting kernels transform x
+  if (prec == 0 && cfg > 14) return -7;   // the exact-fp32 test mode exists on the register-staged kernel only
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 1>(a, prec, st);
     case 2: return launch_cfg<128, 64, 1>(a, prec, st);

@@ -145,13 +145,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         unsigned h, l;
-        split_pair<PREC>(areg[i][0][c], areg[i][1][c], h, l);
+        if constexpr (PREC == 0) {   // exact fp32 (test mode): plane 0 = the even pixel of the pair, plane 1 = the odd one, raw
+          h = __float_as_uint(areg[i][0][c]);
+          l = __float_as_uint(areg[i][1][c]);
+        } else {
+          split_pair<PREC>(areg[i][0][c], areg[i][1][c], h, l);
+        }
         hi[c] = h;
         lo[c] = l;
       }
       unsigned* dst = As + (pra + SA * i) * BC + cqa;
       *reinterpret_cast<u32x4*>(dst) = hi;
-      if (PREC == 3) *reinterpret_cast<u32x4*>(dst + PLANE_A) = lo;
+      if (PREC != 1) *reinterpret_cast<u32x4*>(dst + PLANE_A) = lo;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -159,13 +164,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         unsigned h, l;
-        split_pair<PREC>(breg[i][0][c], breg[i][1][c], h, l);
+        if constexpr (PREC == 0) {
+          h = __float_as_uint(breg[i][0][c]);
+          l = __float_as_uint(breg[i][1][c]);
+        } else {
+          split_pair<PREC>(breg[i][0][c], breg[i][1][c], h, l);
+        }
         hi[c] = h;
         lo[c] = l;
       }
       unsigned* dst = Bs + (prb + SB * i) * BD + cqb;
       *reinterpret_cast<u32x4*>(dst) = hi;
-      if (PREC == 3) *reinterpret_cast<u32x4*>(dst + PLANE_B) = lo;
+      if (PREC != 1) *reinterpret_cast<u32x4*>(dst + PLANE_B) = lo;
     }
   };
 
@@ -178,6 +188,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int stage) {
+    if constexpr (PREC == 0) {
+      // v_mfma_f32_32x32x2_f32 per pixel pair t: lanes 0-31 supply the even pixel (plane 0), lanes 32-63 the odd one (plane 1)
+      const unsigned* A0 = smem + stage * STAGE + (lane >> 5) * PLANE_A + wm * (BC / 2) + (lane & 31);
+      const unsigned* B0 = smem + stage * STAGE + 2 * PLANE_A + (lane >> 5) * PLANE_B + wn * (BD / 2) + (lane & 31);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = __uint_as_float(A0[t * BC + i * 32]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = __uint_as_float(B0[t * BD + j * 32]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     const unsigned* As = smem + stage * STAGE + wm * (BC / 2) + (lane & 31);
     const unsigned* Bs = smem + stage * STAGE + 2 * PLANE_A + wn * (BD / 2) + (lane & 31);
     const int prow = (lane >> 5) * 4;
@@ -483,6 +511,8 @@ int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, hipStream_t
   dim3 grid(tiles * splitk), block(256);
   if (prec == 1)
     hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 1>), grid, block, 0, st, a);
+  else if (prec == 0)
+    hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 0>), grid, block, 0, st, a);   // exact fp32 (test mode)
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 3>), grid, block, 0, st, a);
   return ZS3_LAUNCH_CHECK();
@@ -528,9 +558,10 @@ static int tile_override() {
 // kernel 2 (LDS-DMA, 256x256 tiles) takes the leading multiple-of-256 input channels when Cout fills 256-wide tiles;
 // a remainder of <= 128 input channels (the 304-channel decoder concat) goes to kernel 1 in a second launch over the
 // same split-K slabs.  Returns the number of input channels given to kernel 2.  ZS3_WGRAD_KERNEL=1|2 forces one (debug).
+static int g_wgrad_kernel = -1;   // zs3_conv_wgrad_set_kernel; -1: ZS3_WGRAD_KERNEL from the environment
 static int dma_width(int co, int ci, int wo, int M) {
-  static int v = -1;
-  if (v < 0) v = env_int("ZS3_WGRAD_KERNEL");
+  if (g_wgrad_kernel < 0) g_wgrad_kernel = env_int("ZS3_WGRAD_KERNEL");
+  const int v = g_wgrad_kernel;
   if (v == 1) return 0;
   if (v == 2) return ci;
   // short reductions (the GMMN generator's per-class pixel sets) stay on kernel 1: the 256x256 blocks' prologue, tile store
@@ -564,6 +595,14 @@ static int pick_splitk_dma(int M, int tiles, long out_elems) {
   }
   return best;
 }
+// 0: the rules above, 1: register-staged kernel for every layer (what the exact-fp32 test mode, prec = 0, needs), 2: LDS-DMA kernel
+// wherever Cin allows; returns the previous value.  Plans (zs3_conv_wgrad_plan) made under another setting are stale.
+extern "C" int zs3_conv_wgrad_set_kernel(int kernel) {
+  if (g_wgrad_kernel < 0) g_wgrad_kernel = env_int("ZS3_WGRAD_KERNEL");
+  const int old = g_wgrad_kernel;
+  if (kernel >= 0 && kernel <= 2) g_wgrad_kernel = kernel;
+  return old;
+}
 constexpr int STEM_FOLD = 32;   // channel count of the stem's NHWC4 windows (8 pixels x 4 channels)
 extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
   int s;
@@ -589,8 +628,9 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
                               int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read,
                               int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
                               const void* zero_page, void* stream) {
-  if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
+  if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 0 && prec != 1 && prec != 3) || zero_page == nullptr) return -1;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15)) return -2;
+  if (prec == 0 && dma_width(co_write, ci_write, Wo, N * Ho * Wo) > 0) return -7;   // exact fp32: zs3_conv_wgrad_set_kernel(1) first
   WgradArgs a;
   a.dy = dy; a.x = x; a.zero = (const float*)zero_page;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;

@@ -45,6 +45,29 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* 
   }
 }
 
+// Exact-fp32 test mode (prec = 0, conv_igemm.hip / conv_wgrad.hip on v_mfma_f32_32x32x2_f32): the same two operands as plain
+// fp32 [row][k] rows with the same zero padding.  A 32-wide K chunk is 128 bytes here as well, so the plane buffers, their
+// strides and the staging loads of conv_igemm_kernel are those of the packed bf16 {hi,lo} form.
+__global__ void prep_weight_f32_kernel(const float* __restrict__ w, float* __restrict__ f_pk, float* __restrict__ t_pk, int cout,
+                                       int taps, int cin, int cin_pad, int cout_pad) {
+  const long nf = (long)cout * taps * cin_pad;
+  const long nt = t_pk ? (long)cin * taps * cout_pad : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nt; i += (long)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int ci = (int)(i % cin_pad);
+      const long r = i / cin_pad;
+      const int tap = (int)(r % taps), co = (int)(r / taps);
+      f_pk[i] = ci < cin ? w[((long)co * taps + tap) * cin + ci] : 0.f;
+    } else {
+      const long kk = i - nf;
+      const int co = (int)(kk % cout_pad);
+      const long r = kk / cout_pad;
+      const int tap = (int)(r % taps), ci = (int)(r / taps);
+      t_pk[kk] = co < cout ? w[((long)co * taps + tap) * cin + ci] : 0.f;
+    }
+  }
+}
+
 // All weights of a model in one launch (after the optimizer step): table[e] = {w, f_pk, t_pk, cout, taps, cin, cin_pad,
 // cout_pad}, blockmap[b] = {entry, chunk}.  A chunk is one filter tap x 32 output channels x up to 256 input channels,
 // processed as 32x32 tiles: w is read once, coalesced along ci; the forward plane is written from registers (8 bytes
@@ -149,6 +172,17 @@ extern "C" int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout,
   if (blocks < 1) return 0;
   hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)f_pk,
                      (unsigned short*)t_pk, cout, taps, cin, cin_pad, cout_pad);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_prep_weight_f32(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad,
+                                   int cout_pad, void* stream) {
+  long total = (long)cout * taps * cin_pad + (t_pk ? (long)cin * taps * cout_pad : 0);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(prep_weight_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)f_pk, (float*)t_pk, cout,
+                     taps, cin, cin_pad, cout_pad);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -136,6 +136,9 @@ def refresh_planes(*params):
     """After an optimizer step through raw pointers: recompute the cached planes of every parameter that has any, in ONE
     launch (zs3_prep_weight_multi) into the existing plane buffers, instead of one zs3_prep_weight per layer at its next
     forward.  Parameters whose memory is not the [Cout][KH][KW][Cin] storage the planes were built from are invalidated."""
+    if ops.PREC_DEFAULT == 0:   # exact-fp32 test mode: the one-launch refresh writes bf16 planes
+        invalidate_planes(*params)
+        return
     todo = []
     for w in params:
         hit = _planes.get(id(w))

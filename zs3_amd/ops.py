@@ -12,7 +12,7 @@ import torch
 
 from ._lib import F, I, P, check, lib, require_gpu, stream
 
-PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs
+PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs; 0 = exact fp32 (test mode, set_exact_fp32)
 PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event, tile_cfg) per conv launch
 PROFILE_CFGS = None   # optional set of tile_cfg values to restrict the recording to (event pairs serialise kernel boundaries)
 PROFILE_SAMPLE = None  # optional [stride, phase, counter]: record every stride-th eligible launch (an event pair costs host time)
@@ -23,6 +23,30 @@ PW = os.environ.get("ZS3_PW", "1") == "1"                      # persistent poin
 PW_FORCE = int(os.environ.get("ZS3_PW_FORCE", "0"))           # 51 / 52: every eligible 1x1 layer on that tile (A/B runs)
 WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"         # producer-split weight gradient of the 1x1 stride-1 layers
 HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
+
+
+def set_exact_fp32(on=True):
+    """Test mode: every convolution / linear product on v_mfma_f32_32x32x2_f32 (prec = 0 of the register-staged kernels, ~1/16 of
+    the bf16 rate) -- the arithmetic of the reference's own fp32 convolutions, summation order aside.  It answers one question:
+    is a difference from the reference bf16x3 arithmetic or structure?  (tests/test_gpu_model.py runs the reference's default-init
+    train-mode goldens through it.)  Switches the producer-converting kernel families off, since they exist in bf16 only."""
+    global PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW
+    from . import functional as Fz
+    if on:
+        PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW = 0, False, False, False, False
+    else:
+        PREC_DEFAULT = 3
+        HALO = os.environ.get("ZS3_HALO", "1") == "1"
+        PW = os.environ.get("ZS3_PW", "1") == "1"
+        WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"
+        WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"
+    lib().zs3_conv_wgrad_set_kernel(I(1 if on else 0))
+    _TILE_CHOICE.clear()
+    _WGRAD_PLAN.clear()
+    _MTILES.clear()
+    Fz._planes.clear()
+    Fz._defer_choice.clear()
+    Fz._refresh_tables.clear()
 
 
 def halo_ok(x_shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg):
@@ -165,8 +189,8 @@ def prep_weight(w, need_t=True, cin_pad=None):
     dev = w.device
     f_pk = torch.empty((cout, 2 * taps * cin_pad), dtype=torch.bfloat16, device=dev)
     t_pk = torch.empty((cin, 2 * taps * cout_pad), dtype=torch.bfloat16, device=dev) if need_t else None
-    check(lib().zs3_prep_weight(P(wl), P(f_pk), P(t_pk), I(cout), I(taps), I(cin), I(cin_pad), I(cout_pad), stream()),
-          "zs3_prep_weight")
+    prep = lib().zs3_prep_weight_f32 if PREC_DEFAULT == 0 else lib().zs3_prep_weight   # same buffers: 4 bytes per element either way
+    check(prep(P(wl), P(f_pk), P(t_pk), I(cout), I(taps), I(cin), I(cin_pad), I(cout_pad), stream()), "zs3_prep_weight")
     return WeightPlanes(f_pk, t_pk, cout, cin, kh, kw, cin_pad, cout_pad)
 
 
@@ -180,6 +204,8 @@ _TILE_CHOICE, _MTILES = {}, {}
 def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec,
                  pw_epilogue):
     """tile_cfg of a conv launch: the caller's explicit choice where that kernel can run the launch, else the rules."""
+    if prec == 0:   # exact fp32 (test mode): register-staged kernel only
+        return tile_cfg if 0 < tile_cfg <= 14 else (14 if ncols <= 64 or ((m + 127) // 128) * ((ncols + 127) // 128) < 1000 else 11)
     if tile_cfg in (51, 52) and not (pw_epilogue and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
                                                            pad_w, tile_cfg)):
         tile_cfg = 0               # not a 1x1 stride-1 layer, or an epilogue the persistent kernel leaves to the others
@@ -212,7 +238,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     in_affine = (scale, shift): x is read through max(x * scale + shift, 0) by the kernel's producer waves (the BatchNorm-apply +
     ReLU of the layer that produced x; only the strip-resident / persistent pointwise kernels: ask `consumer_applies_bn` first)."""
     require_gpu(x, w_pk, out, scale, shift, res)
-    prec = prec or PREC_DEFAULT
+    prec = PREC_DEFAULT if (prec is None or PREC_DEFAULT == 0) else prec   # (the exact-fp32 test mode overrides per-call choices: its planes are fp32)
     n, h, w_, _ = x.shape
     ldx = _check_nhwc(x)
     if out is None:
@@ -335,7 +361,7 @@ def consumer_applies_bn(xshape, ldx, wp, stride, pad, dil, prec=None):
     """Can the conv that consumes x (NHWC shape `xshape`, row stride ldx) apply the BatchNorm + ReLU of the layer that produced x
     in its own operand path -- forward AND weight gradient on kernels whose producer waves convert the operand (strip-resident /
     pointwise)?  Then the producing layer skips its BN-apply pass and hands over its raw conv output (functional._ConvBnAct)."""
-    prec = prec or PREC_DEFAULT
+    prec = PREC_DEFAULT if (prec is None or PREC_DEFAULT == 0) else prec
     n, h, w_, _ = xshape
     ho, wo = conv_out_size(h, wp.kh, stride, pad, dil), conv_out_size(w_, wp.kw, stride, pad, dil)
     cin_valid = min(_round_up(wp.cin, 4), ldx)
@@ -352,7 +378,7 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
     """dy: NHWC [N,Ho,Wo,>=cout]; x: NHWC [N,H,W,>=cin] -> dw [cout, kh, kw, cin] (channels_last weight storage).
     x_affine = (scale, shift): x is read through max(x * scale + shift, 0) (strip-resident / pointwise kernels only)."""
     require_gpu(dy, x)
-    prec = prec or PREC_DEFAULT
+    prec = PREC_DEFAULT if (prec is None or PREC_DEFAULT == 0) else prec
     pad_w = pad_h if pad_w is None else pad_w
     n, ho, wo, _ = dy.shape
     _, h, w_, _ = x.shape
