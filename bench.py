@@ -108,7 +108,6 @@ def main():
     from zs3_amd.modeling.deeplab import DeepLab
     from zs3_amd.modeling.gmmn import GMMNnetwork
     from zs3_amd.optim import SGD, Adam
-    from zs3_amd.parallel import GradSync, broadcast_parameters, enable_sync_bn
     from zs3_amd.utils.loss import SegmentationLosses
     from zs3_amd.utils.lr_scheduler import LR_Scheduler
     from zs3_amd.utils.synthetic import make_batch
@@ -121,18 +120,20 @@ def main():
     seen = [c for c in range(args.classes) if c not in unseen]
     torch.manual_seed(1)
     model = DeepLab(num_classes=args.classes, pretrained=False, sync_bn=bool(args.sync_bn)).to(dev).train()
-    broadcast_parameters(model)
+    # (supervised: the model takes rank 0's parameters when it arms itself at its first training forward; GMMN workloads: GMMNStep
+    # does it at its first step)
     # sync_bn=True models exchange their BatchNorm sums across ranks by construction; nothing to switch on
     groups = [{"params": model.get_1x_lr_params(), "lr": 0.007}, {"params": model.get_10x_lr_params(), "lr": 0.07}]
     opt = SGD(groups, momentum=0.9, weight_decay=5e-4, nesterov=False)
-    crit = SegmentationLosses(cuda=True, group=True if (world > 1 or args.ddp_selftest) else None).build_loss("ce")
+    crit = SegmentationLosses(cuda=True).build_loss("ce")   # normalises over every rank's shard by itself when world > 1
     sched = LR_Scheduler("poly", 0.007, 50, 1000, verbose=False)
     multi = world > 1 or args.ddp_selftest
     if args.ddp_selftest:
         import zs3_amd.parallel as par
         par.FORCE_COLLECTIVES = True      # one-rank group: run every collective of the N>1 path anyway
-    # supervised step: bucketed gradient all-reduce from grad hooks; the GMMN step has its own two small exchanges (GMMNStep)
-    sync = GradSync(list(model.parameters()), force=args.ddp_selftest) if (multi and args.workload == "supervised") else None
+    # supervised step: the model arms its bucketed gradient all-reduce itself at its first training forward
+    # (zs3_amd.parallel.ensure_data_parallel, the path a reference script gets); the GMMN step has its own two small exchanges
+    sync, sync_bytes = None, None
     batch = make_batch(args.batch, args.size, args.classes, unseen, seed=1 + rank, device=dev)
     image, label = batch["image"], batch["label"]
 
@@ -193,21 +194,17 @@ def main():
         w = torch.ones(args.classes, device=dev)
         w[unseen] = 100.0
         dp = multi and args.workload != "supervised"
-        crit_g = SegmentationLosses(weight=w, cuda=True, group=True if dp else None).build_loss("ce")
+        crit_g = SegmentationLosses(weight=w, cuda=True).build_loss("ce")
         gb = make_batch(args.batch, args.size, args.classes, unseen, seed=101 + rank, with_label_emb=True, device=dev)
-        if dp:
-            broadcast_parameters(gen)
         if args.workload == "gcn_context":    # train_context_GMMN_GCNcontext.py step (BASELINE configs[4] flow)
             from zs3_amd.gcn_trainer import GCNContextStep
             from zs3_amd.modeling.gmmn import GMMNnetwork_GCN
             gcn = GMMNnetwork_GCN(300, 300, 256, 256).to(dev).train()
-            if dp:
-                broadcast_parameters(gcn)
             stepper = GCNContextStep(model, gen, gcn, opt, opt_g, Adam(gcn.parameters(), lr=2e-4), crit_g, seen=seen,
-                                     unseen=unseen, noise="device", group=True if dp else None)
+                                     unseen=unseen, noise="device")
         else:
             stepper = GMMNStep(model, gen, opt, opt_g, crit_g, seen=seen, unseen=unseen, noise="device",
-                               group=True if dp else None)
+                               )
         # next_image: the trainers look one batch ahead and start its frozen-backbone feature pass next to this batch's
         # generator loop (GMMNStep.prefetch); the synthetic loader returns the same batch every time
         fn = lambda i: stepper(gb["image"], gb["label"], gb["label_emb"], next_image=gb["image"] if args.gmmn_pipeline else None)
@@ -297,7 +294,11 @@ def main():
             dt, last = run(supervised_step, args.steps, args.warmup)
             prof, warm_prof = [], []
         gflop_img = TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7)
+        sync = getattr(model, "_zs3_grad_sync", None)      # armed by the model's first training forward when world > 1
+        sync_bytes = sync.bytes_reduced if sync is not None else None
         if args.gmmn_steps > 0 and world == 1:
+            from zs3_amd.parallel import disarm_data_parallel
+            disarm_data_parallel(model)   # (--ddp-selftest: the GMMN step exchanges pred_conv's gradients itself)
             gmmn_info = gmmn_report(build_gmmn(), args.gmmn_steps)
     else:
         gstep = build_gmmn()
@@ -325,7 +326,7 @@ def main():
         "model_frac_of_bf16_peak": value * gflop_img / 1e3 / (PEAK_BF16_TF * world),
     }
     if sync is not None:
-        result["rccl_bytes_per_rank_per_step"] = sync.bytes_reduced // max(1, args.steps + args.warmup)
+        result["rccl_bytes_per_rank_per_step"] = sync_bytes // max(1, args.steps + args.warmup)
     if gmmn_info:
         result["gmmn"] = gmmn_info
     if rank == 0 and prof:

@@ -124,6 +124,26 @@ def _worker(rank, world, port, q):
         assert sync.bytes_reduced > 0
         sync.remove()
         _zero_copy_and_global_ce(rank, world)
+        # data parallelism by construction: what DeepLab.forward / patch_replication_callback call
+        from zs3_amd import parallel
+        assert parallel.resolve_group("auto") is True and parallel.resolve_group(None) is None and parallel.resolve_group(False) is None
+        torch.manual_seed(200 + rank)     # different init per rank again: arming must hand every rank rank 0's parameters
+        lin = torch.nn.Linear(6, 4)
+        armed = parallel.ensure_data_parallel(lin)
+        assert armed is not None and parallel.ensure_data_parallel(lin) is armed and lin._zs3_grad_sync is armed
+        torch.manual_seed(200)
+        want0 = torch.nn.Linear(6, 4)
+        assert torch.equal(lin.weight, want0.weight) and torch.equal(lin.bias, want0.bias)
+        torch.manual_seed(300)
+        xs = [torch.randn(5, 6) for _ in range(world)]
+        lin(xs[rank]).sum().backward()    # no GradSync line here: the hooks ensure_data_parallel installed reduce the gradient
+        assert torch.allclose(lin.weight.grad, sum(x.sum(0) for x in xs).expand(4, 6), rtol=1e-6, atol=1e-6)
+        assert torch.allclose(lin.bias.grad, torch.full((4,), float(5 * world)))
+        parallel.disarm_data_parallel(lin)
+        assert lin._zs3_grad_sync is None
+        lin.zero_grad()
+        lin(xs[rank]).sum().backward()
+        assert torch.allclose(lin.weight.grad, xs[rank].sum(0).expand(4, 6), rtol=1e-6, atol=1e-6)   # local again
         # SyncBN statistics: global sums / count from per-rank chunk partials
         part = torch.arange(2 * 2 * 4, dtype=torch.float32).reshape(2, 2, 4) * (rank + 1)
         buf, cnt = combine_bn_partials(part, 10 * (rank + 1))

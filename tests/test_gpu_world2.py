@@ -1,14 +1,15 @@
 """World-size-2 run of the PRODUCT's N>1 path on ONE MI355X: two processes share cuda:0 and talk through the gloo backend on
 device tensors (RCCL refuses two ranks on one device; the collectives' call sites are the same for either backend).
 
-  supervised: DeepLab(sync_bn=True) + GradSync (zero-copy buckets, hooks, end-of-backward join) + the globally normalised CE
-              on two DIFFERENT shards must equal the single-process step on the concatenated batch -- logits (SyncBN
+  supervised: DeepLab(sync_bn=True) -- which arms GradSync by itself at its first training forward (zero-copy buckets, hooks,
+              end-of-backward join) -- + the CE, which normalises over both shards by itself: the worker's body names no
+              GradSync and no group.  Two DIFFERENT shards must equal the single-process step on the concatenated batch -- logits (SyncBN
               statistics are global), loss, every gradient, the BN running statistics.  SyncBN is on by construction: the
               script makes no enable call (zs3/modeling/sync_batchnorm/batchnorm.py:46-89, train_pascal.py:279).
-  GMMN step : GMMNStep(group=True) on two shards ends with identical generator / pred_conv weights on both ranks, the
+  GMMN step : GMMNStep (group="auto", the default) on two shards ends with identical generator / pred_conv weights on both ranks, the
               generator equal to the average of the two single-process runs on the shards (replicas with
               parameter averaging), the classifier loss equal to the CE normalised over both shards.
-  GCN-context: GCNContextStep(group=True): both generators (GMMN and graph) identical on both ranks and equal to the mean of the
+  GCN-context: GCNContextStep (likewise): both generators (GMMN and graph) identical on both ranks and equal to the mean of the
               two single-shard runs.
 """
 import os
@@ -42,17 +43,16 @@ def _tamed_model(sync_bn):
     return m
 
 
-def _supervised(dev, image, label, ddp):
-    from zs3_amd.parallel import GradSync, broadcast_parameters
+def _supervised(dev, image, label):
+    """The body a reference training script has -- model, criterion, forward, loss, backward -- and nothing else: no gradient-sync
+    object, no process-group argument, no SyncBN switch.  Under torch.distributed with two ranks the model arms its
+    gradient all-reduce at this first training forward, SyncBN exchanges its sums, and the criterion normalises over both
+    shards, all by construction; in a single process the same lines are the plain step."""
     from zs3_amd.utils.loss import SegmentationLosses
     m = _tamed_model(sync_bn=True).to(dev).train()
-    sync = None
-    if ddp:
-        broadcast_parameters(m)
-        sync = GradSync(list(m.parameters()), bucket_mb=16.0)
     w = torch.ones(21, device=dev)
     w[[10, 14]] = 100.0
-    crit = SegmentationLosses(weight=w, cuda=True, group=True if ddp else None).build_loss("ce")
+    crit = SegmentationLosses(weight=w, cuda=True).build_loss("ce")
     out = m(image)
     loss = crit(out, label)
     loss.backward()
@@ -66,13 +66,15 @@ def _supervised(dev, image, label, ddp):
            "running": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()
                        if k in ("backbone.bn1.running_mean", "backbone.layer3.5.bn2.running_var", "aspp.bn1.running_var",
                                 "decoder.last_conv.1.running_mean")}}
+    sync = getattr(m, "_zs3_grad_sync", None)     # what the model armed by itself (None in a single process)
     if sync is not None:
         res["bytes"] = sync.bytes_reduced
-        sync.remove()
+        from zs3_amd.parallel import disarm_data_parallel
+        disarm_data_parallel(m)
     return res
 
 
-def _gmmn(dev, image, label, table, ddp, steps=1):
+def _gmmn(dev, image, label, table, steps=1):
     from zs3_amd import functional as Fz
     from zs3_amd.gmmn_trainer import GMMNStep
     from zs3_amd.modeling.gmmn import GMMNnetwork
@@ -90,8 +92,8 @@ def _gmmn(dev, image, label, table, ddp, steps=1):
     w[[10, 14]] = 100.0
     groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
     opt, opt_g = SGD(groups, momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4)
-    crit = SegmentationLosses(weight=w, cuda=True, group=True if ddp else None).build_loss("ce")
-    step = GMMNStep(m, gen, opt, opt_g, crit, seen=seen, unseen=[10, 14], noise="cpu", group=True if ddp else None)
+    crit = SegmentationLosses(weight=w, cuda=True).build_loss("ce")
+    step = GMMNStep(m, gen, opt, opt_g, crit, seen=seen, unseen=[10, 14], noise="cpu")
     losses = []
     for it in range(steps):
         torch.manual_seed(21 + it)
@@ -102,8 +104,8 @@ def _gmmn(dev, image, label, table, ddp, steps=1):
             "pred_w": m.decoder.pred_conv.weight.detach().cpu().clone(), "pred_b": m.decoder.pred_conv.bias.detach().cpu().clone()}
 
 
-def _gcn(dev, image, label, table, ddp):
-    """GCNContextStep (train_context_GMMN_GCNcontext.py:239-457) with group=: the graph generator is a second replica"""
+def _gcn(dev, image, label, table):
+    """GCNContextStep (train_context_GMMN_GCNcontext.py:239-457): the graph generator is a second replica"""
     from zs3_amd import functional as Fz
     from zs3_amd.gcn_trainer import GCNContextStep
     from zs3_amd.modeling.gmmn import GMMNnetwork, GMMNnetwork_GCN
@@ -120,9 +122,8 @@ def _gcn(dev, image, label, table, ddp):
     w[[10, 14]] = 100.0
     groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
     opt, opt_g, opt_c = SGD(groups, momentum=0.9, weight_decay=5e-4), Adam(gen.parameters(), lr=2e-4), Adam(gcn.parameters(), lr=2e-4)
-    crit = SegmentationLosses(weight=w, cuda=True, group=True if ddp else None).build_loss("ce")
-    step = GCNContextStep(m, gen, gcn, opt, opt_g, opt_c, crit, seen=seen, unseen=[10, 14], noise="cpu", GCN_weight=0.1,
-                          group=True if ddp else None)
+    crit = SegmentationLosses(weight=w, cuda=True).build_loss("ce")
+    step = GCNContextStep(m, gen, gcn, opt, opt_g, opt_c, crit, seen=seen, unseen=[10, 14], noise="cpu", GCN_weight=0.1)
     torch.manual_seed(22)
     gl, gcl, cl, _ = step(image, label, table=table)
     torch.cuda.synchronize()
@@ -154,9 +155,9 @@ def _worker(rank, world, port, outdir):
     try:
         image, label, seen_only, table = _batch()
         sl = slice(2 * rank, 2 * rank + 2)
-        res = {"sup": _supervised(dev, image[sl].to(dev), label[sl].to(dev), ddp=True),
-               "gmmn": _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev), ddp=True),
-               "gcn": _gcn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev), ddp=True)}
+        res = {"sup": _supervised(dev, image[sl].to(dev), label[sl].to(dev)),
+               "gmmn": _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev)),
+               "gcn": _gcn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev))}
         torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
@@ -177,7 +178,7 @@ def test_two_ranks_on_one_device_equal_the_single_process_step():
         mp.spawn(_worker, args=(2, _free_port(), td), nprocs=2, join=True)
         r = [torch.load(os.path.join(td, f"rank{k}.pt")) for k in range(2)]
     # ---------------- supervised: two shards + SyncBN + GradSync + global CE == one process on the whole batch
-    one = _supervised(dev, image.to(dev), label.to(dev), ddp=False)
+    one = _supervised(dev, image.to(dev), label.to(dev))
     both = torch.cat([r[0]["sup"]["logits"], r[1]["sup"]["logits"]], 0)
     assert _rel(both, one["logits"]) < 2e-4                 # global BN statistics in every one of the 113 layers
     for k in range(2):
@@ -193,7 +194,7 @@ def test_two_ranks_on_one_device_equal_the_single_process_step():
     for a, b in zip(r[0]["gmmn"]["gen"], r[1]["gmmn"]["gen"]):
         assert torch.equal(a, b)
     assert torch.equal(r[0]["gmmn"]["pred_w"], r[1]["gmmn"]["pred_w"])
-    solo = [_gmmn(dev, image[2 * k:2 * k + 2].to(dev), seen_only[2 * k:2 * k + 2].to(dev), table.to(dev), ddp=False)
+    solo = [_gmmn(dev, image[2 * k:2 * k + 2].to(dev), seen_only[2 * k:2 * k + 2].to(dev), table.to(dev))
             for k in range(2)]
     for p2, pa, pb in zip(r[0]["gmmn"]["gen"], solo[0]["gen"], solo[1]["gen"]):
         assert _rel(p2, (pa + pb) / 2) < 1e-5               # generator = mean of the two ranks' locally trained replicas
@@ -210,7 +211,7 @@ def test_two_ranks_on_one_device_equal_the_single_process_step():
         for a, b in zip(r[0]["gcn"][key], r[1]["gcn"][key]):
             assert torch.equal(a, b), key
     assert torch.equal(r[0]["gcn"]["pred_w"], r[1]["gcn"]["pred_w"])
-    solo_g = [_gcn(dev, image[2 * k:2 * k + 2].to(dev), seen_only[2 * k:2 * k + 2].to(dev), table.to(dev), ddp=False)
+    solo_g = [_gcn(dev, image[2 * k:2 * k + 2].to(dev), seen_only[2 * k:2 * k + 2].to(dev), table.to(dev))
               for k in range(2)]
     for key in ("gen", "gcn"):
         for p2, pa, pb in zip(r[0]["gcn"][key], solo_g[0][key], solo_g[1][key]):

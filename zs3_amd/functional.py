@@ -57,6 +57,7 @@ def wgrad_stream(device):
 def join_wgrad_stream():
     """Make the current stream wait for every wgrad launched on the side streams (called at the end of backward)."""
     _join_armed[0] = False
+    _wgrad_side_of.clear()
     for pool in _side.values():
         for st in pool:
             torch.cuda.current_stream(st.device).wait_stream(st)
@@ -102,11 +103,25 @@ def register_grad_buffer(param, flat_view):
 
 _handed = set()          # parameters that already received their bucket slice in the running backward pass
 _handed_armed = [False]
+_wgrad_side_of = {}      # id(weight) -> side stream of its first weight-gradient launch in the running backward pass
 
 
 def _end_of_backward():
     _handed.clear()
     _handed_armed[0] = False
+
+
+def _reset_backward_state():
+    """The per-backward bookkeeping is normally cleared by engine callbacks at the end of the pass; those do not run when backward
+    raises (an out-of-memory error the caller catches and retries).  A fused layer's FORWARD means no backward pass of ours is in
+    flight, so it clears whatever a dead pass left behind -- otherwise grad_buffer() would answer None for every registered
+    parameter from then on and GradSync would silently fall back to its copy path."""
+    if _handed_armed[0] or _handed:
+        _end_of_backward()
+    if _join_armed[0]:
+        join_wgrad_stream()
+    if _wgrad_side_of:
+        _wgrad_side_of.clear()
 
 
 def grad_buffer(param):
@@ -255,6 +270,12 @@ class _ConvBnAct(torch.autograd.Function):
         drop = cfg.get("drop")   # (p, seed): nn.Dropout behind this layer's activation, fused into affine_act / bn_act_bwd
         y = a = st = mbits = None
         in_aff = cfg.get("in_affine")   # x is the RAW conv output of the producing layer: its BN-apply + ReLU runs in our producers
+        if in_aff is not None and not _applies_in_affine(x, wp, stride, pad, dil, prec, bn, residual, need_grad):
+            # the producer handed its raw output over expecting a training-mode consumer on the producer-converting kernels; this
+            # consumer runs otherwise (eval-mode BatchNorm with a residual epilogue, another precision, ...): apply the BatchNorm +
+            # ReLU here as the stored pass the producer skipped, and carry on as if nothing had been deferred
+            x = ops.affine_act(x, in_aff[0], in_aff[1], act=ACT_RELU)
+            in_aff = None
         conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, in_affine=in_aff, **k)) if geom is None else (
             lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, **geom, **k))
         defer = bool(cfg.get("defer_out"))
@@ -438,6 +459,14 @@ class _ConvBnAct(torch.autograd.Function):
                     dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec,
                                           out=_bucket_out(weight, wp), x_affine=ctx.x_affine)
                 dw.record_stream(main)
+                first_side = _wgrad_side_of.get(id(weight))
+                if first_side is not None:
+                    # a weight used by two layers: autograd ADDS this contribution to the first one on the main stream as soon as
+                    # both exist -- before the end-of-backward join -- so the main stream has to see both launches finished
+                    main.wait_stream(first_side)
+                    main.wait_stream(side)
+                else:
+                    _wgrad_side_of[id(weight)] = side
                 if not (weight.is_leaf and weight.grad is None):
                     # the gradient is READ inside this backward pass -- accumulated into an existing .grad (a second
                     # backward before the optimizer step) or propagated through a non-leaf weight (a transposed /
@@ -456,6 +485,33 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 dw = cfg["wgrad"](dy, x)
         return dx, dw, dgamma, dbeta, dbias, dres, None
+
+
+def _applies_in_affine(x, wp, stride, pad, dil, prec, bn, residual, need_grad):
+    """Will THIS layer's forward run on a kernel whose producers transform the operand (and its weight gradient likewise)?  The
+    launch that decides is the one _ConvBnAct.forward is about to make: with batch statistics (or a gradient to keep) the conv
+    has a store-only epilogue; an eval-mode no-grad layer fuses scale / shift / residual into it, and a residual makes it a
+    loading epilogue, which the persistent pointwise kernel leaves to the register-staged ones."""
+    n, h, w_, _ = x.shape
+    ldx = ops._rows(x)[2]
+    if wp.cin % 4 or ldx % 4:
+        return False
+    prec = ops.PREC_DEFAULT if (prec is None or ops.PREC_DEFAULT == 0) else prec
+    store_only = residual is None or (bn is not None and (bn["training"] or need_grad))
+    key = (n, h, w_, ldx, wp.cin, wp.cout, wp.kh, wp.kw, stride, pad, dil, prec, store_only, need_grad, ops.HALO, ops.HALO_BM, ops.PW,
+           ops.PW_FORCE, ops.WGRAD_STRIP, ops.WGRAD_PW)
+    hit = _in_affine_choice.get(key)
+    if hit is None:
+        ho, wo = ops.conv_out_size(h, wp.kh, stride, pad, dil), ops.conv_out_size(w_, wp.kw, stride, pad, dil)
+        tile = ops._choose_tile(0, x.shape, n * ho * wo, ho, wo, wp.cin_pad, min(ops._round_up(wp.cin, 4), ldx), ldx, wp.kh, wp.kw,
+                                stride, pad, pad, dil, wp.cout, False, prec, store_only)
+        hit = tile in (41, 42, 51, 52) and (not need_grad or ops._wgrad_plan(
+            n, h, w_, ho, wo, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout, wp.cin)[0] in ("strip", "pw"))
+        _in_affine_choice[key] = hit
+    return hit
+
+
+_in_affine_choice = {}
 
 
 def _bucket_out(weight, wp):
@@ -485,7 +541,7 @@ def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
     cout, _, kh, kw = weight.shape if weight.dim() == 4 else (*weight.shape, 1, 1)
     oshape = (n, ops.conv_out_size(h, kh, stride, pad, dil), ops.conv_out_size(w_, kw, stride, pad, dil), cout)
     key = (oshape, tuple(next_conv.weight.shape), next_conv.stride[0], next_conv.padding[0], next_conv.dilation[0],
-           next_conv.bias is None, prec, ops.PREC_DEFAULT, ops.HALO, ops.PW, ops.WGRAD_STRIP, ops.WGRAD_PW)
+           next_conv.bias is None, prec, ops.PREC_DEFAULT, ops.HALO, ops.HALO_BM, ops.PW, ops.PW_FORCE, ops.WGRAD_STRIP, ops.WGRAD_PW)
     hit = _defer_choice.get(key)
     if hit is None:
         nw = next_conv.weight
@@ -508,6 +564,8 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
     # dropout: (p, training) of an nn.Dropout that follows this layer's activation.  conv + BN + ReLU layers without a residual
     # (every dropout of the network sits behind one: aspp.py:100, decoder.py:19,23) take it into the BN-apply pass and its
     # backward (same mask as the stand-alone kernel, same position in the seed stream); anything else gets the separate pass.
+    if _handed_armed[0] or _join_armed[0]:
+        _reset_backward_state()
     drop, drop_after = None, None
     if dropout is not None and dropout[1] and dropout[0] > 0.0:
         if dropout[0] >= 1.0:
@@ -546,7 +604,7 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
             else:
                 nbt = bn.num_batches_tracked   # incremented by the finalize kernel
         cfg["bn"] = {"training": use_batch, "nbt": nbt, "eps": bn.eps, "momentum": mom if mom is not None else 0.0,
-                     "sync": getattr(bn, "_zs3_sync_group", None),
+                     "sync": getattr(bn, "_zs3_sync_group", None) if use_batch else None,   # eval never touches torch.distributed
                      "running_mean": bn.running_mean if (bn.training and bn.track_running_stats) or not use_batch else None,
                      "running_var": bn.running_var if (bn.training and bn.track_running_stats) or not use_batch else None}
     res = _ConvBnAct.apply(x, weight, gamma, beta, bias, residual, cfg)
@@ -617,7 +675,7 @@ def bn_act(y, bn, act=ACT_NONE, out=None):
             nbt = bn.num_batches_tracked
     track = bn.training and bn.track_running_stats
     cfg = {"training": use_batch, "nbt": nbt, "eps": bn.eps, "momentum": mom if mom is not None else 0.0, "act": act, "out": out,
-           "sync": getattr(bn, "_zs3_sync_group", None),
+           "sync": getattr(bn, "_zs3_sync_group", None) if use_batch else None,
            "running_mean": bn.running_mean if track or not use_batch else None,
            "running_var": bn.running_var if track or not use_batch else None}
     return _BnAct.apply(y, bn.weight, bn.bias, cfg)

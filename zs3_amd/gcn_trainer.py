@@ -54,6 +54,9 @@ class GCNContextStep(GMMNStep):
     def _replica_parameters(self):
         return list(self.generator.parameters()) + list(self.generator_GCN.parameters())
 
+    def _replica_modules(self):
+        return [self.generator, self.generator_GCN]
+
     # ---- per batch: every image's cluster graph in one launch (:307-322), counts read back with the class histogram
     def _before_images(self, label_maps):
         self._graphs = ClusterGraphBatch(label_maps, self.max_clusters)

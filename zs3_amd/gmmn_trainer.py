@@ -54,11 +54,28 @@ CHAIN_SIZES = tuple(1 << k for k in range(CHAIN_MAX.bit_length() - 1, -1, -1))
 class GMMNStep:
     _hook_reads_generator = True   # does _after_image() need the generator's weights up to date? (GCNContextStep: no)
 
+    @property
+    def group(self):
+        """the process group of this step's two exchanges (None: single process), resolved when asked: "auto" follows
+        torch.distributed's state"""
+        from .parallel import resolve_group
+        return resolve_group(self._group_arg)
+
+    @property
+    def grad_reduce(self):
+        """"sum" when the criterion normalises by the global batch / valid-pixel weight (SegmentationLosses' group), else "mean" """
+        if self._grad_reduce_arg is not None:
+            return self._grad_reduce_arg
+        from .parallel import resolve_group
+        owner = getattr(self.criterion, "__self__", None)
+        return "sum" if resolve_group(getattr(owner, "group", None)) is not None else "mean"
+
     def __init__(self, model, generator, optimizer, optimizer_generator, criterion, *, seen, unseen, noise_dim=300,
                  embed_dim=300, feature_dim=256, batch_size_generator=128, real_seen_features=True,
-                 sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True, group=None, grad_reduce=None,
+                 sigma=(2, 5, 10, 20, 40, 80), noise="device", use_graph=True, group="auto", grad_reduce=None,
                  context_aware=False, fused_mlp=True):
-        """group: None (single process) | True (default process group) | a torch.distributed group.
+        """group: "auto" (replicas with parameter averaging as soon as torch.distributed runs with more than one rank; resolved at
+        every step) | None (single process) | True (default process group) | a torch.distributed group.
         grad_reduce: "sum" when `criterion` already normalises by the global batch / valid-pixel weight
         (SegmentationLosses(group=...)), "mean" when it normalises per rank; default: picked from the criterion.
         context_aware: the generator's second input is the image's mean embedding over labelled pixels instead of
@@ -75,13 +92,11 @@ class GMMNStep:
         self.context_aware = bool(context_aware)
         if self.context_aware and noise_dim != embed_dim:
             raise ValueError("context_aware feeds the mean embedding where the noise goes: noise_dim must equal embed_dim")
-        self.group = group
-        if grad_reduce is None:
-            owner = getattr(criterion, "__self__", None)
-            grad_reduce = "sum" if getattr(owner, "group", None) is not None else "mean"
-        if grad_reduce not in ("sum", "mean"):
+        self._group_arg = group
+        if grad_reduce not in (None, "sum", "mean"):
             raise ValueError("grad_reduce must be 'sum' or 'mean'")
-        self.grad_reduce = grad_reduce
+        self._grad_reduce_arg = grad_reduce
+        self._dp_ready = False
         self.bytes_reduced = 0
         if not isinstance(generator.model, torch.nn.Sequential):
             raise NotImplementedError("GMMNStep needs the hidden-layer generator (hidden_size > 0)")
@@ -405,6 +420,9 @@ class GMMNStep:
         """parameters averaged over the ranks once per step in multi-GPU runs"""
         return list(self.generator.parameters())
 
+    def _replica_modules(self):
+        return [self.generator]
+
     # ------------------------------------------------------------------ frozen-backbone feature pass, pipelined
     def _features(self, image):
         with torch.no_grad():
@@ -456,6 +474,17 @@ class GMMNStep:
         require_gpu(image, target, embedding, table)
         model, dev = self.model, image.device
         b = image.shape[0]
+        if not self._dp_ready and self.group is not None:
+            # first step of a multi-rank run (every rank is here): all replicas start from rank 0's segmentation model and
+            # generator(s) -- nn.DataParallel's replicate guarantee, made once instead of at every forward
+            from .parallel import broadcast_parameters
+            pg = None if self.group is True else self.group
+            broadcast_parameters(model, group=pg)
+            for mod in self._replica_modules():
+                broadcast_parameters(mod, group=pg)
+            if self._st is not None:
+                self._resplit()
+            self._dp_ready = True
         real = self._take_features(image)
         if next_image is not None:      # the caller already knows the next batch: overlap its feature pass with this loop
             self.prefetch(next_image)   # (queued before the loop: 38.5 ms per step; after it: 39.9 ms; with the loop on a

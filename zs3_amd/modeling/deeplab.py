@@ -5,6 +5,7 @@ signature, the attributes `backbone` / `aspp` / `decoder`, the five forward vari
 LR-group generators (Conv/BN parameters of the backbone vs. of ASPP + decoder, in `named_modules()` order) and
 the 680 / 675 state-dict keys.  Everything numeric runs in libzs3hip.so; tensors cross this API as logical NCHW
 (channels_last in memory, which is the kernels' native NHWC)."""
+import torch
 import torch.nn as nn
 
 from .. import functional as Fz
@@ -42,6 +43,15 @@ class DeepLab(nn.Module):
 
     # ------------------------------------------------------------------ the reference's forward variants
     def forward(self, input):
+        if self.training and torch.is_grad_enabled():
+            # data parallelism by construction ("DDP must live inside the build's modules"): the supervised scripts
+            # run this forward in training mode on every rank (base_trainer.py:17), so under torch.distributed with more than
+            # one rank the first such call arms the gradient all-reduce -- no GradSync line in the training script.  The
+            # GMMN / GCN-context steps never come here with gradients enabled (they train pred_conv through
+            # forward_class_prediction and exchange its gradients themselves).
+            from .. import parallel
+            if getattr(self, "_zs3_grad_sync", None) is None:
+                parallel.ensure_data_parallel(self, broadcast=not getattr(self, "_zs3_broadcast_done", False))
         context, low = self._encode(input)
         features = self.decoder.features_nhwc(context, low)
         return self._logits_to_image(self.decoder.predict_nhwc(features), input.shape[2:])

@@ -22,15 +22,25 @@ from ..layers import BatchNorm2d
 class SynchronizedBatchNorm2d(BatchNorm2d):
     sync_enabled = True
     sync_group = None
+    _sync_cache = None   # (state the answer was computed under, answer); enable_sync_bn resets it
 
     @property
     def _zs3_sync_group(self):
-        """What zs3_amd.functional reads: None = local statistics, True = the default process group, or a group."""
+        """What zs3_amd.functional reads -- in training mode only, so an eval forward never touches torch.distributed:
+        None = local statistics, True = the default process group, or a group.  The answer is cached per module and recomputed
+        when the process-group state changes (113 layers x every forward would otherwise each ask torch.distributed)."""
         from ... import parallel
+        state = (self.sync_enabled, parallel.FORCE_COLLECTIVES, dist.is_available() and dist.is_initialized())
+        hit = self._sync_cache
+        if hit is not None and hit[0] == state:
+            return hit[1]
         if not self.sync_enabled:
-            return None
-        if parallel.FORCE_COLLECTIVES:          # single-rank plumbing tests run the whole reduction path
-            return self.sync_group if self.sync_group is not None else True
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.sync_group) < 2:
-            return None
-        return self.sync_group if self.sync_group is not None else parallel.bn_group()
+            ans = None
+        elif parallel.FORCE_COLLECTIVES:          # single-rank plumbing tests run the whole reduction path
+            ans = self.sync_group if self.sync_group is not None else True
+        elif not state[2] or dist.get_world_size(self.sync_group) < 2:
+            ans = None
+        else:
+            ans = self.sync_group if self.sync_group is not None else parallel.bn_group()
+        self._sync_cache = (state, ans)
+        return ans

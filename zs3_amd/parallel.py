@@ -16,6 +16,56 @@ import torch.distributed as dist
 # single-GPU plumbing tests set this to run the SyncBN reduction path with one rank
 FORCE_COLLECTIVES = False
 
+AUTO = "auto"
+
+
+def resolve_group(group):
+    """`group` arguments across the package: "auto" (the default everywhere) = the default process group as soon as
+    torch.distributed runs with more than one rank, nothing otherwise -- data parallelism by construction, the training script
+    names no group; None / False = never exchange; True = the default group; anything else = that process group."""
+    if group is None or group is False:
+        return None
+    if isinstance(group, str):
+        if group != AUTO:
+            raise ValueError(f"group must be 'auto', None, True or a process group, got {group!r}")
+        if FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized():
+            return True
+        return True if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    return group
+
+
+def ensure_data_parallel(module, broadcast=True):
+    """Arm `module` (a DeepLab) for one-process-per-GPU data parallelism; a no-op unless torch.distributed runs with more than
+    one rank.  COLLECTIVE: every rank must call it at the same point -- which is the case for its two callers, the first
+    training-mode forward of the model (zs3_amd.modeling.deeplab.DeepLab.forward) and `patch_replication_callback` (the call every
+    reference script makes right after wrapping the model, train_pascal.py:92).  Once per module: parameters and buffers are
+    made rank 0's (nn.DataParallel.replicate's guarantee, C1 of SURVEY 2.2), the SyncBN communicator is created, and GradSync
+    hooks the parameters (bucketed SUM all-reduce from the weight-gradient stream while backward runs).  Returns the GradSync
+    or None."""
+    sync = getattr(module, "_zs3_grad_sync", None)
+    if sync is not None:
+        return sync
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size() < 2 and not FORCE_COLLECTIVES:
+        return None
+    from . import functional as Fz
+    if any(id(p) in Fz._grad_buffers for p in module.parameters()):
+        return None      # the script manages a GradSync over these parameters itself
+    if broadcast:
+        broadcast_parameters(module)
+    bn_group()
+    sync = GradSync(list(module.parameters()), force=FORCE_COLLECTIVES and dist.get_world_size() < 2)
+    object.__setattr__(module, "_zs3_grad_sync", sync)
+    return sync
+
+
+def disarm_data_parallel(module):
+    sync = getattr(module, "_zs3_grad_sync", None)
+    if sync is not None:
+        sync.remove()
+        object.__setattr__(module, "_zs3_grad_sync", None)
+
 
 class GradSync:
     def __init__(self, params, process_group=None, bucket_mb=64.0, average=False, force=False):
@@ -178,6 +228,7 @@ def broadcast_parameters(module, src=0, group=None):
     # writes through .data do not bump the autograd version counter the bf16 weight-plane cache is keyed on
     from . import functional as Fz
     Fz.invalidate_planes(*module.parameters())
+    bn_group()   # a point every rank reaches together: create the SyncBN communicator here rather than in some forward
 
 
 def all_reduce_tensors(tensors, group=None, average=False, force=False):
@@ -215,10 +266,14 @@ def bn_group():
     GradSync launches from the weight-gradient stream while backward is still running.  `ZS3_BN_GROUP=0`: the default group."""
     global _bn_group
     import os
-    if os.environ.get("ZS3_BN_GROUP", "1") != "1" or not dist.is_initialized() or dist.get_world_size() < 2:
+    if not dist.is_initialized() or dist.get_world_size() < 2:
         return True
     if _bn_group is None:
-        _bn_group = dist.new_group()
+        # dist.new_group() is itself a collective: it happens here exactly once, and the callers that reach this first are
+        # collective points by contract -- ensure_data_parallel (first training forward / patch_replication_callback) and
+        # broadcast_parameters; a synchronised BatchNorm forward only gets here in training mode (eval forwards, e.g. a
+        # rank-0-only validation, never touch torch.distributed).  The choice is remembered so later calls cost one test.
+        _bn_group = dist.new_group() if os.environ.get("ZS3_BN_GROUP", "1") == "1" else True
     return _bn_group
 
 
@@ -254,5 +309,6 @@ def enable_sync_bn(module, group=None, enabled=True):
         if isinstance(m, SynchronizedBatchNorm2d):
             m.sync_group = group
             m.sync_enabled = bool(enabled)
+            m._sync_cache = None
             n += 1
     return n

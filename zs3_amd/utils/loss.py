@@ -28,6 +28,8 @@ class _CrossEntropy(torch.autograd.Function):
         check(lib().zs3_ce_fwd(P(z), I(ld), P(target), I(int(target.dtype == torch.int64)), P(weight), ctypes.c_long(pix),
                                I(c), I(ignore_index), I(batch), P(part), P(loss_ws), stream()), "zs3_ce_fwd")
         loss = loss_ws[0].clone()
+        from ..parallel import resolve_group
+        group = resolve_group(group)
         if group is not None:
             loss, batch = global_ce_normalise(loss_ws, batch, group)
         ctx.save_for_backward(z, target, weight, loss_ws)
@@ -58,8 +60,10 @@ def global_ce_normalise(loss_ws, batch, group):
     return loss_ws[2] / loss_ws[1] / (batch if batch > 0 else 1), batch
 
 
-def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True, group=None):
-    """group: None (single process) | True (default process group) | a torch.distributed group."""
+def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True, group="auto"):
+    """group: "auto" (normalise over every rank's shard as soon as torch.distributed runs with more than one rank: the loss of
+    the gathered batch that nn.DataParallel hands the reference's criterion) | None (this process only) | True (default process
+    group) | a torch.distributed group."""
     if weight is not None:
         weight = weight.to(device=logit.device, dtype=torch.float32).contiguous()
     batch = logit.shape[0] if batch_average else 0
@@ -67,7 +71,7 @@ def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average
 
 
 class SegmentationLosses:
-    def __init__(self, weight=None, size_average=True, batch_average=True, ignore_index=255, cuda=False, group=None):
+    def __init__(self, weight=None, size_average=True, batch_average=True, ignore_index=255, cuda=False, group="auto"):
         self.group = group
         self.ignore_index = ignore_index
         self.weight = weight
