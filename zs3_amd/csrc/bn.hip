@@ -36,8 +36,11 @@ struct ColArgs {
   unsigned long long drop_seed;
 };
 
-template <int MODE>
+template <int MODE, typename T = float>   // T: element type of the activation tensors x / a / y (float or bf16_t)
 __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
+  const T* const px = reinterpret_cast<const T*>(p.x);
+  const T* const pa = reinterpret_cast<const T*>(p.a);
+  const T* const py = reinterpret_cast<const T*>(p.y);
   __shared__ float red[2][256 * 4];
   const int c4n = p.C >> 2;                       // channel quads
   const int tx_n = c4n < 256 ? c4n : 256;         // threads along channels
@@ -62,12 +65,12 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
         }
       }
       for (int r = row0 + ty; r < row1; r += ty_n) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (size_t)r * p.ldx + cq * 4);
+        f32x4 v = ld4<T>(px + (size_t)r * p.ldx + cq * 4);
         if (MODE == 0) {
           s += v;
           q += v * v;
         } else {
-          f32x4 yv = *reinterpret_cast<const f32x4*>(p.y + (size_t)r * p.ldy + cq * 4);
+          f32x4 yv = ld4<T>(py + (size_t)r * p.ldy + cq * 4);
           if (p.drop_p > 0.f) {
             const unsigned long long e = (unsigned long long)r * p.C + cq * 4;
 #pragma unroll
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = (mb >> k) & 1u ? v[k] : 0.f;
           } else if (p.a) {
-            f32x4 av = *reinterpret_cast<const f32x4*>(p.a + (size_t)r * p.lda + cq * 4);
+            f32x4 av = ld4<T>(pa + (size_t)r * p.lda + cq * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = av[k] > 0.f ? v[k] : 0.f;
           } else if (p.mscale) {
@@ -264,11 +267,12 @@ __device__ __forceinline__ AffCol aff_col(const AffArgs& p, int cq) {
   c.shift = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cq) : f32x4{0.f, 0.f, 0.f, 0.f};
   return c;
 }
+template <typename TI, typename TO>   // element types of x / res (TI) and out (TO)
 __device__ __forceinline__ void aff_elem(const AffArgs& p, long i, long m, int cq, const AffCol& col) {
   const long ms = p.div > 1 ? m / p.div : m;
-  f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ms * p.ldx + cq);
+  f32x4 v = ld4<TI>(reinterpret_cast<const TI*>(p.x) + ms * p.ldx + cq);
   f32x4 r = {0.f, 0.f, 0.f, 0.f};
-  if (p.res) r = *reinterpret_cast<const f32x4*>(p.res + m * p.ldr + cq);
+  if (p.res) r = ld4<TI>(reinterpret_cast<const TI*>(p.res) + m * p.ldr + cq);
   if (p.scale) v = v * col.scale;
   if (p.shift) v = v + col.shift;
   v = v * p.alpha;
@@ -286,10 +290,11 @@ __device__ __forceinline__ void aff_elem(const AffArgs& p, long i, long m, int c
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = u01(p.drop_seed, e + k) >= p.drop_p ? v[k] * p.drop_inv_keep : 0.f;
   }
-  float* dst = p.out + m * p.ldo + cq;
-  if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
-  *reinterpret_cast<f32x4*>(dst) = v;
+  TO* dst = reinterpret_cast<TO*>(p.out) + m * p.ldo + cq;
+  if (p.accumulate) v = v + ld4<TO>(dst);
+  st4<TO>(dst, v);
 }
+template <typename TI = float, typename TO = float>
 __global__ __launch_bounds__(256) void affine_act_kernel(const AffArgs p) {
   const int c4n = p.C >> 2;
   const long total = p.M * c4n;
@@ -302,12 +307,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const AffArgs p) {
     const int cq = (int)(i0 - m * c4n) * 4;
     const long dm = stride / c4n;
     const AffCol col = aff_col(p, cq);
-    for (long i = i0; i < total; i += stride, m += dm) aff_elem(p, i, m, cq, col);
+    for (long i = i0; i < total; i += stride, m += dm) aff_elem<TI, TO>(p, i, m, cq, col);
   } else {
     for (long i = i0; i < total; i += stride) {
       const long m = i / c4n;
       const int cq = (int)(i - m * c4n) * 4;
-      aff_elem(p, i, m, cq, aff_col(p, cq));
+      aff_elem<TI, TO>(p, i, m, cq, aff_col(p, cq));
     }
   }
 }
@@ -348,10 +353,11 @@ __device__ __forceinline__ BwdCol bwd_col(const BnBwdArgs& p, int cq) {
   c.msh = from_y ? *reinterpret_cast<const f32x4*>(p.mshift + cq) : zero;
   return c;
 }
+template <typename T>   // element type of every activation tensor of the call (dA, a, y, dy, dres)
 __device__ __forceinline__ void bwd_elem(const BnBwdArgs& p, long i, long m, int cq, const BwdCol& col) {
-  f32x4 dz = *reinterpret_cast<const f32x4*>(p.dA + m * p.ldd + cq);
+  f32x4 dz = ld4<T>(reinterpret_cast<const T*>(p.dA) + m * p.ldd + cq);
   f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-  if (p.y) yv = *reinterpret_cast<const f32x4*>(p.y + m * p.ldy + cq);
+  if (p.y) yv = ld4<T>(reinterpret_cast<const T*>(p.y) + m * p.ldy + cq);
   if (p.drop_p > 0.f) {   // backward of the fused dropout: the same mask, recomputed
     const unsigned long long e = (unsigned long long)m * p.C + cq;
 #pragma unroll
@@ -362,7 +368,7 @@ __device__ __forceinline__ void bwd_elem(const BnBwdArgs& p, long i, long m, int
 #pragma unroll
     for (int k = 0; k < 4; ++k) dz[k] = (mb >> k) & 1u ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
   } else if (p.a) {
-    f32x4 av = *reinterpret_cast<const f32x4*>(p.a + m * p.lda + cq);
+    f32x4 av = ld4<T>(reinterpret_cast<const T*>(p.a) + m * p.lda + cq);
 #pragma unroll
     for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : (p.act == 2 ? dz[k] * p.leak : 0.f);
   } else if (p.mscale) {
@@ -371,10 +377,10 @@ __device__ __forceinline__ void bwd_elem(const BnBwdArgs& p, long i, long m, int
     for (int k = 0; k < 4; ++k) dz[k] = av[k] > 0.f ? dz[k] : 0.f;
   }
   if (p.dres) {
-    float* dr = p.dres + m * p.ldr + cq;
+    T* dr = reinterpret_cast<T*>(p.dres) + m * p.ldr + cq;
     f32x4 o = dz;
-    if (p.dres_accumulate) o = o + *reinterpret_cast<const f32x4*>(dr);
-    *reinterpret_cast<f32x4*>(dr) = o;
+    if (p.dres_accumulate) o = o + ld4<T>(dr);
+    st4<T>(dr, o);
   }
   if (p.dy) {
     f32x4 out;
@@ -384,9 +390,10 @@ __device__ __forceinline__ void bwd_elem(const BnBwdArgs& p, long i, long m, int
     } else {
       out = col.g * col.is * dz;
     }
-    *reinterpret_cast<f32x4*>(p.dy + m * p.ldo + cq) = out;
+    st4<T>(reinterpret_cast<T*>(p.dy) + m * p.ldo + cq, out);
   }
 }
+template <typename T = float>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
   const int c4n = p.C >> 2;
   const long total = p.M * c4n;
@@ -397,12 +404,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const BnBwdArgs p) {
     const int cq = (int)(i0 - m * c4n) * 4;
     const long dm = stride / c4n;
     const BwdCol col = bwd_col(p, cq);
-    for (long i = i0; i < total; i += stride, m += dm) bwd_elem(p, i, m, cq, col);
+    for (long i = i0; i < total; i += stride, m += dm) bwd_elem<T>(p, i, m, cq, col);
   } else {
     for (long i = i0; i < total; i += stride) {
       const long m = i / c4n;
       const int cq = (int)(i - m * c4n) * 4;
-      bwd_elem(p, i, m, cq, bwd_col(p, cq));
+      bwd_elem<T>(p, i, m, cq, bwd_col(p, cq));
     }
   }
 }
@@ -415,17 +422,18 @@ struct SumArgs {
   long n4;
   int n;
 };
+template <typename T = float>
 __global__ __launch_bounds__(256) void sum_n_kernel(const SumArgs p) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (k < p.n) v[k] = reinterpret_cast<const f32x4*>(p.src[k])[i];
+      if (k < p.n) v[k] = ld4<T>(reinterpret_cast<const T*>(p.src[k]) + 4 * i);
     f32x4 acc = v[0];
 #pragma unroll
     for (int k = 1; k < 8; ++k)
       if (k < p.n) acc += v[k];
-    reinterpret_cast<f32x4*>(p.out)[i] = acc;
+    st4<T>(reinterpret_cast<T*>(p.out) + 4 * i, acc);
   }
 }
 
@@ -433,8 +441,11 @@ __global__ __launch_bounds__(256) void sum_n_kernel(const SumArgs p) {
 // (64 channel quads per block left the ASPP pool -- 16 images x 2048 channels x 1089 pixels, 143 MB -- with 128 workgroups of
 // 272-row serial chains: 154 us; 16 quads per block = 512 workgroups, 68 rows per thread.)
 constexpr int GCS_TX = 16;
-__global__ __launch_bounds__(256) void group_colsum_kernel(const float* x, int ldx, int R, int C, float scale, float* out,
+template <typename T = float>   // x and out share the element type
+__global__ __launch_bounds__(256) void group_colsum_kernel(const float* x_, int ldx, int R, int C, float scale, float* out_,
                                                           int ldo) {
+  const T* const x = reinterpret_cast<const T*>(x_);
+  T* const out = reinterpret_cast<T*>(out_);
   __shared__ float red[256 * 4];
   const int c4n = C >> 2;
   const int tx_n = c4n < GCS_TX ? c4n : GCS_TX;   // 16 lanes x 16 B = 256 contiguous bytes of a row; 16 row groups per block
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(256) void group_colsum_kernel(const float* x, int l
   const bool ok = ty < ty_n && cq < c4n;
   if (ok) {
 #pragma unroll 8
-    for (int r = ty; r < R; r += ty_n) s += *reinterpret_cast<const f32x4*>(x + ((size_t)g * R + r) * ldx + cq * 4);
+    for (int r = ty; r < R; r += ty_n) s += ld4<T>(x + ((size_t)g * R + r) * ldx + cq * 4);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) red[tid * 4 + k] = ok ? s[k] : 0.f;
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(256) void group_colsum_kernel(const float* x, int l
     for (int gg = 0; gg < ty_n; ++gg)
 #pragma unroll
       for (int k = 0; k < 4; ++k) t[k] += red[((gg * tx_n) + tx) * 4 + k];
-    *reinterpret_cast<f32x4*>(out + (size_t)g * ldo + cq * 4) = t * scale;
+    st4<T>(out + (size_t)g * ldo + cq * 4, t * scale);
   }
 }
 
@@ -481,21 +492,22 @@ extern "C" int zs3_colstats_plan(int M, int C, int* chunks, int* rows_per_block)
   return 0;
 }
 
-extern "C" int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, void* stream) {
-  if (C % 4 || ldx % 4) return -1;
+extern "C" int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, int io, void* stream) {
+  if (C % 4 || ldx % 4 || (io & ~1)) return -1;
   ColArgs a{};
   a.x = x; a.partial = partial; a.M = M; a.C = C; a.ldx = ldx;
   int chunks;
   zs3_colstats_plan(M, C, &chunks, &a.rows_per_block);
-  hipLaunchKernelGGL(colstats_kernel<0>, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  if (io & ZS3_IO_IN16) hipLaunchKernelGGL((colstats_kernel<0, bf16_t>), dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((colstats_kernel<0, float>), dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }
 
 extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy,
                                 const float* mean, const float* invstd, const float* mask_scale,
                                 const float* mask_shift, const unsigned char* mask_bits, int M, int C, float* partial,
-                                float drop_p, unsigned long long drop_seed, void* stream) {
-  if (C % 4 || ldd % 4 || ldy % 4 || (a_out && lda % 4) || drop_p < 0.f || drop_p >= 1.f) return -1;
+                                float drop_p, unsigned long long drop_seed, int io, void* stream) {
+  if (C % 4 || ldd % 4 || ldy % 4 || (a_out && lda % 4) || drop_p < 0.f || drop_p >= 1.f || (io & ~1)) return -1;
   ColArgs a{};
   a.drop_p = drop_p; a.drop_inv_keep = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
   a.x = dA; a.a = a_out; a.y = y; a.mean = mean; a.invstd = invstd; a.partial = partial;
@@ -503,7 +515,8 @@ extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, in
   a.M = M; a.C = C; a.ldx = ldd; a.lda = lda; a.ldy = ldy;
   int chunks;
   zs3_colstats_plan(M, C, &chunks, &a.rows_per_block);
-  hipLaunchKernelGGL(colstats_kernel<1>, dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  if (io & ZS3_IO_IN16) hipLaunchKernelGGL((colstats_kernel<1, bf16_t>), dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((colstats_kernel<1, float>), dim3(chunks), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -557,14 +570,21 @@ extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, doub
 extern "C" int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shift, float alpha,
                               const float* res, int ldr, float* out, int ldo, long M, int C, int div, int act,
                               float leak, int accumulate, unsigned char* mask_out, float drop_p,
-                              unsigned long long drop_seed, void* stream) {
-  if (C % 4 || ldx % 4 || ldo % 4 || (res && ldr % 4) || drop_p < 0.f || drop_p >= 1.f) return -1;
+                              unsigned long long drop_seed, int io, void* stream) {
+  if (C % 4 || ldx % 4 || ldo % 4 || (res && ldr % 4) || drop_p < 0.f || drop_p >= 1.f || (io & ~3)) return -1;
   if (M <= 0) return 0;
   AffArgs a;
   a.drop_p = drop_p; a.drop_inv_keep = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
   a.x = x; a.scale = scale; a.shift = shift; a.res = res; a.out = out; a.mask = mask_out; a.M = M; a.C = C; a.ldx = ldx; a.ldr = ldr;
   a.ldo = ldo; a.div = div; a.act = act; a.accumulate = accumulate; a.alpha = alpha; a.leak = leak;
-  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(ew_blocks(M * (C / 4)));
+  hipStream_t st = (hipStream_t)stream;
+  switch (io) {   // bit 0: x / res are bf16, bit 1: out is (a mixed call is the cast between the two storage forms)
+    case 0: hipLaunchKernelGGL((affine_act_kernel<float, float>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((affine_act_kernel<bf16_t, float>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((affine_act_kernel<float, bf16_t>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((affine_act_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, a); break;
+  }
   return ZS3_LAUNCH_CHECK();
 }
 
@@ -573,8 +593,9 @@ extern "C" int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int 
                               const float* c2, const float* mask_scale, const float* mask_shift,
                               const unsigned char* mask_bits, float* dy, int ldo, float* dres, int ldr,
                               int dres_accumulate, long M, int C, int act, float leak, float drop_p,
-                              unsigned long long drop_seed, void* stream) {
+                              unsigned long long drop_seed, int io, void* stream) {
   if (C % 4 || ldd % 4 || (dy && ldo % 4) || (a_out && lda % 4) || (dres && ldr % 4) || drop_p < 0.f || drop_p >= 1.f) return -1;
+  if (io != 0 && io != 3) return -1;   // every activation tensor of the call has one element type
   if (M <= 0) return 0;
   BnBwdArgs a;
   a.drop_p = drop_p; a.drop_inv_keep = 1.f / (1.f - drop_p); a.drop_seed = drop_seed;
@@ -582,31 +603,34 @@ extern "C" int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int 
   a.mscale = mask_scale; a.mshift = mask_shift; a.mbits = mask_bits;
   a.dy = dy; a.dres = dres; a.M = M; a.C = C; a.ldd = ldd; a.lda = lda; a.ldy = ldy; a.ldo = ldo; a.ldr = ldr;
   a.dres_accumulate = dres_accumulate; a.act = act; a.leak = leak;
-  hipLaunchKernelGGL(bn_act_bwd_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  if (io) hipLaunchKernelGGL((bn_act_bwd_kernel<bf16_t>), dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((bn_act_bwd_kernel<float>), dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }
 
-extern "C" int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo,
+extern "C" int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo, int io,
                                 void* stream) {
-  if (C % 4 || ldx % 4 || ldo % 4) return -1;
+  if (C % 4 || ldx % 4 || ldo % 4 || (io != 0 && io != 3)) return -1;
   if (G <= 0) return 0;
   int c4n = C / 4;
   int tx_n = c4n < GCS_TX ? c4n : GCS_TX;
   dim3 grid((c4n + tx_n - 1) / tx_n, G);
-  hipLaunchKernelGGL(group_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, scale, out, ldo);
+  if (io) hipLaunchKernelGGL((group_colsum_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, scale, out, ldo);
+  else hipLaunchKernelGGL((group_colsum_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, scale, out, ldo);
   return ZS3_LAUNCH_CHECK();
 }
 
 /* out[i] = src[0][i] + ... + src[n-1][i], 2 <= n <= 8 dense fp32 arrays of `count` elements (count % 4 == 0, 16-byte aligned);
  * srcs: HOST array of n device pointers.  out may alias src[0]. */
-extern "C" int zs3_sum_n(const void* const* srcs, int n, float* out, long count, void* stream) {
-  if (n < 2 || n > 8 || count <= 0 || (count & 3) || ((uintptr_t)out & 15)) return -1;
+extern "C" int zs3_sum_n(const void* const* srcs, int n, float* out, long count, int io, void* stream) {
+  if (n < 2 || n > 8 || count <= 0 || (count & 3) || ((uintptr_t)out & 15) || (io != 0 && io != 3)) return -1;
   SumArgs a = {};
   for (int k = 0; k < n; ++k) {
     if (!srcs[k] || ((uintptr_t)srcs[k] & 15)) return -1;
     a.src[k] = (const float*)srcs[k];
   }
   a.out = out; a.n4 = count / 4; a.n = n;
-  hipLaunchKernelGGL(sum_n_kernel, dim3(ew_blocks(count / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  if (io) hipLaunchKernelGGL((sum_n_kernel<bf16_t>), dim3(ew_blocks(count / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((sum_n_kernel<float>), dim3(ew_blocks(count / 4)), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }

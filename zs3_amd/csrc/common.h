@@ -49,11 +49,53 @@ __device__ __forceinline__ f32x4 affine_relu4(f32x4 v, f32x4 sc, f32x4 sh) {
   return f32x4{fmaxf(lo[0], 0.f), fmaxf(lo[1], 0.f), fmaxf(hi[0], 0.f), fmaxf(hi[1], 0.f)};
 }
 
+// ---- bf16-STORED activations (the 2-byte mode: BASELINE configs[4], `io` arguments of the C ABI) ---------------------------
+// Activation tensors are fp32 or bf16 in HBM; every kernel computes in fp32 registers.  Four channels = one 16-byte (fp32) or
+// 8-byte (bf16) access per lane.  `io` bit 0 (ZS3_IO_IN16): the call's activation INPUTS are bf16, bit 1 (ZS3_IO_OUT16): its
+// activation OUTPUTS are (conv: x | y, res, accumulate target, bn_y; wgrad: dy | x); strides stay in elements.
+typedef unsigned short bf16_t;
+#define ZS3_IO_IN16 1
+#define ZS3_IO_OUT16 2
+__device__ __forceinline__ f32x4 bf16x4_to_f32(u32x2 v) {
+  return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xFFFF0000u), __uint_as_float(v[1] << 16),
+               __uint_as_float(v[1] & 0xFFFF0000u)};
+}
+__device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v);
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const u32x2*>(p)); }
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return __uint_as_float(((unsigned)*p) << 16); }
+// run-time element type (conv epilogues: one wave-uniform test per row, not in any inner loop); `idx` in elements
+__device__ __forceinline__ f32x4 ld4_rt(const void* base, size_t idx, int bf16) {
+  return bf16 ? ld4<bf16_t>(static_cast<const bf16_t*>(base) + idx) : ld4<float>(static_cast<const float*>(base) + idx);
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   unsigned u = __float_as_uint(f);
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v) { return u32x2{cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3])}; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) { *reinterpret_cast<u32x2*>(p) = f32x4_to_bf16(v); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16_rne(v); }
+__device__ __forceinline__ void st4_rt(void* base, size_t idx, f32x4 v, int bf16) {
+  if (bf16) st4<bf16_t>(static_cast<bf16_t*>(base) + idx, v);
+  else st4<float>(static_cast<float*>(base) + idx, v);
+}
+__device__ __forceinline__ float ld1_rt(const void* base, size_t idx, int bf16) {
+  return bf16 ? ld1<bf16_t>(static_cast<const bf16_t*>(base) + idx) : static_cast<const float*>(base)[idx];
+}
+__device__ __forceinline__ void st1_rt(void* base, size_t idx, float v, int bf16) {
+  if (bf16) static_cast<bf16_t*>(base)[idx] = f32_to_bf16_rne(v);
+  else static_cast<float*>(base)[idx] = v;
 }
 
 // XCD-aware bijective remap of a 1-D block id: blocks that land on one XCD (id % 8) get a contiguous

@@ -25,7 +25,8 @@ struct ConvArgs {
   // tensor is never stored): x' = max(x * in_scale[c] + in_shift[c], 0).  Strip-resident and persistent pointwise kernels only.
   const float* in_scale;
   const float* in_shift;
-  int x_bf16;   // x is stored as bf16 (strip-resident kernel, tile_cfg 141 / 142); ldx then counts bf16 elements
+  int x_bf16;   // x is stored as bf16 (`io` bit 0; ldx counts elements)
+  int y_bf16;   // y -- and with it res, the accumulate target and bs_y: the layer-level activations of the output side -- are bf16 (`io` bit 1)
   float leak;
   // optional BatchNorm-backward statistics of the layer whose output gradient this launch produces (dgrad epilogue):
   // bs_partial[mtile][2][ncols] = (sum dz, sum dz*xhat) with dz = stored value * ReLU mask, xhat = (bs_y - mean) * istd
@@ -72,15 +73,16 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
       msh = *reinterpret_cast<const f32x4*>(p.bs_msh + col);
     }
   }
+  const int y16 = p.y_bf16;
   for (int rr = r0; rr < nrows; rr += RPP) {
     const int row = row_base + rr;
     if (row >= p.M || col >= p.ncols) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
     if (affine) v = v * sc + sh;
-    float* dst = p.y + (size_t)row * p.ldy + col;
+    const size_t di = (size_t)row * p.ldy + col;
     if (vec) {
       if (p.res) {
-        f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+        f32x4 rv = ld4_rt(p.res, (size_t)row * p.ldr + col, y16);
         if (p.res_mbits) {
           const unsigned mb = p.res_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
 #pragma unroll
@@ -95,10 +97,17 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
       }
-      if (p.accumulate) v = v + *reinterpret_cast<const f32x4*>(dst);
-      *reinterpret_cast<f32x4*>(dst) = v;
+      if (p.accumulate) v = v + ld4_rt(p.y, di, y16);
+      if (y16) {
+        // the BatchNorm-backward sums below are taken over the values the next kernel will read: the stored, rounded ones
+        const u32x2 pk = f32x4_to_bf16(v);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.y) + di) = pk;
+        v = bf16x4_to_f32(pk);
+      } else {
+        *reinterpret_cast<f32x4*>(p.y + di) = v;
+      }
       if (bstat) {
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(p.bs_y + (size_t)row * p.bs_ldy + col);
+        const f32x4 yv = ld4_rt(p.bs_y, (size_t)row * p.bs_ldy + col, y16);
         f32x4 dz = v;
         if (p.bs_mbits) {
           const unsigned mb = p.bs_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
@@ -117,11 +126,11 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
       for (int e = 0; e < 4; ++e)
         if (col + e < p.ncols) {
           float t = v[e];
-          if (p.res) t += p.res[(size_t)row * p.ldr + col + e];
+          if (p.res) t += ld1_rt(p.res, (size_t)row * p.ldr + col + e, y16);
           if (p.act == 1) t = fmaxf(t, 0.f);
           else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
-          if (p.accumulate) t += dst[e];
-          dst[e] = t;
+          if (p.accumulate) t += ld1_rt(p.y, di + e, y16);
+          st1_rt(p.y, di + e, t, y16);
         }
     }
   }

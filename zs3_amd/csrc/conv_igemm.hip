@@ -27,8 +27,14 @@
 
 namespace {
 
-template <int BM, int BN, int PREC, int PIPE>
+// A16: x is stored as bf16 (plain-bf16 products only): 8 bytes per lane and row piece, written to LDS as they arrive.
+template <int BM, int BN, int PREC, int PIPE, bool A16 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  static_assert(!A16 || PREC == 1, "bf16-stored input: plain bf16 products only");
+  using XT = std::conditional_t<A16, bf16_t, float>;             // element type of x in memory
+  using XV = std::conditional_t<A16, u32x2, f32x4>;              // four channels of it in registers
+  const XT* const xbase = reinterpret_cast<const XT*>(p.x);
+  const XT* const xzero = reinterpret_cast<const XT*>(p.zero);
   constexpr int ROW = 72;               // bf16 per LDS row (144 B)
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int STAGE = (BM + BN) * ROW;
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int q = tid & 7, tg = tid >> 3;
   const int srow = (tg & ~5) | ((tg & 1) << 2) | ((tg >> 2) & 1);   // 0..31
   constexpr int RA = BM / 32, RB = BN / 32;                          // rows of A / B staged per thread
-  const float* xrow[RA];
+  const XT* xrow[RA];
   int bh[RA], bw[RA];
   bool rvalid[RA];
 #pragma unroll
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     int hw = p.Ho * p.Wo;
     int n = mm / hw, rem = mm - n * hw;
     int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-    xrow[i] = p.x + (size_t)n * p.H * p.W * p.ldx;
+    xrow[i] = xbase + (size_t)n * p.H * p.W * p.ldx;
     if (p.dgrad) {
       bh[i] = oh + p.pad_h;
       bw[i] = ow + p.pad_w;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 
   struct Stage {
-    f32x4 areg[RA];
+    XV areg[RA];
     u32x4 breg[RB];
   };
   int kh = 0, kw = 0, c0 = 0, kofs = 0;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   // Branch-free tile loads: masked lanes read the zero page, so the loop body is straight-line code.  The
   // per-row gather address (bounds checks, 64-bit pointer) is recomputed only when a new filter tap
   // starts (c0 == 0, a wave-uniform test); inside a tap the pointer just advances by 32 channels.
-  const float* abase[RA];
+  const XT* abase[RA];
   int astep[RA];
   auto load_tile = [&](Stage& S) {
     if (c0 == 0) {
@@ -107,15 +113,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           ok = ok && ((hi | wi) >= 0);
         }
         ok = ok && hi < p.H && wi < p.W;
-        abase[i] = ok ? xrow[i] + ((hi * p.W + wi) * p.ldx + q * 4) : p.zero;
+        abase[i] = ok ? xrow[i] + ((hi * p.W + wi) * p.ldx + q * 4) : xzero;
         astep[i] = ok ? 1 : 0;
       }
     }
     const bool cok = c0 + q * 4 < p.cin_valid;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const float* ptr = cok ? abase[i] + c0 * astep[i] : p.zero;
-      S.areg[i] = *reinterpret_cast<const f32x4*>(ptr);
+      const XT* ptr = cok ? abase[i] + c0 * astep[i] : xzero;
+      S.areg[i] = *reinterpret_cast<const XV*>(ptr);
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) S.breg[j] = *reinterpret_cast<const u32x4*>(wrow[j] + 2 * kofs * wstep[j]);
@@ -138,6 +144,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     for (int i = 0; i < RA; ++i) {
       if constexpr (PREC == 0) {   // exact fp32 (test mode): the row holds the 32 raw floats of the K step
         *reinterpret_cast<f32x4*>(As + (srow + 32 * i) * ROW + q * 8) = S.areg[i];
+        continue;
+      }
+      if constexpr (A16) {         // already bf16: the four channels go to LDS as they came
+        *reinterpret_cast<u32x2*>(As + (srow + 32 * i) * ROW + q * 4) = S.areg[i];
         continue;
       }
       u32x2 hi, lo;
@@ -789,7 +799,10 @@ template <int BM, int BN, int PIPE>
 int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   int mt = (a.M + BM - 1) / BM, nt = (a.ncols + BN - 1) / BN;
   dim3 grid(mt * nt), block(256);
-  if (prec == 1)
+  if (a.x_bf16) {   // bf16-stored input: plain-bf16 products on the two-deep-prefetch form of the tile
+    if (prec != 1) return -7;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true>), grid, block, 0, st, a);
+  } else if (prec == 1)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, PIPE>), grid, block, 0, st, a);
   else if (prec == 0)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 0, PIPE>), grid, block, 0, st, a);   // exact fp32 (w_pk from zs3_prep_weight_f32)
@@ -820,7 +833,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
                            int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec, int tile_cfg,
                            const void* zero_page, void* stream, const float* bs_y, int bs_ldy, const float* bs_mean,
                            const float* bs_istd, const float* bs_msc, const float* bs_msh,
-                           const unsigned char* bs_mbits, float* bs_partial, const unsigned char* res_mbits,
+                           const unsigned char* bs_mbits, float* bs_partial, const unsigned char* res_mbits, int io,
                            const float* in_scale = nullptr, const float* in_shift = nullptr) {
   if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 0 && prec != 1 && prec != 3)) return -1;
   if (stride < 1 || (stride & (stride - 1)) != 0 || zero_page == nullptr) return -1;
@@ -839,7 +852,10 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
   a.zero = (const float*)zero_page;
   a.bs_y = bs_y; a.bs_ldy = bs_ldy; a.bs_mean = bs_mean; a.bs_istd = bs_istd; a.bs_msc = bs_msc; a.bs_msh = bs_msh;
   a.bs_mbits = bs_mbits; a.bs_partial = bs_partial; a.res_mbits = res_mbits;
-  a.x_bf16 = 0;
+  a.x_bf16 = io & ZS3_IO_IN16 ? 1 : 0;
+  a.y_bf16 = io & ZS3_IO_OUT16 ? 1 : 0;
+  if (io & ~3) return -1;
+  if (a.x_bf16 && (prec != 1 || in_scale)) return -7;   // bf16-stored input: plain-bf16 products, no producer-side transform
   a.in_scale = in_scale; a.in_shift = in_shift;
   if ((in_scale == nullptr) != (in_shift == nullptr) || ((uintptr_t)in_scale & 15) || ((uintptr_t)in_shift & 15)) return -1;
   a.stride_log2 = 0;
@@ -855,6 +871,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
   }
   if (in_scale && cfg != 41 && cfg != 42 && cfg != 51 && cfg != 52) return -7;   // only the producer-converting kernels transform x
   if (prec == 0 && cfg > 14) return -7;   // the exact-fp32 test mode exists on the register-staged kernel only
+  if (a.x_bf16 && cfg == 31) return -7;   // the LDS-DMA kernel moves raw fp32 rows
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 1>(a, prec, st);
     case 2: return launch_cfg<128, 64, 1>(a, prec, st);
@@ -867,7 +884,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 31: return launch_dma(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);
-    case 141: a.x_bf16 = 1; return zs3conv::launch_halo(a, 256, prec, st);   // x stored as bf16 (prec 1 only)
+    case 141: a.x_bf16 = 1; return zs3conv::launch_halo(a, 256, prec, st);   // (round-3 spelling of io bit 0 on tile_cfg 41 / 42)
     case 142: a.x_bf16 = 1; return zs3conv::launch_halo(a, 192, prec, st);
     case 51: return zs3conv::launch_pw(a, 256, prec, st);     // -7: not a 1x1 stride-1 layer (zs3_conv_pw_ok)
     case 52: return zs3conv::launch_pw(a, 128, prec, st);
@@ -879,10 +896,10 @@ extern "C" int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const 
                               const float* shift, const float* res, float* stat_partial, int N, int H, int W,
                               int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
                               int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int act, float leak,
-                              int accumulate, int dgrad, int prec, int tile_cfg, const void* zero_page, void* stream) {
+                              int accumulate, int dgrad, int prec, int tile_cfg, const void* zero_page, int io, void* stream) {
   return conv_igemm_impl(x, w_pk, y, scale, shift, res, stat_partial, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
                          stride, pad_h, pad_w, dil, ncols, ldy, ldr, act, leak, accumulate, dgrad, prec, tile_cfg,
-                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, io);
 }
 
 // zs3_conv_igemm with the input read through x' = max(x * in_scale[c] + in_shift[c], 0) (tile_cfg 41 / 42 / 51 / 52 only, -7 otherwise):
@@ -891,11 +908,11 @@ extern "C" int zs3_conv_igemm_in(const float* x, const void* w_pk, float* y, con
                                  const float* res, float* stat_partial, int N, int H, int W, int Ho, int Wo, int cin_pad,
                                  int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int ncols,
                                  int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec, int tile_cfg,
-                                 const void* zero_page, const float* in_scale, const float* in_shift, void* stream) {
+                                 const void* zero_page, const float* in_scale, const float* in_shift, int io, void* stream) {
   if (!in_scale || !in_shift) return -1;
   return conv_igemm_impl(x, w_pk, y, scale, shift, res, stat_partial, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
                          stride, pad_h, pad_w, dil, ncols, ldy, ldr, act, leak, accumulate, dgrad, prec, tile_cfg,
-                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, in_scale,
+                         zero_page, stream, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, io, in_scale,
                          in_shift);
 }
 
@@ -905,10 +922,10 @@ extern "C" int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y
                                       int ncols, int ldy, int ldr, int accumulate, int dgrad, int prec, int tile_cfg,
                                       const void* zero_page, const float* bn_y, int bn_ldy, const float* bn_mean,
                                       const float* bn_invstd, const float* mask_scale, const float* mask_shift,
-                                      const unsigned char* mask_bits, float* bn_partial, void* stream) {
+                                      const unsigned char* mask_bits, float* bn_partial, int io, void* stream) {
   if (!bn_partial && !res_mask_bits) return -1;
   return conv_igemm_impl(x, w_pk, y, nullptr, nullptr, res, nullptr, N, H, W, Ho, Wo, cin_pad, cin_valid, ldx, KH, KW,
                          stride, pad_h, pad_w, dil, ncols, ldy, ldr, 0, 0.f, accumulate, dgrad, prec, tile_cfg, zero_page,
                          stream, bn_y, bn_ldy, bn_mean, bn_invstd, mask_scale, mask_shift, mask_bits, bn_partial,
-                         res_mask_bits);
+                         res_mask_bits, io);
 }

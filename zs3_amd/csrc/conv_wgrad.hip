@@ -22,7 +22,7 @@
 namespace {
 
 struct WgradArgs {
-  const float* dy;
+  const float* dy;   // (bf16 when the launch says so: `io` bit 0 = dy, bit 1 = x; strides in elements)
   const float* x;
   float* dw;
   const float* zero;   // >= 256 B of zeros for masked loads
@@ -35,8 +35,11 @@ struct WgradArgs {
   int fold;   // > 0: the KH taps of a KH x 1 filter over `fold`-channel rows are folded into the channel axis (see zs3_conv_wgrad)
 };
 
-template <int BC, int BD, int PREC>  // BC = dy-channel (co) tile, BD = x-channel (ci) tile
+// TDY / TX: element types of dy / x in memory (float or bf16_t; bf16 storage with plain-bf16 products only)
+template <int BC, int BD, int PREC, typename TDY = float, typename TX = float>  // BC = dy-channel (co) tile, BD = x-channel (ci) tile
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  const TDY* const dybase = reinterpret_cast<const TDY*>(p.dy);
+  const TX* const xbase = reinterpret_cast<const TX*>(p.x);
   constexpr int PA = BC / 64, PB = BD / 64;   // pixel pairs per thread and stage
   constexpr int TM = BC / 64, TN = BD / 64;   // 32x32 tiles per wave
   constexpr int PLANE_A = 16 * BC, PLANE_B = 16 * BD;  // words per plane (16 pixel pairs)
@@ -73,14 +76,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   // Per-thread pixel slots.  A slot's pixel index advances by 32 every K step; (n, oh, ow) are carried
   // incrementally (one division when the block starts, none in the loop) and masked loads read the zero page,
   // so the loop body is branch-free apart from the wave-uniform trip count.
-  const float* aptr[PA][2];
+  const TDY* aptr[PA][2];
   int am[PA][2];
 #pragma unroll
   for (int i = 0; i < PA; ++i)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       am[i][e] = m_begin + 2 * (pra + SA * i) + e;
-      aptr[i][e] = p.dy + (size_t)am[i][e] * p.lddy + co0 + cqa;
+      aptr[i][e] = dybase + (size_t)am[i][e] * p.lddy + co0 + cqa;
     }
   int bm[PB][2], bn[PB][2], boh[PB][2], bow[PB][2];
   {
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < PA; ++i)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float* ptr = (a_cok && am[i][e] < m_end) ? aptr[i][e] : p.zero;
-        areg[i][e] = *reinterpret_cast<const f32x4*>(ptr);
+        const TDY* ptr = (a_cok && am[i][e] < m_end) ? aptr[i][e] : reinterpret_cast<const TDY*>(p.zero);
+        areg[i][e] = ld4<TDY>(ptr);
         am[i][e] += 32;
         aptr[i][e] += (size_t)32 * p.lddy;
       }
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       for (int e = 0; e < 2; ++e) {
         const int hi = boh[i][e] * p.stride + tap_h, wi = bow[i][e] * p.stride + tap_w;
         const bool ok = b_cok && bm[i][e] < m_end && ((hi | wi) >= 0) && hi < p.H && wi < p.W;
-        const float* ptr = ok ? p.x + ((((size_t)bn[i][e] * p.H + hi) * p.W + wi) * p.ldx + cch) : p.zero;
-        breg[i][e] = *reinterpret_cast<const f32x4*>(ptr);
+        const TX* ptr = ok ? xbase + ((((size_t)bn[i][e] * p.H + hi) * p.W + wi) * p.ldx + cch) : reinterpret_cast<const TX*>(p.zero);
+        breg[i][e] = ld4<TX>(ptr);
         // advance this slot by 32 pixels
         bm[i][e] += 32;
         bow[i][e] += 32;
@@ -506,10 +509,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restr
 }
 
 template <int BC, int BD>
-int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, hipStream_t st) {
+int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, int io, hipStream_t st) {
   int tiles = ((a.co_write + BC - 1) / BC) * ((a.ci_write + BD - 1) / BD) * taps;
   dim3 grid(tiles * splitk), block(256);
-  if (prec == 1)
+  if (io) {   // bf16-stored dy (bit 0) and / or x (bit 1): plain-bf16 products
+    if (prec != 1) return -7;
+    if (io == 3) hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 1, bf16_t, bf16_t>), grid, block, 0, st, a);
+    else if (io == 1) hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 1, bf16_t, float>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 1, float, bf16_t>), grid, block, 0, st, a);
+  } else if (prec == 1)
     hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 1>), grid, block, 0, st, a);
   else if (prec == 0)
     hipLaunchKernelGGL((conv_wgrad_kernel<BC, BD, 0>), grid, block, 0, st, a);   // exact fp32 (test mode)
@@ -627,10 +635,11 @@ extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int*
 extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int Ho,
                               int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read,
                               int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
-                              const void* zero_page, void* stream) {
+                              const void* zero_page, int io, void* stream) {
+  if (io & ~3) return -1;
   if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 0 && prec != 1 && prec != 3) || zero_page == nullptr) return -1;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15)) return -2;
-  if (prec == 0 && dma_width(co_write, ci_write, Wo, N * Ho * Wo) > 0) return -7;   // exact fp32: zs3_conv_wgrad_set_kernel(1) first
+  if ((prec == 0 || io) && dma_width(co_write, ci_write, Wo, N * Ho * Wo) > 0) return -7;   // exact fp32 / bf16 storage: zs3_conv_wgrad_set_kernel(1) first
   WgradArgs a;
   a.dy = dy; a.x = x; a.zero = (const float*)zero_page;
   a.N = N; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
@@ -659,7 +668,7 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
   }
   if (wd < ci_write) {   // remaining (or all) input channels: register-staged kernel, same slabs and pixel chunks
     WgradArgs r = a;
-    r.x = a.x + wd;
+    r.x = a.x + wd;      // (wd > 0 only with fp32 storage)
     r.dw = a.dw + wd;
     r.ci_write = ci_write - wd;
     r.ci_read = ci_read - wd;
@@ -676,10 +685,10 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
     }
     int bc = pick_tile_dim(r.co_write), bd = pick_tile_dim(r.ci_write);
     if (tile_override() == 64) { bc = 64; bd = 64; }
-    if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(r, taps_r, splitk, prec, st);
-    else if (bc == 128) rc = launch_wgrad<128, 64>(r, taps_r, splitk, prec, st);
-    else if (bd == 128) rc = launch_wgrad<64, 128>(r, taps_r, splitk, prec, st);
-    else rc = launch_wgrad<64, 64>(r, taps_r, splitk, prec, st);
+    if (bc == 128 && bd == 128) rc = launch_wgrad<128, 128>(r, taps_r, splitk, prec, io, st);
+    else if (bc == 128) rc = launch_wgrad<128, 64>(r, taps_r, splitk, prec, io, st);
+    else if (bd == 128) rc = launch_wgrad<64, 128>(r, taps_r, splitk, prec, io, st);
+    else rc = launch_wgrad<64, 64>(r, taps_r, splitk, prec, io, st);
   }
   if (rc) return rc;
   if (splitk > 1) {

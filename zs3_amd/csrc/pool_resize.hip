@@ -9,9 +9,12 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int ldx, float* out, int ldo,
+template <typename T = float>   // element type of x and out
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x_, int ldx, float* out_, int ldo,
                                                          unsigned char* idx, int N, int H, int W, int Ho, int Wo, int C,
                                                          int K, int stride, int pad) {
+  const T* const x = reinterpret_cast<const T*>(x_);
+  T* const out = reinterpret_cast<T*>(out_);
   const int c4n = C >> 2;
   const long total = (long)N * Ho * Wo * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -28,7 +31,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int ld
       for (int kw = 0; kw < K; ++kw) {
         const int w = ow * stride - pad + kw;
         if (w < 0 || w >= W) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long)n * H + h) * W + w) * ldx + cq);
+        f32x4 v = ld4<T>(x + (((long)n * H + h) * W + w) * ldx + cq);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (v[k] > best[k] || v[k] != v[k]) {  // first maximum wins, NaN propagates (ATen semantics)
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int ld
           }
       }
     }
-    *reinterpret_cast<f32x4*>(out + m * ldo + cq) = best;
+    st4<T>(out + m * ldo + cq, best);
     if (idx) {
       unsigned pk = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
       *reinterpret_cast<unsigned*>(idx + m * C + cq) = pk;
@@ -45,9 +48,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int ld
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, int ldd, const unsigned char* idx, float* dx,
+template <typename T = float>   // element type of dy and dx
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy_, int ldd, const unsigned char* idx, float* dx_,
                                                          int ldo, int N, int H, int W, int Ho, int Wo, int C, int K,
                                                          int stride, int pad) {
+  const T* const dy = reinterpret_cast<const T*>(dy_);
+  T* const dx = reinterpret_cast<T*>(dx_);
   const int c4n = C >> 2;
   const long total = (long)N * H * W * c4n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -69,14 +75,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* dy, int l
         if (ow >= Wo) continue;
         const long mo = ((long)n * Ho + oh) * Wo + ow;
         const unsigned pk = *reinterpret_cast<const unsigned*>(idx + mo * C + cq);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + mo * ldd + cq);
+        const f32x4 d = ld4<T>(dy + mo * ldd + cq);
         const unsigned tap = (unsigned)(kh * K + kw);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (((pk >> (8 * k)) & 0xFFu) == tap) g[k] += d[k];
       }
     }
-    *reinterpret_cast<f32x4*>(dx + m * ldo + cq) = g;
+    st4<T>(dx + m * ldo + cq, g);
   }
 }
 
@@ -100,7 +106,9 @@ struct ResizeArgs {
   float sh, sw;
 };
 
+template <typename T = float>   // element type of x and out
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const ResizeArgs p) {
+  T* const pout = reinterpret_cast<T*>(p.out);
   const int c4n = p.C >> 2;
   const bool vec = (p.C & 3) == 0 && (p.ldx & 3) == 0 && (p.ldo & 3) == 0;
   const int cn = vec ? c4n : p.C;
@@ -115,22 +123,22 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const ResizeArgs p) {
     float lh, lw;
     src_index(oh, p.sh, p.H, h0, h1, lh);
     src_index(ow, p.sw, p.W, w0, w1, lw);
-    const float* b = p.x + (long)n * p.H * p.W * p.ldx;
+    const T* b = reinterpret_cast<const T*>(p.x) + (long)n * p.H * p.W * p.ldx;
     const float w00 = (1.f - lh) * (1.f - lw), w01 = (1.f - lh) * lw, w10 = lh * (1.f - lw), w11 = lh * lw;
     if (vec) {
       const int c = ci * 4;
-      const f32x4 a00 = *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w0) * p.ldx + c);
-      const f32x4 a01 = *reinterpret_cast<const f32x4*>(b + ((long)h0 * p.W + w1) * p.ldx + c);
-      const f32x4 a10 = *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w0) * p.ldx + c);
-      const f32x4 a11 = *reinterpret_cast<const f32x4*>(b + ((long)h1 * p.W + w1) * p.ldx + c);
+      const f32x4 a00 = ld4<T>(b + ((long)h0 * p.W + w0) * p.ldx + c);
+      const f32x4 a01 = ld4<T>(b + ((long)h0 * p.W + w1) * p.ldx + c);
+      const f32x4 a10 = ld4<T>(b + ((long)h1 * p.W + w0) * p.ldx + c);
+      const f32x4 a11 = ld4<T>(b + ((long)h1 * p.W + w1) * p.ldx + c);
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = bilerp(w00, w01, w10, w11, a00[e], a01[e], a10[e], a11[e]);
-      *reinterpret_cast<f32x4*>(p.out + m * p.ldo + c) = v;
+      st4<T>(pout + m * p.ldo + c, v);
     } else {
-      p.out[m * p.ldo + ci] = bilerp(w00, w01, w10, w11, b[((long)h0 * p.W + w0) * p.ldx + ci],
-                                     b[((long)h0 * p.W + w1) * p.ldx + ci], b[((long)h1 * p.W + w0) * p.ldx + ci],
-                                     b[((long)h1 * p.W + w1) * p.ldx + ci]);
+      st1<T>(pout + m * p.ldo + ci, bilerp(w00, w01, w10, w11, ld1<T>(b + ((long)h0 * p.W + w0) * p.ldx + ci),
+                                           ld1<T>(b + ((long)h0 * p.W + w1) * p.ldx + ci), ld1<T>(b + ((long)h1 * p.W + w0) * p.ldx + ci),
+                                           ld1<T>(b + ((long)h1 * p.W + w1) * p.ldx + ci)));
     }
   }
 }
@@ -152,6 +160,7 @@ __device__ __forceinline__ void cand_range(int i, float scale, int out_n, int& l
 // column weights are computed once per input pixel (not once per candidate row), and rows / columns of zero weight are skipped
 // before any address is formed.  BWD_MAXCAND bounds the unrolled column window; larger ratios take the general loop.
 constexpr int BWD_MAXCAND = 12;
+template <typename T = float>   // element type of the incoming and the produced gradient
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const ResizeArgs p) {
   const bool vec = (p.C & 3) == 0 && (p.ldx & 3) == 0 && (p.ldo & 3) == 0;
   const int cn = vec ? (p.C >> 2) : p.C;
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const ResizeArgs p) {
     cand_range(h, p.sh, p.Ho, olo, ohi);
     cand_range(w, p.sw, p.Wo, wlo, whi);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* g = p.x + (long)n * p.Ho * p.Wo * p.ldx;
+    const T* g = reinterpret_cast<const T*>(p.x) + (long)n * p.Ho * p.Wo * p.ldx;
     if (whi - wlo < BWD_MAXCAND) {
       float wwv[BWD_MAXCAND];
 #pragma unroll
@@ -186,19 +195,19 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const ResizeArgs p) {
         // all candidates of the row in one burst of unbranched loads (window columns past `whi` re-read the last one; their
         // weight is zero and a select keeps them out of the sum): a load under `if (weight != 0)` is waited for before the
         // next one is issued
-        const float* row = g + ((long)oh * p.Wo + wlo) * p.ldx + (vec ? ci * 4 : ci);
+        const T* row = g + ((long)oh * p.Wo + wlo) * p.ldx + (vec ? ci * 4 : ci);
         const int jmax = whi - wlo;
         if (vec) {
           f32x4 v[BWD_MAXCAND];
 #pragma unroll
-          for (int j = 0; j < BWD_MAXCAND; ++j) v[j] = *reinterpret_cast<const f32x4*>(row + (long)(j < jmax ? j : jmax) * p.ldx);
+          for (int j = 0; j < BWD_MAXCAND; ++j) v[j] = ld4<T>(row + (long)(j < jmax ? j : jmax) * p.ldx);
 #pragma unroll
           for (int j = 0; j < BWD_MAXCAND; ++j)
             if (wwv[j] != 0.f) acc += (wh * wwv[j]) * v[j];
         } else {
           float v[BWD_MAXCAND];
 #pragma unroll
-          for (int j = 0; j < BWD_MAXCAND; ++j) v[j] = row[(long)(j < jmax ? j : jmax) * p.ldx];
+          for (int j = 0; j < BWD_MAXCAND; ++j) v[j] = ld1<T>(row + (long)(j < jmax ? j : jmax) * p.ldx);
 #pragma unroll
           for (int j = 0; j < BWD_MAXCAND; ++j)
             if (wwv[j] != 0.f) acc[0] += (wh * wwv[j]) * v[j];
@@ -218,21 +227,21 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const ResizeArgs p) {
           const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
           if (ww == 0.f) continue;
           const float wt = wh * ww;
-          const float* src = g + ((long)oh * p.Wo + ow) * p.ldx;
+          const T* src = g + ((long)oh * p.Wo + ow) * p.ldx;
           if (vec)
-            acc += wt * *reinterpret_cast<const f32x4*>(src + ci * 4);
+            acc += wt * ld4<T>(src + ci * 4);
           else
-            acc[0] += wt * src[ci];
+            acc[0] += wt * ld1<T>(src + ci);
         }
       }
     }
     if (vec) {
-      float* dst = p.out + m * p.ldo + ci * 4;
-      if (p.accumulate) acc += *reinterpret_cast<const f32x4*>(dst);
-      *reinterpret_cast<f32x4*>(dst) = acc;
+      T* dst = reinterpret_cast<T*>(p.out) + m * p.ldo + ci * 4;
+      if (p.accumulate) acc += ld4<T>(dst);
+      st4<T>(dst, acc);
     } else {
-      float* dst = p.out + m * p.ldo + ci;
-      *dst = (p.accumulate ? *dst : 0.f) + acc[0];
+      T* dst = reinterpret_cast<T*>(p.out) + m * p.ldo + ci;
+      st1<T>(dst, (p.accumulate ? ld1<T>(dst) : 0.f) + acc[0]);
     }
   }
 }
@@ -247,17 +256,25 @@ inline int ew_blocks(long total) {
 }  // namespace
 
 extern "C" int zs3_maxpool_fwd(const float* x, int ldx, float* out, int ldo, void* idx, int N, int H, int W, int Ho,
-                               int Wo, int C, int K, int stride, int pad, void* stream) {
-  if (C % 4 || ldx % 4 || ldo % 4 || K * K > 255) return -1;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                               int Wo, int C, int K, int stride, int pad, int io, void* stream) {
+  if (C % 4 || ldx % 4 || ldo % 4 || K * K > 255 || (io != 0 && io != 3)) return -1;
+  if (io)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       x, ldx, out, ldo, (unsigned char*)idx, N, H, W, Ho, Wo, C, K, stride, pad);
+  else
+  hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_blocks((long)N * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                      x, ldx, out, ldo, (unsigned char*)idx, N, H, W, Ho, Wo, C, K, stride, pad);
   return ZS3_LAUNCH_CHECK();
 }
 
 extern "C" int zs3_maxpool_bwd(const float* dy, int ldd, const void* idx, float* dx, int ldo, int N, int H, int W,
-                               int Ho, int Wo, int C, int K, int stride, int pad, void* stream) {
-  if (C % 4 || ldd % 4 || ldo % 4) return -1;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                               int Ho, int Wo, int C, int K, int stride, int pad, int io, void* stream) {
+  if (C % 4 || ldd % 4 || ldo % 4 || (io != 0 && io != 3)) return -1;
+  if (io)
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(ew_blocks((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       dy, ldd, (const unsigned char*)idx, dx, ldo, N, H, W, Ho, Wo, C, K, stride, pad);
+  else
+  hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_blocks((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                      dy, ldd, (const unsigned char*)idx, dx, ldo, N, H, W, Ho, Wo, C, K, stride, pad);
   return ZS3_LAUNCH_CHECK();
 }
@@ -320,19 +337,23 @@ static ResizeArgs make_resize(const float* x, int ldx, float* out, int ldo, int 
 
 /* x: [N,H,W,C] -> out: [N,Ho,Wo,C] */
 extern "C" int zs3_bilinear_fwd(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int Ho, int Wo,
-                                int C, void* stream) {
+                                int C, int io, void* stream) {
+  if (io != 0 && io != 3) return -1;
   ResizeArgs a = make_resize(x, ldx, out, ldo, N, H, W, Ho, Wo, C, 0);
   long total = (long)N * Ho * Wo * ((C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0) ? C / 4 : C);
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+  if (io) hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((bilinear_fwd_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }
 
 /* dout: [N,Ho,Wo,C] (grad of the resized map) -> dx: [N,H,W,C] */
 extern "C" int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int H, int W, int Ho, int Wo,
-                                int C, int accumulate, void* stream) {
+                                int C, int accumulate, int io, void* stream) {
+  if (io != 0 && io != 3) return -1;
   ResizeArgs a = make_resize(dout, ldd, dx, ldo, N, H, W, Ho, Wo, C, accumulate);
   long total = (long)N * H * W * ((C % 4 == 0 && ldd % 4 == 0 && ldo % 4 == 0) ? C / 4 : C);
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+  if (io) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((bilinear_bwd_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, a);
   return ZS3_LAUNCH_CHECK();
 }
 
