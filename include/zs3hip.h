@@ -1,7 +1,7 @@
 /* zs3hip.h -- C ABI of libzs3hip.so, the MI355X (gfx950) kernel library under the zs3_amd Python host.
  *
  * Conventions: plain pointers are DEVICE pointers unless said otherwise; tensors
- * are fp32, activations NHWC ("channels_last") with an explicit pixel stride in floats; every call
+ * are fp32, activations NHWC ("channels_last") with an explicit pixel stride in ELEMENTS; every call
  * is asynchronous on the HIP stream passed last (hipStream_t as void*); return value 0 = launched,
  * >0 = hipError_t, <0 = argument error.  No call allocates, frees or synchronises.
  *
@@ -10,6 +10,14 @@
  */
 #ifndef ZS3HIP_H
 #define ZS3HIP_H
+/* `io` (the argument before the stream of every call that reads or writes ACTIVATION tensors): their element type in HBM.
+ * Bit 0 (ZS3_IO_IN16) = the call's activation inputs are bf16, bit 1 (ZS3_IO_OUT16) = its activation outputs are; 0 = all
+ * fp32 (BASELINE configs[1-3]), 3 = all bf16 (the 2-byte mode of configs[4]).  The pointers stay declared `float*`; strides
+ * count elements; all arithmetic is fp32 in registers either way, and statistics / parameters / weight gradients are always
+ * fp32.  Convolutions: bit 0 = x, bit 1 = y together with res, the accumulate target and bn_y; bf16 x needs prec = 1.  Weight
+ * gradients: bit 0 = dy, bit 1 = x.  Element-wise calls accept 0 or 3; zs3_affine_act accepts all four (1 and 2 are the casts). */
+#define ZS3_IO_IN16 1
+#define ZS3_IO_OUT16 2
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -55,7 +63,7 @@ int zs3_conv_igemm(const float* x, const void* w_pk, float* y, const float* scal
                    const float* shift, const float* res, float* stat_partial, int N, int H, int W, int Ho, int Wo,
                    int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride, int pad_h, int pad_w, int dil,
                    int ncols, int ldy, int ldr, int act, float leak, int accumulate, int dgrad, int prec,
-                   int tile_cfg, const void* zero_page, void* stream);
+                   int tile_cfg, const void* zero_page, int io, void* stream);
 int zs3_conv_igemm_mtiles(int M, int ncols, int tile_cfg);
 /* zs3_conv_igemm whose input is read through x' = max(x * in_scale[c] + in_shift[c], 0) by the producer waves of the strip-resident and
  * persistent pointwise kernels (tile_cfg 41 / 42 / 51 / 52; -7 for any other kernel): BatchNorm-apply + ReLU of the layer that produced
@@ -65,7 +73,7 @@ int zs3_conv_igemm_in(const float* x, const void* w_pk, float* y, const float* s
                       float* stat_partial, int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW,
                       int stride, int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int act, float leak, int accumulate,
                       int dgrad, int prec, int tile_cfg, const void* zero_page, const float* in_scale, const float* in_shift,
-                      void* stream);
+                      int io, void* stream);
 /* tile_cfg 31: wave-specialised 256x128 LDS-DMA kernel, one tile per workgroup. */
 /* tile_cfg 41 / 42 (csrc/conv_halo.hip): strip-resident kernel for stride-1, same-size multi-tap (3x3, dilated 3x3)
  * convolutions and their data gradients, 256- / 192-row tiles.  The input strip of a tile (tile rows + the halo the taps
@@ -102,7 +110,7 @@ int zs3_conv_igemm_bnstats(const float* x, const void* w_pk, float* y, const flo
                            int stride, int pad_h, int pad_w, int dil, int ncols, int ldy, int ldr, int accumulate, int dgrad,
                            int prec, int tile_cfg, const void* zero_page, const float* bn_y, int bn_ldy,
                            const float* bn_mean, const float* bn_invstd, const float* mask_scale, const float* mask_shift,
-                           const unsigned char* mask_bits, float* bn_partial, void* stream);
+                           const unsigned char* mask_bits, float* bn_partial, int io, void* stream);
 
 /* ---- weight gradient ------------------------------------------------------------------------- */
 /* Strip-resident weight gradient (csrc/conv_wgrad_strip.hip) of the stride-1, same-size 3x3 convolutions (pad = dilation):
@@ -138,7 +146,7 @@ int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, float* workspa
 int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats);
 int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int Ho, int Wo,
                    int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co_read, int co_write, int ci_read,
-                   int ci_write, int lddy, int ldx, int prec, const void* zero_page, void* stream);
+                   int ci_write, int lddy, int ldx, int prec, const void* zero_page, int io, void* stream);
 /* Kernel choice of zs3_conv_wgrad / zs3_conv_wgrad_plan: 0 = the library's rules, 1 = the register-staged kernel for every layer
  * (required before prec = 0, which exists on that kernel only: -7 otherwise), 2 = the LDS-DMA kernel wherever the channel counts
  * allow.  Returns the previous setting; plans made under another setting are stale. */
@@ -148,14 +156,14 @@ int zs3_conv_wgrad_set_kernel(int kernel);
 /* Replaces native_batch_norm fwd/bwd, relu_, threshold_backward, residual add_ at resnet.py:33-53,
  * aspp.py:25-29,111-116, decoder.py:30-32,15-24.  Partial-sum buffers are [chunks][2][C] floats. */
 int zs3_colstats_plan(int M, int C, int* chunks, int* rows_per_block);
-int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, void* stream);
+int zs3_colstats(const float* x, int ldx, int M, int C, float* partial, int io, void* stream);
 /* ReLU mask, first that is given: mask_bits (one byte per 4 channels, dense [M][C/4], written by zs3_affine_act),
    a_out (> 0), or recomputed as y*mask_scale + mask_shift > 0 (layers without residual).
    drop_p > 0: dA is the gradient of a dropout fused behind the activation (zs3_affine_act): its mask is applied first. */
 int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
                      const float* invstd, const float* mask_scale, const float* mask_shift,
                      const unsigned char* mask_bits, int M, int C, float* partial, float drop_p,
-                     unsigned long long drop_seed, void* stream);
+                     unsigned long long drop_seed, int io, void* stream);
 /* num_batches_tracked (nullable): BatchNorm's int64 step counter, incremented by the kernel.
    count_dev (nullable): device-resident sample count that overrides `count` (cross-rank SyncBN: the count is
    all-reduced together with the sums and never visits the host) */
@@ -180,28 +188,28 @@ int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, double count, c
    the mask zs3_dropout draws for (drop_seed, element m*C + c) -- saves a read + write of the activation per dropout. */
 int zs3_affine_act(const float* x, int ldx, const float* scale, const float* shift, float alpha, const float* res,
                    int ldr, float* out, int ldo, long M, int C, int div, int act, float leak, int accumulate,
-                   unsigned char* mask_out, float drop_p, unsigned long long drop_seed, void* stream);
+                   unsigned char* mask_out, float drop_p, unsigned long long drop_seed, int io, void* stream);
 /* dz = act'(a_out)*dA; dres (=|+=) dz; dy = gamma*invstd*(dz - c1 - xhat*c2)  (c1==NULL: dy = gamma*invstd*dz);
    drop_p > 0: dA is first passed through the backward of the fused dropout (same mask, recomputed) */
 int zs3_bn_act_bwd(const float* dA, int ldd, const float* a_out, int lda, const float* y, int ldy, const float* mean,
                    const float* invstd, const float* gamma, const float* c1, const float* c2, const float* mask_scale,
                    const float* mask_shift, const unsigned char* mask_bits, float* dy, int ldo, float* dres, int ldr,
                    int dres_accumulate, long M, int C, int act, float leak, float drop_p, unsigned long long drop_seed,
-                   void* stream);
+                   int io, void* stream);
 /* out[g][c] = scale * sum_{r<R} x[g*R + r][c]: AdaptiveAvgPool2d((1,1)) of aspp.py:85 and its broadcast backward */
-int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo, void* stream);
+int zs3_group_colsum(const float* x, int ldx, int G, int R, int C, float scale, float* out, int ldo, int io, void* stream);
 
 /* ---- pooling / resize (pool_resize.hip) ------------------------------------------------------- */
 /* nn.MaxPool2d(3,2,1) of resnet.py:82 (idx: one byte per output element, the winning tap) */
 int zs3_maxpool_fwd(const float* x, int ldx, float* out, int ldo, void* idx, int N, int H, int W, int Ho, int Wo, int C,
-                    int K, int stride, int pad, void* stream);
+                    int K, int stride, int pad, int io, void* stream);
 int zs3_maxpool_bwd(const float* dy, int ldd, const void* idx, float* dx, int ldo, int N, int H, int W, int Ho, int Wo,
-                    int C, int K, int stride, int pad, void* stream);
+                    int C, int K, int stride, int pad, int io, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=True) of aspp.py:109, decoder.py:34-36, deeplab.py:44,55 */
 int zs3_bilinear_fwd(const float* x, int ldx, float* out, int ldo, int N, int H, int W, int Ho, int Wo, int C,
-                     void* stream);
+                     int io, void* stream);
 int zs3_bilinear_bwd(const float* dout, int ldd, float* dx, int ldo, int N, int H, int W, int Ho, int Wo, int C,
-                     int accumulate, void* stream);
+                     int accumulate, int io, void* stream);
 
 /* Validation without shipping logits to the host (train_pascal.py:130-134, Evaluator._generate_matrix metrics.py:73-79):
  * conf[gt*C + pred] += 1 for every target pixel with 0 <= gt < C, pred = first argmax over the C channels of x
@@ -284,7 +292,7 @@ int zs3_gmmn_mlp_wgrad_adam(const float* dy2, int ldy2, const float* x2, int ldx
  * int64[M]): row m of x is row row_idx[m] of the tensor the mask was drawn for (sampled-row backward). */
 /* seed_dev (optional): device uint64 added to `seed`, so a launch captured in a hipGraph draws a fresh mask per replay */
 int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
-                const long* row_idx, const void* seed_dev, void* stream);
+                const long* row_idx, const void* seed_dev, int io, void* stream);
 int zs3_uniform(float* out, long n, unsigned long long seed, const void* seed_dev, void* stream);
 /* counter[0] += v (device int64 / uint64): advances the stream position / step count between graph replays */
 int zs3_counter_add(void* counter, long v, void* stream);
@@ -300,7 +308,7 @@ int zs3_dropout_act_bwd(const float* dy, int ldd, const float* h, int ldh, float
 /* out = srcs[0] + ... + srcs[n-1] in that order, 2 <= n <= 8 dense fp32 arrays of `count` elements: the gradient of a tensor
  * with several consumers (aspp.py:104-108: x feeds five branches; deeplab.py:41-42: layer1's output feeds layer2 and the
  * decoder) in one pass -- autograd would add pairwise.  srcs: HOST array of device pointers; out may alias srcs[0]. */
-int zs3_sum_n(const void* const* srcs, int n, float* out, long count, void* stream);
+int zs3_sum_n(const void* const* srcs, int n, float* out, long count, int io, void* stream);
 /* out[c] = sum_m x[m][c] (rows in order): bias gradients of the generator's Linear layers */
 int zs3_colsum(const float* x, int ldx, int M, int C, float* out, void* stream);
 /* torch.optim.Adam for several tensors in one launch, device-resident step count; table[e] = {p, g, exp_avg, exp_avg_sq,

@@ -238,7 +238,7 @@ def test_binding_declares_every_signature_from_the_header(libpath):
         fn = getattr(handle, name)
         assert fn.argtypes is not None, name
     assert handle.zs3_ce_ws_doubles.argtypes == []
-    assert len(handle.zs3_affine_act.argtypes) == 19          # x .. mask_out, drop_p, drop_seed, stream
+    assert len(handle.zs3_affine_act.argtypes) == 20          # x .. mask_out, drop_p, drop_seed, io, stream
     with pytest.raises((ctypes.ArgumentError, TypeError)):
         handle.zs3_colstats_plan(1000, 64)                      # two of four arguments
     with pytest.raises((ctypes.ArgumentError, TypeError)):

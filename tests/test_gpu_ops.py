@@ -842,7 +842,7 @@ def test_conv_pointwise_persistent_kernel(dev, prec, wgs):
     out = torch.zeros(1, 16, 16, 128, device=dev)
     rc = lib().zs3_conv_igemm(P(x), P(wp.f_pk), P(out), None, None, P(out), None, I(1), I(16), I(16), I(16), I(16), I(64), I(64),
                               I(64), I(1), I(1), I(1), I(0), I(0), I(1), I(128), I(128), I(128), I(0), Fl(0.2), I(0), I(0), I(3),
-                              I(51), P(ops.zero_page(dev)), stream())
+                              I(51), P(ops.zero_page(dev)), I(0), stream())
     assert rc == -7
 
 

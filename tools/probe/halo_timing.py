@@ -14,7 +14,7 @@ for cfg in (41, 42):
         dbg = torch.zeros(4096, dtype=torch.int64, device=dev)
         y0 = torch.empty(16, h, h, co, device=dev)
         for rep in range(2):
-            check(lib().zs3_conv_igemm(P(x), P(wp.f_pk), P(y0), None, None, P(dbg), None, I(16), I(h), I(h), I(h), I(h), I(wp.cin_pad), I(ci), I(ci), I(3), I(3), I(1), I(d), I(d), I(d), I(co), I(co), I(0), I(99), F(0.2), I(0), I(0), I(3), I(cfg), P(ops.zero_page(dev)), stream()), "dbg")
+            check(lib().zs3_conv_igemm(P(x), P(wp.f_pk), P(y0), None, None, P(dbg), None, I(16), I(h), I(h), I(h), I(h), I(wp.cin_pad), I(ci), I(ci), I(3), I(3), I(1), I(d), I(d), I(d), I(co), I(co), I(0), I(99), F(0.2), I(0), I(0), I(3), I(cfg), P(ops.zero_page(dev)), I(0), stream()), "dbg")
         torch.cuda.synchronize()
         t = dbg.cpu()[:24].view(8, 3).double()
         ns = 9 * ((ci + 15) // 16)

@@ -12,7 +12,7 @@ for (h, ci, co, k) in ((129, 256, 256, 3), (33, 1024, 256, 1), (33, 256, 256, 3)
     y0, _ = ops.conv2d_fwd(x, wp, 1, k // 2, 1, tile_cfg=cfg)
     n, hh, ww, _ = x.shape
     for rep in range(2):
-        check(lib().zs3_conv_igemm(P(x), P(wp.f_pk), P(y0), None, None, P(dbg), None, I(n), I(hh), I(ww), I(hh), I(ww), I(wp.cin_pad), I(ci), I(ci), I(k), I(k), I(1), I(k // 2), I(k // 2), I(1), I(co), I(co), I(0), I(99), F(0.2), I(0), I(0), I(3), I(cfg), P(ops.zero_page(dev)), stream()), "dbg")
+        check(lib().zs3_conv_igemm(P(x), P(wp.f_pk), P(y0), None, None, P(dbg), None, I(n), I(hh), I(ww), I(hh), I(ww), I(wp.cin_pad), I(ci), I(ci), I(k), I(k), I(1), I(k // 2), I(k // 2), I(1), I(co), I(co), I(0), I(99), F(0.2), I(0), I(0), I(3), I(cfg), P(ops.zero_page(dev)), I(0), stream()), "dbg")
     torch.cuda.synchronize()
     t = dbg.cpu().view(-1, 3)[:8].double()
     KT = k * k * ci // 32

@@ -31,23 +31,24 @@ __global__ void dropout_kernel(const float* x, int ldx, float* y, int ldy, long 
 // float4 form of the above for C % 4 == 0 and 16-byte aligned rows (every dropout of the network: 256 channels): one row
 // division per four elements and 16-byte accesses; the mask of element (m, c) is the same u01(seed, m*C + c).  (The scalar
 // kernel moved the decoder's 272 MB activations at 2.4 TB/s.)
-__global__ __launch_bounds__(256) void dropout4_kernel(const float* x, int ldx, float* y, int ldy, long M, int C, float p,
+template <typename T = float>   // element type of x and y
+__global__ __launch_bounds__(256) void dropout4_kernel(const float* x_, int ldx, float* y_, int ldy, long M, int C, float p,
                                                        float inv_keep, unsigned long long seed, const long* row_idx,
                                                        const unsigned long long* seed_dev) {
+  const T* const x = reinterpret_cast<const T*>(x_);
+  T* const y = reinterpret_cast<T*>(y_);
   if (seed_dev) seed += seed_dev[0];
   const int c4 = C >> 2;
   const long total = M * c4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / c4;
     const int c = (int)(i - m * c4) << 2;
-    const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + c);
+    const f32x4 v = ld4<T>(x + m * ldx + c);
     const unsigned long long e = (unsigned long long)((row_idx ? row_idx[m] : m) * C + c);
-    float4 o;
-    o.x = u01(seed, e) >= p ? v.x * inv_keep : 0.f;
-    o.y = u01(seed, e + 1) >= p ? v.y * inv_keep : 0.f;
-    o.z = u01(seed, e + 2) >= p ? v.z * inv_keep : 0.f;
-    o.w = u01(seed, e + 3) >= p ? v.w * inv_keep : 0.f;
-    *reinterpret_cast<float4*>(y + m * ldy + c) = o;
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = u01(seed, e + k) >= p ? v[k] * inv_keep : 0.f;
+    st4<T>(y + m * ldy + c, o);
   }
 }
 
@@ -383,10 +384,15 @@ __global__ __launch_bounds__(1024) void label_order_kernel(const TT* target, int
 }  // namespace
 
 extern "C" int zs3_dropout(const float* x, int ldx, float* y, int ldy, long M, int C, float p, unsigned long long seed,
-                           const long* row_idx, const void* seed_dev, void* stream) {
+                           const long* row_idx, const void* seed_dev, int io, void* stream) {
   if (M <= 0) return 0;
-  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
-    hipLaunchKernelGGL(dropout4_kernel, dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C,
+  if (io != 0 && io != 3) return -1;
+  if (io) {   // bf16 storage: the vector form only (every dropout of the network has 256 channels)
+    if (C % 4 || ldx % 4 || ldy % 4 || (((uintptr_t)x | (uintptr_t)y) & 7)) return -1;
+    hipLaunchKernelGGL((dropout4_kernel<bf16_t>), dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M,
+                       C, p, 1.f / (1.f - p), seed, row_idx, (const unsigned long long*)seed_dev);
+  } else if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL((dropout4_kernel<float>), dim3(ew_blocks(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C,
                        p, 1.f / (1.f - p), seed, row_idx, (const unsigned long long*)seed_dev);
   else
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(M * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, C, p,

@@ -276,8 +276,9 @@ class _ConvBnAct(torch.autograd.Function):
             # ReLU here as the stored pass the producer skipped, and carry on as if nothing had been deferred
             x = ops.affine_act(x, in_aff[0], in_aff[1], act=ACT_RELU)
             in_aff = None
-        conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, in_affine=in_aff, **k)) if geom is None else (
-            lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, **geom, **k))
+        odt = cfg.get("out_dtype")   # element type of this layer's output (None: ops.ACT_DTYPE; the class scores stay fp32)
+        conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, in_affine=in_aff, out_dtype=odt, **k)) if geom is None else (
+            lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, out_dtype=odt, **geom, **k))
         defer = bool(cfg.get("defer_out"))
         if bn is not None and bn["training"]:
             y, part = conv(want_stats=True)
@@ -351,7 +352,7 @@ class _ConvBnAct(torch.autograd.Function):
         dgamma = dbeta = dbias = dres = None
         lazy = ctx.lazy_dres and ctx.has_bn and ctx.needs_input_grad[5] and ops._rows(dA)[2] == dA.shape[-1]
         if ctx.has_res and ctx.needs_input_grad[5] and not lazy:
-            dres = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+            dres = torch.empty(dA.shape, dtype=dA.dtype, device=dA.device)
         m = dA.shape[0] * dA.shape[1] * dA.shape[2] if dA.dim() == 4 else dA.shape[0]
         if ctx.has_bn:
             link = cfg.get("out_link")
@@ -385,7 +386,7 @@ class _ConvBnAct(torch.autograd.Function):
             vec_ok = cout % 4 == 0 and ops._rows(dA)[2] % 4 == 0
             if act != ACT_NONE:
                 if vec_ok:
-                    dz = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+                    dz = torch.empty(dA.shape, dtype=dA.dtype, device=dA.device)
                     ops.bn_act_bwd(dA, a, None, None, None, None, None, None, dres=dz, act=act, leak=leak, want_dy=False)
                 else:
                     dz = dA * _act_grad(a, act, leak)
@@ -413,7 +414,7 @@ class _ConvBnAct(torch.autograd.Function):
                         and dskip.shape[-1] == wp.cin)
                 if lazy_bits is not None and not (fuse and wp.cin % 4 == 0):
                     # cannot mask inside the epilogue: materialise the masked skip gradient first
-                    dz = torch.empty(dskip.shape, dtype=torch.float32, device=dskip.device)
+                    dz = torch.empty(dskip.shape, dtype=dskip.dtype, device=dskip.device)
                     ops.bn_act_bwd(dskip, None, None, None, None, None, None, None, dres=dz, act=ACT_RELU, want_dy=False,
                                    mask_bits=lazy_bits)
                     dskip, lazy_bits = dz, None
@@ -429,21 +430,22 @@ class _ConvBnAct(torch.autograd.Function):
                         wp.cin == ctx.x_shape[-1] and wp.cin % 4 == 0:
                     dx, part_in = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec,
                                                    bn_bwd=(in_link.y, in_link.mean, in_link.istd, in_link.msc,
-                                                           in_link.msh, in_link.mbits), **skip_kw)
+                                                           in_link.msh, in_link.mbits), out_dtype=x.dtype, **skip_kw)
                     in_link.partial, in_link.for_ptr = part_in, dx.data_ptr()
                 else:
-                    dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec, **skip_kw)
+                    dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec, out_dtype=x.dtype,
+                                          **skip_kw)
                 if dskip is not None and not fuse:
                     dx = dx + dskip
                 if dx.shape[-1] != ctx.x_shape[-1]:  # x carried pad channels
-                    full = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dx.device)
+                    full = torch.zeros(ctx.x_shape, dtype=dx.dtype, device=dx.device)
                     full[..., : dx.shape[-1]].copy_(dx)
                     dx = full
             else:
                 raise RuntimeError("the stem convolution has no data gradient (its input is the image)")
         elif dskip is not None and ctx.needs_input_grad[0]:
             if lazy_bits is not None:
-                dz = torch.empty(dskip.shape, dtype=torch.float32, device=dskip.device)
+                dz = torch.empty(dskip.shape, dtype=dskip.dtype, device=dskip.device)
                 ops.bn_act_bwd(dskip, None, None, None, None, None, None, None, dres=dz, act=ACT_RELU, want_dy=False,
                                mask_bits=lazy_bits)
                 dskip = dz
@@ -494,7 +496,7 @@ def _applies_in_affine(x, wp, stride, pad, dil, prec, bn, residual, need_grad):
     loading epilogue, which the persistent pointwise kernel leaves to the register-staged ones."""
     n, h, w_, _ = x.shape
     ldx = ops._rows(x)[2]
-    if wp.cin % 4 or ldx % 4:
+    if wp.cin % 4 or ldx % 4 or x.dtype != torch.float32:
         return False
     prec = ops.PREC_DEFAULT if (prec is None or ops.PREC_DEFAULT == 0) else prec
     store_only = residual is None or (bn is not None and (bn["training"] or need_grad))
@@ -554,7 +556,7 @@ def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
 
 def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
                 leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False, dropout=None,
-                next_conv=None):
+                next_conv=None, out_dtype=None):
     """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None.
     input_has_one_consumer: promise that `x` feeds nothing but this layer (and, with pass_through, the skip tensor this
     layer hands back), which lets this layer's dgrad produce the BN-backward sums of the layer that made `x` (BnLink).
@@ -575,6 +577,7 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
         else:
             drop_after = (float(dropout[0]), None)
     cfg = {"stride": stride, "pad": pad, "dil": dil, "act": act, "out": out, "leak": leak, "prec": prec, "geom": geom,
+           "out_dtype": out_dtype,
            "drop": drop,
            "wgrad": wgrad, "pass_through": pass_through,
            "in_link": getattr(x, "_zs3_bn_link", None) if (input_has_one_consumer and FUSE_BN_BWD_STATS) else None,
@@ -693,7 +696,7 @@ class _Relu(torch.autograd.Function):
     def backward(ctx, dA):
         (a,) = ctx.saved_tensors
         dA = _dense_rows(dA)
-        out = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+        out = torch.empty(dA.shape, dtype=dA.dtype, device=dA.device)
         ops.bn_act_bwd(dA, a, None, None, None, None, None, None, dy=None, dres=out, act=ACT_RELU, want_dy=False)
         return out
 
@@ -741,7 +744,7 @@ class _Bilinear(torch.autograd.Function):
         out = None
         if ctx.grad_pad and c % ctx.grad_pad:
             cp = (c + ctx.grad_pad - 1) // ctx.grad_pad * ctx.grad_pad
-            out = torch.zeros((n, h, w, cp), dtype=torch.float32, device=dout.device)[..., :c]
+            out = torch.zeros((n, h, w, cp), dtype=dout.dtype, device=dout.device)[..., :c]
         return ops.bilinear_bwd(dout, (h, w), out=out), None, None, None
 
 
@@ -808,7 +811,8 @@ class _Fork(torch.autograd.Function):
         if len(gs) == 1:
             return gs[0], None
         dense = [_dense_rows(g) for g in gs]
-        same = all(g.shape == dense[0].shape and g.stride() == dense[0].stride() and g.dtype == torch.float32 and g.is_cuda
+        same = all(g.shape == dense[0].shape and g.stride() == dense[0].stride() and g.dtype == dense[0].dtype and g.is_cuda
+                   and g.dtype in (torch.float32, torch.bfloat16)
                    and g.data_ptr() % 16 == 0 for g in dense)   # zs3_sum_n reads float4: an offset view takes the plain adds
         n = dense[0].numel()
         if not same or len(dense) > 8 or n % 4 or ops._rows(dense[0])[2] != dense[0].shape[-1]:
@@ -818,7 +822,8 @@ class _Fork(torch.autograd.Function):
             return out, None
         out = torch.empty_like(dense[0])
         ptrs = (ctypes.c_void_p * len(dense))(*[g.data_ptr() for g in dense])
-        ops.check(ops.lib().zs3_sum_n(ptrs, ops.I(len(dense)), ops.P(out), ctypes.c_long(n), ops.stream()), "zs3_sum_n")
+        ops.check(ops.lib().zs3_sum_n(ptrs, ops.I(len(dense)), ops.P(out), ctypes.c_long(n),
+                                      ops.I(3 if out.dtype == torch.bfloat16 else 0), ops.stream()), "zs3_sum_n")
         return out, None
 
 

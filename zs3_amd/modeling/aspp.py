@@ -73,7 +73,7 @@ class ASPP(nn.Module):
 
     def forward_nhwc(self, x):
         n, h, w, _ = x.shape
-        cat = torch.empty((n, h, w, 1280), dtype=torch.float32, device=x.device)
+        cat = torch.empty((n, h, w, 1280), dtype=ops.ACT_DTYPE, device=x.device)
         bn = self.global_avg_pool[2] if isinstance(self.global_avg_pool[2], nn.BatchNorm2d) else None
 
         xs = Fz.fork(x, 5)    # five consumers: their gradients are added in one launch, not pairwise

@@ -25,7 +25,7 @@ class Decoder(nn.Module):
     # ---- NHWC internals
     def _merge(self, x, low):
         n, h, w, _ = low.shape
-        cat = torch.empty((n, h, w, 304), dtype=torch.float32, device=x.device)
+        cat = torch.empty((n, h, w, 304), dtype=ops.ACT_DTYPE, device=x.device)
         up = Fz.bilinear(x, (h, w), out=cat[..., :256])
         lo = self.conv1.forward_nhwc(low, self.bn1, act=Fz.ACT_RELU, out=cat[..., 256:304])
         return Fz.cat_slices(cat, [up, lo])
@@ -42,7 +42,8 @@ class Decoder(nn.Module):
         return self._head(self._merge(x, low))
 
     def predict_nhwc(self, feat):
-        return self.pred_conv.forward_nhwc(feat)
+        # the class scores stay fp32 whatever the activation storage: they feed the resize to image size and the loss
+        return self.pred_conv.forward_nhwc(feat, out_dtype=torch.float32)
 
     # ---- reference interface (logical NCHW)
     def forward(self, x, low_level_feat):

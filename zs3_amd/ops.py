@@ -25,6 +25,40 @@ WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"         # producer-split w
 HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
 
 
+ACT_DTYPE = torch.float32   # element type of activation tensors in HBM: torch.float32, or torch.bfloat16 = the 2-byte mode (set_storage)
+BF16 = torch.bfloat16
+
+
+def _io(inp, out=None):
+    """the `io` argument of the C ABI from the element types of a call's activation input / output tensors"""
+    return (1 if inp is not None and inp.dtype == BF16 else 0) | (2 if out is not None and out.dtype == BF16 else 0)
+
+
+def _same_type(ref, *others):
+    for t in others:
+        if t is not None and t.dtype != ref.dtype:
+            raise TypeError(f"activation tensors of one call must share an element type: {t.dtype} next to {ref.dtype}")
+
+
+def set_storage(dtype):
+    """Element type of the activation tensors the fused layers allocate: torch.float32 (BASELINE configs[1-3]) or torch.bfloat16
+    -- the 2-byte mode of configs[4]: conv outputs, BatchNorm-applied activations and every gradient between layers are
+    bf16 in HBM (half the bytes of every HBM-bound pass and of every conv operand), products are plain bf16 (prec = 1),
+    accumulation / statistics / parameters / weight gradients stay fp32.  Image input and class scores stay fp32."""
+    global ACT_DTYPE, PREC_DEFAULT
+    from . import functional as Fz
+    if dtype not in (torch.float32, BF16):
+        raise ValueError("activation storage is torch.float32 or torch.bfloat16")
+    ACT_DTYPE = dtype
+    if dtype == BF16:
+        PREC_DEFAULT = 1
+    lib().zs3_conv_wgrad_set_kernel(I(1 if dtype == BF16 else 0))   # the LDS-DMA weight-gradient kernel moves raw fp32 rows
+    _TILE_CHOICE.clear()
+    _WGRAD_PLAN.clear()
+    Fz._defer_choice.clear()
+    Fz._in_affine_choice.clear()
+
+
 def set_exact_fp32(on=True):
     """Test mode: every convolution / linear product on v_mfma_f32_32x32x2_f32 (prec = 0 of the register-staged kernels, ~1/16 of
     the bf16 rate) -- the arithmetic of the reference's own fp32 convolutions, summation order aside.  It answers one question:
@@ -153,6 +187,13 @@ def nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
+def cast(x, dtype):
+    """fp32 <-> bf16 copy of an activation tensor (zs3_affine_act as a cast); x itself when it already has the type"""
+    if x.dtype == dtype:
+        return x
+    return affine_act(x, out_dtype=dtype)
+
+
 def _check_nhwc(t):
     assert t.dim() == 4 and (t.stride(3) == 1 or t.shape[3] == 1), "expected an NHWC tensor with contiguous channels"
     ld = t.stride(2) if t.shape[2] > 1 else (t.stride(1) if t.shape[1] > 1 else (t.stride(0) if t.shape[0] > 1 else t.shape[3]))
@@ -202,8 +243,11 @@ _TILE_CHOICE, _MTILES = {}, {}
 
 
 def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec,
-                 pw_epilogue):
+                 pw_epilogue, io=0):
     """tile_cfg of a conv launch: the caller's explicit choice where that kernel can run the launch, else the rules."""
+    if io:
+        return _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad,
+                              prec, pw_epilogue, io)
     if prec == 0:   # exact fp32 (test mode): register-staged kernel only
         return tile_cfg if 0 < tile_cfg <= 14 else (14 if ncols <= 64 or ((m + 127) // 128) * ((ncols + 127) // 128) < 1000 else 11)
     if tile_cfg in (51, 52) and not (pw_epilogue and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
@@ -228,9 +272,47 @@ def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, s
     return tile_cfg
 
 
+PW16 = os.environ.get("ZS3_PW16", "1") == "1"        # persistent pointwise kernel on bf16-stored tensors
+HALO16 = os.environ.get("ZS3_HALO16", "1") == "1"    # strip-resident kernel on bf16-stored tensors
+PW16_LOAD_EPI = os.environ.get("ZS3_PW16_EPI", "1") == "1"   # ... including the data-gradient launches whose epilogue loads per element
+
+
+def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec,
+                   pw_epilogue, io):
+    """Kernel choice when x (io bit 0) and / or y (bit 1) are bf16 in memory.  The LDS-DMA kernel (31) moves raw fp32 rows and is
+    out; the strip-resident kernel reads bf16 strips (16 bytes = 8 channels per lane), the persistent pointwise kernel bf16 rows,
+    and the register-staged kernel takes everything else."""
+    x16 = bool(io & 1)
+    vec8 = ldx % 8 == 0 and cin_valid % 8 == 0
+    if tile_cfg in (41, 42) and not (kh * kw == 9 and (not x16 or (vec8 and prec == 1)) and halo_ok(
+            xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg)):
+        tile_cfg = 0
+    if tile_cfg in (51, 52) and not (PW16_CAPABLE and (pw_epilogue or PW16_LOAD_EPI) and (not x16 or vec8) and ncols % 2 == 0 and pw_ok(
+            xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, tile_cfg)):
+        tile_cfg = 0
+    if tile_cfg == 31:
+        tile_cfg = 0
+    if tile_cfg:
+        return tile_cfg
+    if HALO16 and kh * kw == 9 and m >= 8192 and ncols >= 128 and (not x16 or vec8) and (prec == 1 or not x16):
+        cand = pick_halo_tile(m, ncols, dgrad)
+        for c in (cand, 42 if cand == 41 else 41):
+            if halo_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, c):
+                return c
+    if PW16 and PW16_CAPABLE and kh * kw == 1 and (pw_epilogue or PW16_LOAD_EPI) and m >= 8192 and ncols >= 128 and ncols % 2 == 0 and \
+            (not x16 or vec8) and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, 52):
+        return 52
+    if ncols <= 64:
+        return 14
+    return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 512 else 14
+
+
+PW16_CAPABLE = False   # set once conv_pw.hip serves bf16-stored tensors (this build: see zs3_conv_pw_caps)
+
+
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
                scale=None, shift=None, res=None, want_stats=False, act=0, leak=0.2, accumulate=False, dgrad=False,
-               prec=None, tile_cfg=0, bn_bwd=None, res_mask_bits=None, in_affine=None):
+               prec=None, tile_cfg=0, bn_bwd=None, res_mask_bits=None, in_affine=None, out_dtype=None):
     """Raw launcher.  x: NHWC [N,H,W,*]; returns (y [N,ho,wo,ncols] or `out`, stat_partial or None).
     bn_bwd = (y, mean, invstd, mask_scale, mask_shift, mask_bits): also return the BatchNorm-backward partial sums
     (sum dz, sum dz*xhat per row tile) of the layer the output gradient belongs to (zs3_conv_igemm_bnstats).
@@ -242,26 +324,27 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     n, h, w_, _ = x.shape
     ldx = _check_nhwc(x)
     if out is None:
-        out = torch.empty((n, ho, wo, ncols), dtype=torch.float32, device=x.device)
+        out = torch.empty((n, ho, wo, ncols), dtype=out_dtype or ACT_DTYPE, device=x.device)
     ldy = _check_nhwc(out)
     ldr = _check_nhwc(res) if res is not None else 0
+    io = _io(x, out)
+    _same_type(out, res, bn_bwd[0] if bn_bwd is not None else None)
+    if io & 1 and prec != 1:
+        raise ValueError("a bf16-stored input needs plain-bf16 products (prec = 1)")
     m = n * ho * wo
     pw_epilogue = res is None and not accumulate and bn_bwd is None and res_mask_bits is None   # no per-element loads
     # the kernel / tile choice depends on the launch geometry only: decided once per distinct launch (a training step repeats
     # ~60 geometries 230 times; the eligibility questions below are C calls)
+    if tile_cfg in (141, 142):      # round-3 spelling of "tile_cfg 41 / 42 on a bf16-stored input"
+        tile_cfg -= 100
     key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
-           HALO, HALO_BM, PW, PW_FORCE)
+           HALO, HALO_BM, PW, PW_FORCE, io, PW16, HALO16, PW16_LOAD_EPI, PW16_CAPABLE)
     cached = _TILE_CHOICE.get(key)
-    if tile_cfg in (141, 142) or x.dtype == torch.bfloat16:
-        # bf16-STORED input (round-3 kernel-level experiment, csrc/conv_halo.hip A16): strip-resident kernel, plain bf16 only
-        if tile_cfg not in (141, 142) or x.dtype != torch.bfloat16 or prec != 1 or not halo_ok(
-                x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg - 100):
-            raise ValueError("a bf16-stored input needs tile_cfg 141 / 142, prec = 1 and a layer the strip-resident kernel serves")
-    elif cached is not None:
+    if cached is not None:
         tile_cfg = cached
     else:
         tile_cfg = _TILE_CHOICE[key] = _choose_tile(tile_cfg, x.shape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
-                                                    pad_w, dil, ncols, dgrad, prec, pw_epilogue)
+                                                    pad_w, dil, ncols, dgrad, prec, pw_epilogue, io)
     stat = None
     if want_stats or bn_bwd is not None:
         mkey = (m, ncols, tile_cfg)
@@ -284,7 +367,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
                                       I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h),
                                       I(pad_w), I(dil), I(ncols), I(ldy), I(ldr), I(act), F(leak), I(int(accumulate)),
                                       I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), P(in_affine[0]),
-                                      P(in_affine[1]), stream()), "zs3_conv_igemm_in")
+                                      P(in_affine[1]), I(io), stream()), "zs3_conv_igemm_in")
     elif bn_bwd is not None or res_mask_bits is not None:
         assert scale is None and shift is None and act == 0 and not want_stats
         by, bmean, bistd, bmsc, bmsh, bbits = bn_bwd if bn_bwd is not None else (None,) * 6
@@ -295,19 +378,20 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
                                            I(ncols), I(ldy), I(ldr), I(int(accumulate)), I(int(dgrad)), I(prec),
                                            I(tile_cfg), P(zero_page(x.device)), P(by),
                                            I(_check_nhwc(by) if by is not None else 0), P(bmean),
-                                           P(bistd), P(bmsc), P(bmsh), P(bbits), P(stat), stream()),
+                                           P(bistd), P(bmsc), P(bmsh), P(bbits), P(stat), I(io), stream()),
               "zs3_conv_igemm_bnstats")
     else:
         check(lib().zs3_conv_igemm(P(x), P(w_pk), P(out), P(scale), P(shift), P(res), P(stat), I(n), I(h), I(w_),
                                    I(ho), I(wo), I(cin_pad), I(cin_valid), I(ldx), I(kh), I(kw), I(stride), I(pad_h),
                                    I(pad_w), I(dil), I(ncols), I(ldy), I(ldr), I(act), F(leak), I(int(accumulate)),
-                                   I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), stream()),
+                                   I(int(dgrad)), I(prec), I(tile_cfg), P(zero_page(x.device)), I(io), stream()),
               "zs3_conv_igemm")
     if prof:
         e1.record()
-        PROFILE.append(("conv_halo_kernel<%d, %d, %d>" % (prec, 256 if tile_cfg == 41 else 192, halo_ok(
-                            x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg))
-                        if tile_cfg in (41, 42) else "conv_halo_kernel<1, %d, bf16 in>" % (256 if tile_cfg == 141 else 192) if tile_cfg in (141, 142) else
+        PROFILE.append(("conv_halo_kernel<%d, %d, %d%s>" % (prec, 256 if tile_cfg == 41 else 192, halo_ok(
+                            x.shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg),
+                            ", bf16 in" if io & 1 else "")
+                        if tile_cfg in (41, 42) else
                         "conv_pw_kernel<%d, %d>" % (prec, 256 if tile_cfg == 51 else 128) if tile_cfg in (51, 52) else
                         "conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
@@ -336,14 +420,21 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
 _WGRAD_PLAN = {}
 
 
-def _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin):
+WGRAD16_FAST = False   # set once conv_wgrad_strip.hip's kernels read bf16-stored operands (zs3_conv_wgrad_caps)
+
+
+def _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, io=0):
     """(kernel kind, split-K workspace floats) of a weight-gradient launch: a function of the geometry, asked of the library once
     per distinct layer.  kind: "strip" (3x3 strip-resident), "pw" (pointwise), "gemm" (the round-2 kernels)."""
-    key = (n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, WGRAD_STRIP, WGRAD_PW)
+    fast = io == 0 or (WGRAD16_FAST and io == 3)
+    key = (n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, WGRAD_STRIP, WGRAD_PW, io, fast, ACT_DTYPE)
     plan = _WGRAD_PLAN.get(key)
     if plan is None:
         splitk, ws = ctypes.c_int(0), ctypes.c_long(0)
-        if WGRAD_STRIP and kh == 3 and kw == 3 and lib().zs3_conv_wgrad_strip_plan(
+        if not fast:
+            lib().zs3_conv_wgrad_plan(I(n * ho * wo), I(wo), I(cout), I(cin), I(kh * kw), ctypes.byref(splitk), ctypes.byref(ws))
+            plan = ("gemm", ws.value)
+        elif WGRAD_STRIP and kh == 3 and kw == 3 and lib().zs3_conv_wgrad_strip_plan(
                 I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride), I(pad_h), I(pad_w), I(dil), I(cout), I(cin),
                 ctypes.byref(splitk), ctypes.byref(ws)):
             plan = ("strip", ws.value)
@@ -365,7 +456,7 @@ def consumer_applies_bn(xshape, ldx, wp, stride, pad, dil, prec=None):
     n, h, w_, _ = xshape
     ho, wo = conv_out_size(h, wp.kh, stride, pad, dil), conv_out_size(w_, wp.kw, stride, pad, dil)
     cin_valid = min(_round_up(wp.cin, 4), ldx)
-    if wp.cin % 4 or ldx % 4:
+    if wp.cin % 4 or ldx % 4 or ACT_DTYPE == BF16:   # (bf16-stored operands are copied, not converted: no transform in the producers)
         return False
     tile = _choose_tile(0, xshape, n * ho * wo, ho, wo, wp.cin_pad, cin_valid, ldx, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout,
                         False, prec, True)
@@ -387,7 +478,10 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
     ci_read = ci_read or min(_round_up(cin, 4), ldx)
     dw = out if out is not None else torch.empty((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == cout * kh * kw * cin
-    plan = _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin)
+    io = _io(dy) | (_io(x) << 1)
+    if io and prec != 1:
+        raise ValueError("bf16-stored operands need plain-bf16 products (prec = 1)")
+    plan = _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, io)
     kind, nws = plan
     xs, xh = x_affine if x_affine is not None else (None, None)
     if x_affine is not None and kind == "gemm":
@@ -397,15 +491,16 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
         # strip-resident kernel (csrc/conv_wgrad_strip.hip): all nine taps from one LDS-resident strip of x
         check(lib().zs3_conv_wgrad_strip(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(dil), I(co_read), I(cout),
                                          I(ci_read), I(cin), I(lddy), I(ldx), I(prec), P(zero_page(x.device)), P(xs), P(xh),
-                                         stream()), "zs3_conv_wgrad_strip")
+                                         *((I(io),) if WGRAD16_FAST else ()), stream()), "zs3_conv_wgrad_strip")
     elif kind == "pw":
         # pointwise kernel (csrc/conv_wgrad_strip.hip): producer waves split both operands once, transposing fragment reads
         check(lib().zs3_conv_wgrad_pw(P(dy), P(x), P(dw), P(work), I(n * h * w_), I(co_read), I(cout), I(ci_read), I(cin),
-                                      I(lddy), I(ldx), I(prec), P(zero_page(x.device)), P(xs), P(xh), stream()), "zs3_conv_wgrad_pw")
+                                      I(lddy), I(ldx), I(prec), P(zero_page(x.device)), P(xs), P(xh),
+                                      *((I(io),) if WGRAD16_FAST else ()), stream()), "zs3_conv_wgrad_pw")
     else:
         check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
                                    I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
-                                   I(prec), P(zero_page(x.device)), stream()), "zs3_conv_wgrad")
+                                   I(prec), P(zero_page(x.device)), I(io), stream()), "zs3_conv_wgrad")
     return dw
 
 
@@ -425,7 +520,7 @@ def colstats(x):
     chunks, rpb = ctypes.c_int(0), ctypes.c_int(0)
     lib().zs3_colstats_plan(I(m), I(c), ctypes.byref(chunks), ctypes.byref(rpb))
     part = torch.empty((chunks.value, 2, c), dtype=torch.float32, device=x.device)
-    check(lib().zs3_colstats(P(x), I(ld), I(m), I(c), P(part), stream()), "zs3_colstats")
+    check(lib().zs3_colstats(P(x), I(ld), I(m), I(c), P(part), I(_io(x)), stream()), "zs3_colstats")
     return part
 
 
@@ -480,19 +575,20 @@ def _drop_args(drop):
 
 
 def affine_act(x, scale=None, shift=None, alpha=1.0, res=None, out=None, div=1, act=0, leak=0.2, accumulate=False,
-               out_shape=None, mask_out=None, drop=None):
+               out_shape=None, mask_out=None, drop=None, out_dtype=None):
     """mask_out: optional uint8 tensor of M*C/4 bytes receiving the sign bits of the pre-activation values.
     drop: (p, seed) -- nn.Dropout fused behind the activation, the mask `dropout(out, p, seed)` would draw."""
     require_gpu(x, scale, shift, res, out)
     m_in, c, ldx = _rows(x)
     if out is None:
-        out = torch.empty(out_shape if out_shape is not None else x.shape, dtype=torch.float32, device=x.device)
+        out = torch.empty(out_shape if out_shape is not None else x.shape, dtype=out_dtype or x.dtype, device=x.device)
     m, c2, ldo = _rows(out)
     assert c2 == c and m == m_in * div
+    _same_type(x, res)
     ldr = _rows(res)[2] if res is not None else 0
     check(lib().zs3_affine_act(P(x), I(ldx), P(scale), P(shift), F(alpha), P(res), I(ldr), P(out), I(ldo),
                                ctypes.c_long(m), I(c), I(div), I(act), F(leak), I(int(accumulate)), P(mask_out), *_drop_args(drop),
-                               stream()), "zs3_affine_act")
+                               I(_io(x, out)), stream()), "zs3_affine_act")
     return out
 
 
@@ -503,8 +599,9 @@ def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None, m
     chunks, rpb = ctypes.c_int(0), ctypes.c_int(0)
     lib().zs3_colstats_plan(I(m), I(c), ctypes.byref(chunks), ctypes.byref(rpb))
     part = torch.empty((chunks.value, 2, c), dtype=torch.float32, device=dA.device)
+    _same_type(dA, a_out, y)
     check(lib().zs3_bn_bwd_stats(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), P(mask_scale), P(mask_shift),
-                                 P(mask_bits), I(m), I(c), P(part), *_drop_args(drop), stream()), "zs3_bn_bwd_stats")
+                                 P(mask_bits), I(m), I(c), P(part), *_drop_args(drop), I(_io(dA)), stream()), "zs3_bn_bwd_stats")
     return part
 
 
@@ -526,14 +623,15 @@ def bn_act_bwd(dA, a_out, y, mean, invstd, gamma, c1, c2, dy=None, dres=None, dr
     require_gpu(dA, a_out, y, dy, dres)
     m, c, ldd = _rows(dA)
     if want_dy and dy is None:
-        dy = torch.empty(dA.shape, dtype=torch.float32, device=dA.device)
+        dy = torch.empty(dA.shape, dtype=dA.dtype, device=dA.device)
+    _same_type(dA, a_out, y, dy, dres)
     lda = _rows(a_out)[2] if a_out is not None else 0
     ldy = _rows(y)[2] if y is not None else 0
     ldo = _rows(dy)[2] if dy is not None else 0
     ldr = _rows(dres)[2] if dres is not None else 0
     check(lib().zs3_bn_act_bwd(P(dA), I(ldd), P(a_out), I(lda), P(y), I(ldy), P(mean), P(invstd), P(gamma), P(c1), P(c2),
                                P(mask_scale), P(mask_shift), P(mask_bits), P(dy), I(ldo), P(dres), I(ldr), I(int(dres_accumulate)), ctypes.c_long(m), I(c), I(act),
-                               F(leak), *_drop_args(drop), stream()), "zs3_bn_act_bwd")
+                               F(leak), *_drop_args(drop), I(3 if dA.dtype == BF16 else 0), stream()), "zs3_bn_act_bwd")
     return dy
 
 
@@ -541,9 +639,10 @@ def group_colsum(x, groups, scale=1.0, out=None):
     m, c, ld = _rows(x)
     r = m // groups
     if out is None:
-        out = torch.empty((groups, c), dtype=torch.float32, device=x.device)
-    check(lib().zs3_group_colsum(P(x), I(ld), I(groups), I(r), I(c), F(scale), P(out), I(_rows(out)[2]), stream()),
-          "zs3_group_colsum")
+        out = torch.empty((groups, c), dtype=x.dtype, device=x.device)
+    _same_type(x, out)
+    check(lib().zs3_group_colsum(P(x), I(ld), I(groups), I(r), I(c), F(scale), P(out), I(_rows(out)[2]), I(3 if x.dtype == BF16 else 0),
+                                 stream()), "zs3_group_colsum")
     return out
 
 
@@ -551,19 +650,19 @@ def group_colsum(x, groups, scale=1.0, out=None):
 def maxpool_fwd(x, k=3, stride=2, pad=1):
     n, h, w_, c = x.shape
     ho, wo = conv_out_size(h, k, stride, pad, 1), conv_out_size(w_, k, stride, pad, 1)
-    out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
     idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
     check(lib().zs3_maxpool_fwd(P(x), I(_check_nhwc(x)), P(out), I(c), P(idx), I(n), I(h), I(w_), I(ho), I(wo), I(c), I(k),
-                                I(stride), I(pad), stream()), "zs3_maxpool_fwd")
+                                I(stride), I(pad), I(3 if x.dtype == BF16 else 0), stream()), "zs3_maxpool_fwd")
     return out, idx
 
 
 def maxpool_bwd(dy, idx, in_hw, k=3, stride=2, pad=1):
     n, ho, wo, c = dy.shape
     h, w_ = in_hw
-    dx = torch.empty((n, h, w_, c), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((n, h, w_, c), dtype=dy.dtype, device=dy.device)
     check(lib().zs3_maxpool_bwd(P(dy), I(_check_nhwc(dy)), P(idx), P(dx), I(c), I(n), I(h), I(w_), I(ho), I(wo), I(c),
-                                I(k), I(stride), I(pad), stream()), "zs3_maxpool_bwd")
+                                I(k), I(stride), I(pad), I(3 if dy.dtype == BF16 else 0), stream()), "zs3_maxpool_bwd")
     return dx
 
 
@@ -571,9 +670,10 @@ def bilinear_fwd(x, size, out=None):
     n, h, w_, c = x.shape
     ho, wo = size
     if out is None:
-        out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        out = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    _same_type(x, out)
     check(lib().zs3_bilinear_fwd(P(x), I(_check_nhwc(x)), P(out), I(_check_nhwc(out)), I(n), I(h), I(w_), I(ho), I(wo),
-                                 I(c), stream()), "zs3_bilinear_fwd")
+                                 I(c), I(3 if x.dtype == BF16 else 0), stream()), "zs3_bilinear_fwd")
     return out
 
 
@@ -581,9 +681,10 @@ def bilinear_bwd(dout, in_hw, out=None, accumulate=False):
     n, ho, wo, c = dout.shape
     h, w_ = in_hw
     if out is None:
-        out = torch.empty((n, h, w_, c), dtype=torch.float32, device=dout.device)
+        out = torch.empty((n, h, w_, c), dtype=dout.dtype, device=dout.device)
+    _same_type(dout, out)
     check(lib().zs3_bilinear_bwd(P(dout), I(_check_nhwc(dout)), P(out), I(_check_nhwc(out)), I(n), I(h), I(w_), I(ho),
-                                 I(wo), I(c), I(int(accumulate)), stream()), "zs3_bilinear_bwd")
+                                 I(wo), I(c), I(int(accumulate)), I(3 if dout.dtype == BF16 else 0), stream()), "zs3_bilinear_bwd")
     return out
 
 
@@ -591,9 +692,10 @@ def bilinear_bwd(dout, in_hw, out=None, accumulate=False):
 def dropout(x, p, seed, out=None, row_idx=None, seed_dev=None):
     m, c, ld = _rows(x)
     if out is None:
-        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _same_type(x, out)
     check(lib().zs3_dropout(P(x), I(ld), P(out), I(_rows(out)[2]), ctypes.c_long(m), I(c), F(p),
-                            ctypes.c_ulonglong(seed), P(row_idx), P(seed_dev), stream()), "zs3_dropout")
+                            ctypes.c_ulonglong(seed), P(row_idx), P(seed_dev), I(3 if x.dtype == BF16 else 0), stream()), "zs3_dropout")
     return out
 
 
