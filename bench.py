@@ -29,7 +29,9 @@ import torch.distributed as dist  # noqa: E402
 FWD_GFLOP_PER_IMG = {21: 185.64, 60: 185.97}          # BASELINE.md section 3 (2*MAC, convs only)
 TRAIN_GFLOP_PER_IMG = {21: 555.7, 60: 556.7}          # fwd + dgrad + wgrad, no dgrad for the stem
 DTYPE_NOTE = {"bf16x3": "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate; fp32 storage)",
-              "bf16": "bf16 (plain bf16 MFMA products, fp32 accumulate; fp32 master weights and BN statistics)"}
+              "bf16": "bf16 (activations and inter-layer gradients stored as bf16, plain bf16 MFMA products, fp32 accumulate; fp32 master "
+                      "weights, weight gradients, BN statistics, class scores)",
+              "bf16f32": "bf16 products on fp32 storage (plain bf16 MFMA products, fp32 accumulate; every tensor fp32 in HBM)"}
 LAUNCH_BOUNDARY_US = 1.45         # dependent kernel boundary on one stream (MI355X_MICROARCH.md price list)
 PEAK_BF16_TF = 2500.0                                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -44,9 +46,10 @@ def parse():
     ap.add_argument("--classes", type=int, default=21)
     ap.add_argument("--workload", choices=["supervised", "gmmn", "gcn_context"], default="supervised")
     ap.add_argument("--gmmn-steps", type=int, default=10, help="timed GMMN steps (configs[2]) after the supervised loop; 0 = skip")
-    ap.add_argument("--dtype", choices=["bf16x3", "bf16"], default="bf16x3",
-                    help="conv arithmetic: bf16x3 = fp32 semantics as three bf16 MFMA products (configs[1-3]); "
-                         "bf16 = plain bf16 products, fp32 accumulate (configs[4])")
+    ap.add_argument("--dtype", choices=["bf16x3", "bf16", "bf16f32"], default="bf16x3",
+                    help="bf16x3 = fp32 storage, fp32 semantics as three bf16 MFMA products (configs[1-3]); bf16 = the 2-byte mode of "
+                         "configs[4]: activations and inter-layer gradients stored as bf16, plain bf16 products, fp32 accumulate / "
+                         "statistics / master weights; bf16f32 = plain bf16 products on fp32 storage (the rounds 2-3 form of --dtype bf16)")
     ap.add_argument("--sync-bn", type=int, default=-1,
                     help="SynchronizedBatchNorm2d (cross-rank batch statistics, one fp64 all-reduce per layer and direction): "
                          "-1 = the reference's rule, on iff more than one GPU (train_pascal.py:279); 0 / 1 force it")
@@ -115,7 +118,9 @@ def main():
 
     if args.sync_bn < 0:
         args.sync_bn = 1 if world > 1 else 0
-    ops.PREC_DEFAULT = 1 if args.dtype == "bf16" else 3
+    ops.PREC_DEFAULT = 3 if args.dtype == "bf16x3" else 1
+    if args.dtype == "bf16":
+        ops.set_storage(torch.bfloat16)
     unseen = [10, 14]
     seen = [c for c in range(args.classes) if c not in unseen]
     torch.manual_seed(1)
@@ -345,7 +350,7 @@ def main():
         fam = {k: v for k, v in agg.items() if k.startswith("conv_halo_kernel<")}
         if fam:
             agg = {k: v for k, v in agg.items() if k not in fam}
-            agg["conv_halo<%d>" % (1 if args.dtype == "bf16" else 3)] = [sum(v[i] for v in fam.values()) for i in range(3)]
+            agg["conv_halo<%d>" % (3 if args.dtype == "bf16x3" else 1)] = [sum(v[i] for v in fam.values()) for i in range(3)]
         tag = max(agg, key=lambda k: agg[k][2])
         n, fl, sec = agg[tag]
         ach = fl / sec / 1e12

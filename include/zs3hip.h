@@ -126,7 +126,7 @@ int zs3_conv_wgrad_strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int K
                               int co, int ci, int* splitk_out, long* workspace_floats);
 int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int dil,
                          int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
-                         const void* zero_page, const float* x_scale, const float* x_shift, void* stream);
+                         const void* zero_page, const float* x_scale, const float* x_shift, int io, void* stream);
 /* Pointwise weight gradient (csrc/conv_wgrad_strip.hip) of the stride-1 1x1 convolutions: dw[co][ci] = sum over the M = N*H*W
  * positions of dy[p][co] * x[p][ci], with the strip kernel's division of labour (producer waves split both operands to bf16
  * hi/lo once per (64 or 128)^2 tile and K step, MFMA waves read position-major fragments with ds_read_b64_tr_b16).
@@ -136,7 +136,7 @@ int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* work
 int zs3_conv_wgrad_pw_plan(long M, int co, int ci, int* splitk_out, long* workspace_floats);
 int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, float* workspace, long M, int co_read, int co_write,
                       int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page, const float* x_scale,
-                      const float* x_shift, void* stream);
+                      const float* x_shift, int io, void* stream);
 /* dw[co][kh][kw][ci] = sum_m dy[m][co] * x[gather(m,kh,kw)][ci]  (channels_last weight layout).
  * dy: [M][lddy] with co_read (multiple of 4) readable channels of which co_write rows are produced;
  * x likewise (ci_read / ci_write).  Split-K over pixels: call zs3_conv_wgrad_plan (same M = N*Ho*Wo, Wo, channel

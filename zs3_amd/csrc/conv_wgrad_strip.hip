@@ -69,8 +69,11 @@ struct Pos {           // a lane's position in a padded stream: q and its coordi
   int n, yp, xp;
 };
 
-template <int PREC, bool XAFF = false>
+// IO16: dy and x are stored as bf16 (plain-bf16 products only): the producers copy 8 bytes per lane and position into the LDS rows,
+// no conversion (a register set then holds the raw pair of words in its first two components).
+template <int PREC, bool XAFF = false, bool IO16 = false>
 __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p) {
+  static_assert(!IO16 || (PREC == 1 && !XAFF), "bf16-stored operands: plain bf16 products, no producer-side transform");
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,6 +129,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p
     auto fetch = [&](const Pos& s, const float* base, int ld, int c0, bool cok, bool transform = false) {
       const bool real = s.q >= 0 && s.q < p.Q && s.yp < p.H && s.xp < p.W && cok;
       const long pix = ((long)s.n * p.H + s.yp) * p.W + s.xp;
+      if constexpr (IO16) {
+        const bf16_t* src = real ? reinterpret_cast<const bf16_t*>(base) + pix * ld + c0 + cq * 4 : reinterpret_cast<const bf16_t*>(p.zero);
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(src);
+        return f32x4{__uint_as_float(raw[0]), __uint_as_float(raw[1]), 0.f, 0.f};
+      }
       const float* src = real ? base + pix * ld + c0 + cq * 4 : p.zero;
       f32x4 v = *reinterpret_cast<const f32x4*>(src);
       if constexpr (XAFF) {
@@ -138,6 +146,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_strip_kernel(const StripArgs p
       return v;
     };
     auto conv_write = [&](const f32x4 v, unsigned char* row) {
+      if constexpr (IO16) {
+        *reinterpret_cast<u32x2*>(row + cq * 8) = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])};
+        return;
+      }
       u32x2 hi, lo;
       unsigned h, l;
       split_pair<PREC>(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
@@ -314,8 +326,10 @@ struct PwArgs {
 
 constexpr int PW_ARRAY = 32 * WS_ROW;   // one 64-channel array of a stage: 32 positions
 
-template <int PREC, int NCO, int NCI, bool XAFF = false>
+template <int PREC, int NCO, int NCI, bool XAFF = false, bool IO16 = false>   // IO16: as conv_wgrad_strip_kernel
 __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
+  static_assert(!IO16 || (PREC == 1 && !XAFF), "bf16-stored operands: plain bf16 products, no producer-side transform");
+  constexpr int ESZ = IO16 ? 2 : 4;   // bytes per stored element
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   constexpr int NARR = NCO + NCI;
   constexpr int STAGE = NARR * PW_ARRAY;
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
     const int prow = (tid - 256) >> 4, cq = tid & 15;
     long q = q_begin + prow;    // position of this lane's next load (advances by 16 per half step)
     bool cok[NARR];
-    const float* ptr[NARR];
+    const unsigned char* ptr[NARR];
     long ld16[NARR];
 #pragma unroll
     for (int a = 0; a < NARR; ++a) {
@@ -343,8 +357,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
       const int c = (isd ? co0 + 64 * a : ci0 + 64 * (a - NCO)) + cq * 4;
       const long ld = isd ? p.lddy : p.ldx;
       cok[a] = c < (isd ? p.co_read : p.ci_read);
-      ptr[a] = (isd ? p.dy : p.x) + c + q * ld;
-      ld16[a] = 16 * ld;
+      ptr[a] = reinterpret_cast<const unsigned char*>(isd ? p.dy : p.x) + (c + q * ld) * ESZ;
+      ld16[a] = 16 * ld * ESZ;
     }
     f32x4 xsc[NCI], xsh[NCI];      // (XAFF) scale / shift of this lane's four channels in each x array
     if constexpr (XAFF) {
@@ -362,14 +376,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
         const bool rok = q < p.M;
 #pragma unroll
         for (int a = 0; a < NARR; ++a) {
-          const float* src = rok && cok[a] ? ptr[a] : p.zero;
-          dst[h * NARR + a] = *reinterpret_cast<const f32x4*>(src);
+          const unsigned char* src = rok && cok[a] ? ptr[a] : reinterpret_cast<const unsigned char*>(p.zero);
+          if constexpr (IO16) {
+            const u32x2 raw = *reinterpret_cast<const u32x2*>(src);
+            dst[h * NARR + a] = f32x4{__uint_as_float(raw[0]), __uint_as_float(raw[1]), 0.f, 0.f};
+          } else {
+            dst[h * NARR + a] = *reinterpret_cast<const f32x4*>(src);
+          }
           ptr[a] += ld16[a];
         }
         q += 16;
       }
     };
     auto conv_write = [&](const f32x4 v, unsigned char* row) {
+      if constexpr (IO16) {
+        *reinterpret_cast<u32x2*>(row + cq * 8) = u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])};
+        return;
+      }
       u32x2 hi, lo;
       unsigned h, l;
       split_pair<PREC>(v[0], v[1], h, l); hi[0] = h; lo[0] = l;
@@ -633,20 +656,23 @@ PwPlan pw_plan(long M, int co, int ci) {
   return s;
 }
 
-template <int PREC, int NCO, int NCI, bool XAFF>
+template <int PREC, int NCO, int NCI, bool XAFF, bool IO16 = false>
 int launch_pw_x(const PwArgs& a, int grid, int lds, hipStream_t st) {
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pw_kernel<PREC, NCO, NCI, XAFF>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pw_kernel<PREC, NCO, NCI, XAFF, IO16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return -4;
     configured = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_pw_kernel<PREC, NCO, NCI, XAFF>), dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv_wgrad_pw_kernel<PREC, NCO, NCI, XAFF, IO16>), dim3(grid), dim3(512), lds, st, a);
   return ZS3_LAUNCH_CHECK();
 }
 template <int PREC, int NCO, int NCI>
-int launch_pw(const PwArgs& a, int grid, int lds, hipStream_t st) {
+int launch_pw(const PwArgs& a, int grid, int lds, int io16, hipStream_t st) {
+  if constexpr (PREC == 1) {
+    if (io16) return launch_pw_x<1, NCO, NCI, false, true>(a, grid, lds, st);
+  }
   return a.x_scale ? launch_pw_x<PREC, NCO, NCI, true>(a, grid, lds, st) : launch_pw_x<PREC, NCO, NCI, false>(a, grid, lds, st);
 }
 
@@ -679,10 +705,13 @@ extern "C" int zs3_conv_wgrad_pw_plan(long M, int co, int ci, int* splitk_out, l
 
 extern "C" int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, float* workspace, long M, int co_read, int co_write,
                                  int ci_read, int ci_write, int lddy, int ldx, int prec, const void* zero_page,
-                                 const float* x_scale, const float* x_shift, void* stream) {
+                                 const float* x_scale, const float* x_shift, int io, void* stream) {
   if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 3)) return -2;
   if ((x_scale == nullptr) != (x_shift == nullptr) || ((uintptr_t)x_scale & 15) || ((uintptr_t)x_shift & 15)) return -1;
+  if (io != 0 && io != 3) return -7;                 // one of the two operands bf16: zs3_conv_wgrad
+  if (io && (prec != 1 || x_scale)) return -7;       // bf16-stored operands: plain-bf16 products, no transform
+  const int io16 = io ? 1 : 0;
   const PwPlan s = pw_plan(M, co_write, ci_write);
   if (!s.ok) return -7;
   if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
@@ -702,14 +731,14 @@ extern "C" int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, flo
   int rc;
   const int key = (prec == 3 ? 4 : 0) + (s.nco == 2 ? 2 : 0) + (s.nci == 2 ? 1 : 0);
   switch (key) {
-    case 0: rc = launch_pw<1, 1, 1>(a, grid, s.lds_bytes, st); break;
-    case 1: rc = launch_pw<1, 1, 2>(a, grid, s.lds_bytes, st); break;
-    case 2: rc = launch_pw<1, 2, 1>(a, grid, s.lds_bytes, st); break;
-    case 3: rc = launch_pw<1, 2, 2>(a, grid, s.lds_bytes, st); break;
-    case 4: rc = launch_pw<3, 1, 1>(a, grid, s.lds_bytes, st); break;
-    case 5: rc = launch_pw<3, 1, 2>(a, grid, s.lds_bytes, st); break;
-    case 6: rc = launch_pw<3, 2, 1>(a, grid, s.lds_bytes, st); break;
-    default: rc = launch_pw<3, 2, 2>(a, grid, s.lds_bytes, st); break;
+    case 0: rc = launch_pw<1, 1, 1>(a, grid, s.lds_bytes, io16, st); break;
+    case 1: rc = launch_pw<1, 1, 2>(a, grid, s.lds_bytes, io16, st); break;
+    case 2: rc = launch_pw<1, 2, 1>(a, grid, s.lds_bytes, io16, st); break;
+    case 3: rc = launch_pw<1, 2, 2>(a, grid, s.lds_bytes, io16, st); break;
+    case 4: rc = launch_pw<3, 1, 1>(a, grid, s.lds_bytes, io16, st); break;
+    case 5: rc = launch_pw<3, 1, 2>(a, grid, s.lds_bytes, io16, st); break;
+    case 6: rc = launch_pw<3, 2, 1>(a, grid, s.lds_bytes, io16, st); break;
+    default: rc = launch_pw<3, 2, 2>(a, grid, s.lds_bytes, io16, st); break;
   }
   if (rc) return rc;
   if (s.splitk > 1) rc = reduce_slabs(workspace, dw, a.slab, s.splitk, st);
@@ -729,10 +758,12 @@ extern "C" int zs3_conv_wgrad_strip_plan(int N, int H, int W, int Ho, int Wo, in
 
 extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, float* workspace, int N, int H, int W, int dil,
                                     int co_read, int co_write, int ci_read, int ci_write, int lddy, int ldx, int prec,
-                                    const void* zero_page, const float* x_scale, const float* x_shift, void* stream) {
+                                    const void* zero_page, const float* x_scale, const float* x_shift, int io, void* stream) {
   if (co_read % 4 || ci_read % 4 || lddy % 4 || ldx % 4 || (prec != 1 && prec != 3) || zero_page == nullptr) return -1;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)zero_page & 15) || ((uintptr_t)dw & 3)) return -2;
   if ((x_scale == nullptr) != (x_shift == nullptr) || ((uintptr_t)x_scale & 15) || ((uintptr_t)x_shift & 15)) return -1;
+  if (io != 0 && io != 3) return -7;
+  if (io && (prec != 1 || x_scale)) return -7;
   const StripPlan s = strip_plan(N, H, W, H, W, 3, 3, 1, dil, dil, dil, co_write, ci_write);
   if (!s.ok) return -7;
   if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
@@ -750,12 +781,13 @@ extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, 
   for (int t = 0; t < 9; ++t) a.toff[t] = (t / 3 - 1) * dil * a.Wd + (t % 3 - 1) * dil;
   hipStream_t st = (hipStream_t)stream;
   const int grid = a.tiles_co * a.tiles_ci * s.splitk;
-  static bool configured[4] = {false, false, false, false};
-  const int pi = (prec == 1 ? 0 : 1) + (x_scale ? 2 : 0);
-  const void* fns[4] = {reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1, false>),
+  static bool configured[5] = {false, false, false, false, false};
+  const int pi = io ? 4 : (prec == 1 ? 0 : 1) + (x_scale ? 2 : 0);
+  const void* fns[5] = {reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1, false>),
                         reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<3, false>),
                         reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1, true>),
-                        reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<3, true>)};
+                        reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<3, true>),
+                        reinterpret_cast<const void*>(&conv_wgrad_strip_kernel<1, false, true>)};
   if (!configured[pi]) {
     if (hipFuncSetAttribute(fns[pi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -4;
     configured[pi] = true;
@@ -764,6 +796,7 @@ extern "C" int zs3_conv_wgrad_strip(const float* dy, const float* x, float* dw, 
     case 0: hipLaunchKernelGGL((conv_wgrad_strip_kernel<1, false>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
     case 1: hipLaunchKernelGGL((conv_wgrad_strip_kernel<3, false>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
     case 2: hipLaunchKernelGGL((conv_wgrad_strip_kernel<1, true>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
+    case 4: hipLaunchKernelGGL((conv_wgrad_strip_kernel<1, false, true>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
     default: hipLaunchKernelGGL((conv_wgrad_strip_kernel<3, true>), dim3(grid), dim3(512), s.lds_bytes, st, a); break;
   }
   int rc = ZS3_LAUNCH_CHECK();

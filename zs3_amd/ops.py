@@ -420,7 +420,7 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
 _WGRAD_PLAN = {}
 
 
-WGRAD16_FAST = False   # set once conv_wgrad_strip.hip's kernels read bf16-stored operands (zs3_conv_wgrad_caps)
+WGRAD16_FAST = os.environ.get("ZS3_WGRAD16_FAST", "1") == "1"   # strip-resident / pointwise weight-gradient kernels on bf16-stored operands (both bf16)
 
 
 def _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, io=0):
@@ -491,12 +491,12 @@ def conv2d_wgrad(dy, x, cout, cin, kh, kw, stride=1, pad_h=0, pad_w=None, dil=1,
         # strip-resident kernel (csrc/conv_wgrad_strip.hip): all nine taps from one LDS-resident strip of x
         check(lib().zs3_conv_wgrad_strip(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(dil), I(co_read), I(cout),
                                          I(ci_read), I(cin), I(lddy), I(ldx), I(prec), P(zero_page(x.device)), P(xs), P(xh),
-                                         *((I(io),) if WGRAD16_FAST else ()), stream()), "zs3_conv_wgrad_strip")
+                                         I(io), stream()), "zs3_conv_wgrad_strip")
     elif kind == "pw":
         # pointwise kernel (csrc/conv_wgrad_strip.hip): producer waves split both operands once, transposing fragment reads
         check(lib().zs3_conv_wgrad_pw(P(dy), P(x), P(dw), P(work), I(n * h * w_), I(co_read), I(cout), I(ci_read), I(cin),
                                       I(lddy), I(ldx), I(prec), P(zero_page(x.device)), P(xs), P(xh),
-                                      *((I(io),) if WGRAD16_FAST else ()), stream()), "zs3_conv_wgrad_pw")
+                                      I(io), stream()), "zs3_conv_wgrad_pw")
     else:
         check(lib().zs3_conv_wgrad(P(dy), P(x), P(dw), P(work), I(n), I(h), I(w_), I(ho), I(wo), I(kh), I(kw), I(stride),
                                    I(pad_h), I(pad_w), I(dil), I(co_read), I(cout), I(ci_read), I(cin), I(lddy), I(ldx),
