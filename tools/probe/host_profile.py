@@ -6,6 +6,10 @@ import torch
 from zs3_amd.modeling.deeplab import DeepLab
 from zs3_amd.utils.loss import SegmentationLosses
 from zs3_amd.optim import SGD
+import os
+from zs3_amd import ops
+if os.environ.get("ZS3_STORAGE") == "bf16":
+    ops.set_storage(torch.bfloat16)
 dev = torch.device("cuda:0")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 torch.manual_seed(1)

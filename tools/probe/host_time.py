@@ -2,13 +2,17 @@
 steps (how long python needs to enqueue a step) next to the synced wall time per step, and the queue depth proxy: how long
 torch.cuda.synchronize() blocks after the host has finished enqueuing N steps."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from zs3_amd.modeling.deeplab import DeepLab
 from zs3_amd.optim import SGD
 from zs3_amd.utils.loss import SegmentationLosses
 from zs3_amd.utils.synthetic import make_batch
 
+import os
+from zs3_amd import ops
+if os.environ.get("ZS3_STORAGE") == "bf16":
+    ops.set_storage(torch.bfloat16)
 dev = torch.device("cuda:0")
 torch.manual_seed(1)
 model = DeepLab(num_classes=21, pretrained=False).to(dev).train()

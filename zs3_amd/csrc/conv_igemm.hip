@@ -20,6 +20,8 @@
 //
 // Replaces: every nn.Conv2d on the reference hot path (resnet.py:16-28,79,125-131; aspp.py:11-19,86,97;
 // decoder.py:12,16,20,26) and nn.Linear of the GMMN (gmmn.py:18,33) as a 1x1 conv.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "conv_common.h"
@@ -27,12 +29,16 @@
 
 namespace {
 
-// A16: x is stored as bf16 (plain-bf16 products only): 8 bytes per lane and row piece, written to LDS as they arrive.
-template <int BM, int BN, int PREC, int PIPE, bool A16 = false>
+// A16: x is stored as bf16 (plain-bf16 products only): written to LDS as it arrives.  KS = 64 (A16 only): a K step is 64 channels
+// -- the LDS row's lo half holds channels 32..63 instead of a lo plane, a lane moves 16 bytes = 8 channels per row and only the
+// hi halves of two weight chunks -- so one barrier covers twice the MFMAs (the plain-bf16 K loop is latency-, not MFMA-bound).
+template <int BM, int BN, int PREC, int PIPE, bool A16 = false, int KS = 32>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   static_assert(!A16 || PREC == 1, "bf16-stored input: plain bf16 products only");
+  static_assert(KS == 32 || (KS == 64 && A16), "64-channel K steps: bf16-stored input only");
+  constexpr int CPL = KS / 8;                                    // channels per lane and row: 8 lanes walk a row's K step
   using XT = std::conditional_t<A16, bf16_t, float>;             // element type of x in memory
-  using XV = std::conditional_t<A16, u32x2, f32x4>;              // four channels of it in registers
+  using XV = std::conditional_t<A16, std::conditional_t<KS == 64, u32x4, u32x2>, f32x4>;   // CPL channels of it in registers
   const XT* const xbase = reinterpret_cast<const XT*>(p.x);
   const XT* const xzero = reinterpret_cast<const XT*>(p.zero);
   constexpr int ROW = 72;               // bf16 per LDS row (144 B)
@@ -80,7 +86,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   for (int j = 0; j < RB; ++j) {
     int col = n0 + srow + 32 * j;
     bool ok = col < p.ncols;
-    wrow[j] = ok ? p.w_pk + (size_t)col * (2 * p.ldw) + q * 8 : reinterpret_cast<const unsigned short*>(p.zero);
+    // (KS = 64: the hi halves of two consecutive 32-wide chunks: piece q & 3 of chunk q >> 2)
+    wrow[j] = ok ? p.w_pk + (size_t)col * (2 * p.ldw) + (KS == 64 ? (q >> 2) * 64 + (q & 3) * 8 : q * 8)
+                 : reinterpret_cast<const unsigned short*>(p.zero);
     wstep[j] = ok ? 1 : 0;   // masked columns keep re-reading the zero page
   }
 
@@ -113,11 +121,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           ok = ok && ((hi | wi) >= 0);
         }
         ok = ok && hi < p.H && wi < p.W;
-        abase[i] = ok ? xrow[i] + ((hi * p.W + wi) * p.ldx + q * 4) : xzero;
+        abase[i] = ok ? xrow[i] + ((hi * p.W + wi) * p.ldx + q * CPL) : xzero;
         astep[i] = ok ? 1 : 0;
       }
     }
-    const bool cok = c0 + q * 4 < p.cin_valid;
+    const bool cok = c0 + q * CPL < p.cin_valid;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const XT* ptr = cok ? abase[i] + c0 * astep[i] : xzero;
@@ -127,8 +135,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     for (int j = 0; j < RB; ++j) S.breg[j] = *reinterpret_cast<const u32x4*>(wrow[j] + 2 * kofs * wstep[j]);
   };
   auto advance = [&]() {
-    kofs += 32;
-    c0 += 32;
+    kofs += KS;
+    c0 += KS;
     if (c0 == p.cin_pad) {
       c0 = 0;
       if (++kw == p.KW) {
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         *reinterpret_cast<f32x4*>(As + (srow + 32 * i) * ROW + q * 8) = S.areg[i];
         continue;
       }
-      if constexpr (A16) {         // already bf16: the four channels go to LDS as they came
-        *reinterpret_cast<u32x2*>(As + (srow + 32 * i) * ROW + q * 4) = S.areg[i];
+      if constexpr (A16) {         // already bf16: the lane's channels go to LDS as they came
+        *reinterpret_cast<XV*>(As + (srow + 32 * i) * ROW + q * CPL) = S.areg[i];
         continue;
       }
       u32x2 hi, lo;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j)
-      *reinterpret_cast<u32x4*>(Bs + (srow + 32 * j) * ROW + (q & 3) * 8 + (q >> 2) * 32) = S.breg[j];
+      *reinterpret_cast<u32x4*>(Bs + (srow + 32 * j) * ROW + (q & 3) * 8 + (q >> 2) * 32) = S.breg[j];   // = q * 8: K order
   };
 
   f32x16 acc[TM][TN];
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const unsigned short* As = smem + stage * STAGE + (wm * (BM / 2) + (lane & 31)) * ROW + (lane >> 5) * 8;
     const unsigned short* Bs = smem + stage * STAGE + BM * ROW + (wn * (BN / 2) + (lane & 31)) * ROW + (lane >> 5) * 8;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KS / 16; ++kk) {
       bf16x8 a_hi[TM], a_lo[TM], b_hi[TN], b_lo[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
   };
 
-  const int KT = p.KH * p.KW * (p.cin_pad / 32);
+  const int KT = p.KH * p.KW * (p.cin_pad / KS);
   if (PIPE == 1) {
     // one register stage: loads of step k+1 fly during the MFMAs of step k
     Stage s0;
@@ -801,7 +809,11 @@ int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   dim3 grid(mt * nt), block(256);
   if (a.x_bf16) {   // bf16-stored input: plain-bf16 products on the two-deep-prefetch form of the tile
     if (prec != 1) return -7;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true>), grid, block, 0, st, a);
+    static const bool k64 = getenv("ZS3_IGEMM16_K64") ? atoi(getenv("ZS3_IGEMM16_K64")) != 0 : true;
+    if (k64 && (a.cin_pad & 63) == 0 && (a.cin_valid & 7) == 0 && (a.ldx & 7) == 0)
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true, 64>), grid, block, 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true>), grid, block, 0, st, a);
   } else if (prec == 1)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, PIPE>), grid, block, 0, st, a);
   else if (prec == 0)

@@ -223,50 +223,66 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         for (int c = 0; c < 2; ++c) *reinterpret_cast<u32x4*>(sb + c * 8192 + e * 4096 + wdst) = s.w[e][c];
     };
 
-    // ---- (LEPI) the loading epilogue, one `pass` = this wave's 32 columns x RPW rows of the finished tile.  A lane owns EW
-    // consecutive columns (16 bytes of y / res / bn_y) of one row; per-column operands are loaded once per tile.
-    constexpr int EW = Y16 ? 8 : 4, LPR = 32 / EW, RPW = 64 / LPR, NPASS = LEPI ? BM / RPW : 1;
+    // ---- (LEPI) the loading epilogue.  One `pass` = this wave's 32 columns x 16 rows of the finished tile; a lane owns eight
+    // values of it: bf16 tensors -- eight consecutive columns of one row (one 16-byte piece of y / res / bn_y); fp32 tensors --
+    // four consecutive columns of rows rip and rip + 8 (two 16-byte pieces).  The per-column BatchNorm operands of the tile sit in
+    // LDS (the 2 KB the consumer-side epilogue uses for its column sums: unused here), not in registers.
+    constexpr int EW = 8, CW = Y16 ? 8 : 4, NR = EW / CW, LPR = 32 / CW, NPASS = LEPI ? BM / 16 : 1;
     using YT = std::conditional_t<Y16, bf16_t, float>;
-    using MT = std::conditional_t<Y16, unsigned short, unsigned char>;   // the lane's mask bits: one byte per four columns
-    const int pw = wave - 4, rip = lane / LPR, ecol = 32 * pw + (lane % LPR) * EW;   // row in pass, first column in the tile
+    using MT = std::conditional_t<Y16, unsigned short, unsigned char>;   // a row piece's mask bits: one byte per four columns
+    const int pw = wave - 4, rip = lane / LPR, ecol = 32 * pw + (lane % LPR) * CW;   // row in pass, first column in the tile
     struct EpiRegs {
-      f32x4 res, by, old;   // raw 16 bytes each
-      unsigned rm, bm;
+      f32x4 ro[NR], by[NR];   // raw 16-byte pieces: res or (accumulate) the old y -- never both in one launch --, and bn_y
+      unsigned rm, bm;        // mask bytes of the NR pieces (piece n in bits 16 n ..)
     };
-    EpiRegs ebuf[3][LEPI ? 2 : 1];
-    float bs_s[EW], bs_q[EW], c_mu[EW], c_is[EW], c_msc[EW], c_msh[EW];
+    EpiRegs ebuf[3][LEPI ? (Y16 ? 2 : 1) : 1];
+    float bs_s[CW], bs_q[CW];
+    float* const ccol = reinterpret_cast<float*>(dsm + OFF_CT);   // [4][128]: istd, -mean * istd, mask scale, mask shift
     int e_m0 = 0, e_n0 = 0, e_mt = 0;          // tile whose epilogue is in progress
     int e_issue = NPASS, e_cons = NPASS;       // next pass to request / to finish (NPASS: none)
+    int npend[3] = {0, 0, 0};                  // passes requested into register set 0 / 1 / 2 and not finished yet
     auto epi_begin = [&](int tile) {
       const int mt = tile / ntn, nt = tile - mt * ntn;
       e_mt = mt; e_m0 = mt * BM; e_n0 = nt * BN;
       e_issue = 0; e_cons = 0;
-      const int col = e_n0 + ecol;
-      const bool cok = col < p.ncols;
 #pragma unroll
-      for (int e = 0; e < EW; ++e) {
-        bs_s[e] = 0.f; bs_q[e] = 0.f;
-        c_mu[e] = (p.bs_partial && cok) ? p.bs_mean[col + e] : 0.f;
-        c_is[e] = (p.bs_partial && cok) ? p.bs_istd[col + e] : 0.f;
-        c_msc[e] = (p.bs_partial && p.bs_msc && cok) ? p.bs_msc[col + e] : 0.f;
-        c_msh[e] = (p.bs_partial && p.bs_msc && cok) ? p.bs_msh[col + e] : 0.f;
+      for (int e = 0; e < CW; ++e) {
+        bs_s[e] = 0.f;
+        bs_q[e] = 0.f;
+      }
+      if (p.bs_partial && lane < 32) {           // this wave's 32 columns; read back by the same wave only
+        const int c = 32 * pw + lane, col = e_n0 + c;
+        const bool cok = col < p.ncols;
+        const float is = cok ? p.bs_istd[col] : 0.f;
+        ccol[c] = is;
+        ccol[128 + c] = cok ? -p.bs_mean[col] * is : 0.f;
+        ccol[256 + c] = (cok && p.bs_msc) ? p.bs_msc[col] : 0.f;
+        ccol[384 + c] = (cok && p.bs_msc) ? p.bs_msh[col] : 0.f;
       }
     };
-    auto epi_issue = [&](EpiRegs& d) {        // request pass e_issue (if any)
-      if (e_issue >= NPASS) return;
-      const int row = e_m0 + e_issue * RPW + rip, col = e_n0 + ecol;
-      const bool ok = row < p.M && col < p.ncols;
+    auto epi_issue = [&](EpiRegs& d) -> int { // request pass e_issue (if any); 1 when a request was made
+      if (e_issue >= NPASS) return 0;
+      const int col = e_n0 + ecol;
       const YT* zero = reinterpret_cast<const YT*>(p.zero);
       const unsigned char* zb = reinterpret_cast<const unsigned char*>(p.zero);
-      if (p.res) d.res = *reinterpret_cast<const f32x4*>(ok ? reinterpret_cast<const YT*>(p.res) + (size_t)row * p.ldr + col : zero);
-      if (p.accumulate) d.old = *reinterpret_cast<const f32x4*>(ok ? reinterpret_cast<const YT*>(p.y) + (size_t)row * p.ldy + col : zero);
-      if (p.bs_partial) d.by = *reinterpret_cast<const f32x4*>(ok ? reinterpret_cast<const YT*>(p.bs_y) + (size_t)row * p.bs_ldy + col : zero);
-      const size_t mi = (size_t)row * (p.ncols >> 2) + (col >> 2);
-      if (p.res_mbits) d.rm = *reinterpret_cast<const MT*>(ok ? p.res_mbits + mi : zb);
-      if (p.bs_mbits) d.bm = *reinterpret_cast<const MT*>(ok ? p.bs_mbits + mi : zb);
+      const YT* rsrc = reinterpret_cast<const YT*>(p.accumulate ? p.y : p.res);
+      const int ldro = p.accumulate ? p.ldy : p.ldr;
+      d.rm = 0u;
+      d.bm = 0u;
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int row = e_m0 + e_issue * 16 + rip + 8 * n;
+        const bool ok = row < p.M && col < p.ncols;
+        if (rsrc) d.ro[n] = *reinterpret_cast<const f32x4*>(ok ? rsrc + (size_t)row * ldro + col : zero);
+        if (p.bs_partial) d.by[n] = *reinterpret_cast<const f32x4*>(ok ? reinterpret_cast<const YT*>(p.bs_y) + (size_t)row * p.bs_ldy + col : zero);
+        const size_t mi = (size_t)row * (p.ncols >> 2) + (col >> 2);
+        if (p.res_mbits) d.rm |= (unsigned)*reinterpret_cast<const MT*>(ok ? p.res_mbits + mi : zb) << (16 * n);
+        if (p.bs_mbits) d.bm |= (unsigned)*reinterpret_cast<const MT*>(ok ? p.bs_mbits + mi : zb) << (16 * n);
+      }
       ++e_issue;
+      return 1;
     };
-    auto unpack = [&](const f32x4 raw, float (&o)[EW]) {
+    auto unpack = [&](const f32x4 raw, float (&o)[CW]) {
       if constexpr (Y16) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -279,55 +295,57 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         for (int e = 0; e < 4; ++e) o[e] = raw[e];
       }
     };
-    auto epi_consume = [&](const EpiRegs& s) {   // finish pass e_cons (if requested): LDS tile + operands -> y rows, column sums
-      if (e_cons >= e_issue) return;
-      const int rloc = e_cons * RPW + rip;
-      const int row = e_m0 + rloc, col = e_n0 + ecol;
-      const bool ok = row < p.M && col < p.ncols;
-      const float* ct = reinterpret_cast<const float*>(dsm + OFF_EP) + rloc * PW_LDC + ecol;
-      float v[EW], t[EW];
+    auto epi_consume = [&](const EpiRegs& s) {   // finish pass e_cons with the operands requested into `s`
+
+      const int col = e_n0 + ecol;
+      const bool have_ro = p.res != nullptr || p.accumulate;
 #pragma unroll
-      for (int e = 0; e < EW; e += 4) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(ct + e);
-        v[e] = c[0]; v[e + 1] = c[1]; v[e + 2] = c[2]; v[e + 3] = c[3];
-      }
-      if (p.res) {
-        unpack(s.res, t);
+      for (int n = 0; n < NR; ++n) {
+        const int rloc = e_cons * 16 + rip + 8 * n;
+        const int row = e_m0 + rloc;
+        const bool ok = row < p.M && col < p.ncols;
+        const float* ct = reinterpret_cast<const float*>(dsm + OFF_EP) + rloc * PW_LDC + ecol;
+        float v[CW], t[CW];
 #pragma unroll
-        for (int e = 0; e < EW; ++e) v[e] += (!p.res_mbits || ((s.rm >> e) & 1u)) ? t[e] : 0.f;
-      }
-      if (p.accumulate) {
-        unpack(s.old, t);
-#pragma unroll
-        for (int e = 0; e < EW; ++e) v[e] += t[e];
-      }
-      if constexpr (Y16) {
-        u32x4 pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
-          v[2 * e] = __uint_as_float(pk[e] << 16);              // the sums below see what the next kernel will read
-          v[2 * e + 1] = __uint_as_float(pk[e] & 0xFFFF0000u);
+        for (int e = 0; e < CW; e += 4) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(ct + e);
+          v[e] = c[0]; v[e + 1] = c[1]; v[e + 2] = c[2]; v[e + 3] = c[3];
         }
-        if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.y) + (size_t)row * p.ldy + col) = pk;
-      } else {
-        if (ok) *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = f32x4{v[0], v[1], v[2], v[3]};
-      }
-      if (p.bs_partial) {
-        unpack(s.by, t);
+        if (have_ro) {
+          unpack(s.ro[n], t);
+          const unsigned rm = p.res_mbits ? (s.rm >> (16 * n)) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int e = 0; e < EW; ++e) {
-          bool on = ok;
-          if (p.bs_mbits) on = on && ((s.bm >> e) & 1u);
-          else if (p.bs_msc) on = on && (fmaf(t[e], c_msc[e], c_msh[e]) > 0.f);
-          const float dz = on ? v[e] : 0.f;
-          bs_s[e] += dz;
-          bs_q[e] = fmaf(dz, (t[e] - c_mu[e]) * c_is[e], bs_q[e]);
+          for (int e = 0; e < CW; ++e) v[e] += ((rm >> (8 * (e >> 2) + (e & 3))) & 1u) ? t[e] : 0.f;   // one mask byte per four columns
+        }
+        if constexpr (Y16) {
+          u32x4 pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
+            v[2 * e] = __uint_as_float(pk[e] << 16);              // the sums below see what the next kernel will read
+            v[2 * e + 1] = __uint_as_float(pk[e] & 0xFFFF0000u);
+          }
+          if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.y) + (size_t)row * p.ldy + col) = pk;
+        } else {
+          if (ok) *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+        if (p.bs_partial) {
+          unpack(s.by[n], t);
+          const unsigned bm = s.bm >> (16 * n);
+#pragma unroll
+          for (int e = 0; e < CW; ++e) {
+            bool on = ok;
+            if (p.bs_mbits) on = on && ((bm >> (8 * (e >> 2) + (e & 3))) & 1u);
+            else if (p.bs_msc) on = on && (fmaf(t[e], ccol[256 + ecol + e], ccol[384 + ecol + e]) > 0.f);
+            const float dz = on ? v[e] : 0.f;
+            bs_s[e] += dz;
+            bs_q[e] = fmaf(dz, fmaf(t[e], ccol[ecol + e], ccol[128 + ecol + e]), bs_q[e]);
+          }
         }
       }
       if (++e_cons == NPASS && p.bs_partial) {   // the tile's column sums: rows live in lane bits log2(LPR) .. 5
 #pragma unroll
-        for (int e = 0; e < EW; ++e) {
+        for (int e = 0; e < CW; ++e) {
 #pragma unroll
           for (int o = LPR; o < 64; o <<= 1) {
             bs_s[e] += __shfl_xor(bs_s[e], o, 64);
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         }
         if (rip == 0 && col < p.ncols) {
 #pragma unroll
-          for (int e = 0; e < EW; ++e) {
+          for (int e = 0; e < CW; ++e) {
             p.bs_partial[((size_t)e_mt * 2 + 0) * p.ncols + col + e] = bs_s[e];
             p.bs_partial[((size_t)e_mt * 2 + 1) * p.ncols + col + e] = bs_q[e];
           }
@@ -345,7 +363,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     };
     // passes per interval: the epilogue of a tile is requested in intervals 1 .. NK - 4 of the following tile (its LDS tile is
     // complete after the first barrier of that tile and is overwritten after the last) and finished three intervals later
-    const int ppi = LEPI ? (NPASS + (NK - 4) - 1) / (NK - 4) : 0;   // <= 2 (launch_pw: NK >= 8)
+    constexpr int PPI_MAX = Y16 ? 2 : 1;
+    const int ppi = LEPI ? (NPASS + (NK - 4) - 1) / (NK - 4) : 0;   // <= PPI_MAX (pw_lepi_ok: NK >= 8 with bf16 tensors, >= 12 with fp32)
 
     // prologue: step 0 in stage 0; steps 1, 2, 3 requested into register sets 1, 2, 0
     setup_tile(first);
@@ -368,12 +387,13 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         if constexpr (LEPI) {
           // (register set (r + 1) % 3: what was requested three intervals ago is finished now, then re-requested)
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-            if (q < ppi) epi_consume(ebuf[(r + 1) % 3][q]);
+          for (int q = 0; q < PPI_MAX; ++q)
+            if (q < npend[(r + 1) % 3]) epi_consume(ebuf[(r + 1) % 3][q]);
+          npend[(r + 1) % 3] = 0;
           if (kloc == 1 && tdone >= 1 && i < S) epi_begin(first + (tdone - 1) * G);
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-            if (q < ppi) epi_issue(ebuf[(r + 1) % 3][q]);
+          for (int q = 0; q < PPI_MAX; ++q)
+            if (q < ppi) npend[(r + 1) % 3] += epi_issue(ebuf[(r + 1) % 3][q]);
           if (++kloc == NK) {
             kloc = 0;
             ++tdone;
@@ -393,17 +413,18 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
       // passes still in flight belong to the second-to-last tile only if the padding intervals did not drain them: finish them,
       // then the last tile (its LDS tile is complete after the barrier below), two passes at a time
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+      for (int r = 1; r < 4; ++r)     // (issue order of the register sets: 1, 2, 0)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          if (q < ppi) epi_consume(ebuf[r][q]);
+        for (int q = 0; q < PPI_MAX; ++q)
+          if (q < npend[r % 3]) epi_consume(ebuf[r % 3][q]);
       __builtin_amdgcn_s_barrier();   // X: the consumers have written the last tile
       epi_begin(first + (nmine - 1) * G);
-      for (int t = 0; t < NPASS; t += 2) {
-        epi_issue(ebuf[0][0]);
-        epi_issue(ebuf[0][1]);
-        epi_consume(ebuf[0][0]);
-        epi_consume(ebuf[0][1]);
+      for (int t = 0; t < NPASS; t += 3) {   // three passes in flight (the register sets of the pipelined form)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) npend[r] = epi_issue(ebuf[r][0]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (npend[r]) epi_consume(ebuf[r][0]);
       }
     }
   } else {
@@ -567,7 +588,7 @@ bool pw_geom_ok(const ConvArgs& a, int bm) {
 // loading epilogues: the producers' form (LEPI) -- 128-row tiles, >= 8 K steps per tile, vector-aligned tensors
 bool pw_lepi_ok(const ConvArgs& a, int bm) {
   const int ew = a.y_bf16 ? 8 : 4;
-  if (bm != 128 || (a.cin_pad >> 5) < 8 || a.stat_partial || a.scale || a.shift || a.act || a.in_scale) return false;
+  if (bm != 128 || (a.cin_pad >> 5) < (a.y_bf16 ? 8 : 12) || (a.res && a.accumulate) || a.stat_partial || a.scale || a.shift || a.act || a.in_scale) return false;
   if ((a.ncols % ew) || (a.ldy % ew) || (a.res && (a.ldr % ew)) || (a.bs_partial && (a.bs_ldy % ew))) return false;
   if (a.bs_partial && (!a.bs_y || !a.bs_mean || !a.bs_istd)) return false;
   if (a.res_mbits && !a.res) return false;

@@ -22,6 +22,9 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # of this network launch fewer workgroups than the 256 CUs can hold, so the wgrad kernels run on a second HIP stream
 # next to the dgrad / BatchNorm chain; the main stream joins it once, at the end of backward.
 WGRAD_SIDE_STREAM = True
+# Side streams inside a hipGraph capture (GraphedStep): the side stream joins the capture through its wait on the capturing stream
+# and is joined back by the end-of-backward callback, so the captured graph keeps the dgrad / wgrad overlap of the eager step.
+CAPTURE_SIDE_STREAMS = os.environ.get("ZS3_CAPTURE_SIDE", "1") == "1"
 FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
 DROPOUT_FUSED = os.environ.get("ZS3_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind conv+BN+ReLU inside the BN-apply pass
 # BN-apply + ReLU in the sole consumer's operand path (conv_bn_act: next_conv).  Same-box A/B, ms per step: off 46.64 / 46.87, on
@@ -451,7 +454,8 @@ class _ConvBnAct(torch.autograd.Function):
                 dskip = dz
             dx = dskip
         if need_w:
-            side = wgrad_stream(dy.device) if (WGRAD_SIDE_STREAM and geom is None and not torch.cuda.is_current_stream_capturing()) else None
+            side = wgrad_stream(dy.device) if (WGRAD_SIDE_STREAM and geom is None and (
+                CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())) else None
             if side is not None:
                 main = torch.cuda.current_stream()
                 side.wait_stream(main)          # dy (and x) are ready on the main stream
@@ -506,7 +510,7 @@ def _applies_in_affine(x, wp, stride, pad, dil, prec, bn, residual, need_grad):
     if hit is None:
         ho, wo = ops.conv_out_size(h, wp.kh, stride, pad, dil), ops.conv_out_size(w_, wp.kw, stride, pad, dil)
         tile = ops._choose_tile(0, x.shape, n * ho * wo, ho, wo, wp.cin_pad, min(ops._round_up(wp.cin, 4), ldx), ldx, wp.kh, wp.kw,
-                                stride, pad, pad, dil, wp.cout, False, prec, store_only)
+                                stride, pad, pad, dil, wp.cout, False, prec, 1 if store_only else 0)
         hit = tile in (41, 42, 51, 52) and (not need_grad or ops._wgrad_plan(
             n, h, w_, ho, wo, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout, wp.cin)[0] in ("strip", "pw"))
         _in_affine_choice[key] = hit

@@ -86,7 +86,7 @@ class ASPP(nn.Module):
             p = self.global_avg_pool[1].forward_nhwc(Fz.global_avg_pool(xs[4]), bn, act=Fz.ACT_RELU)   # [N,1,1,256]
             return Fz.broadcast_to(p, (h, w), out=cat[..., 1024:1280])
 
-        concurrent = x.is_cuda and not torch.cuda.is_current_stream_capturing()
+        concurrent = x.is_cuda and (Fz.CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())
         if not concurrent:
             parts = [branch(0), branch(1), branch(2), branch(3), pooled()]
         else:

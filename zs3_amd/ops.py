@@ -21,6 +21,12 @@ PROFILE_SAMPLE = None  # optional [stride, phase, counter]: record every stride-
 WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"   # strip-resident weight gradient of the 3x3 stride-1 layers
 PW = os.environ.get("ZS3_PW", "1") == "1"                      # persistent pointwise kernel for the 1x1 stride-1 layers
 PW_FORCE = int(os.environ.get("ZS3_PW_FORCE", "0"))           # 51 / 52: every eligible 1x1 layer on that tile (A/B runs)
+# fp32 storage: 1x1 data gradients with loading epilogues on the persistent kernel, its producer waves running the epilogue (round 4).
+# Correct (tests/test_gpu_ops.py) and OFF: same-box A/B, ms per step, 46.97 / 47.07 without, 48.31 / 48.57 with; isolated 256 -> 1024
+# dgrad 88 us against 62 (tools/probe/r4g.sh, r4h.sh): 274 tiles of 128 x 128 on 256 persistent workgroups leave most workgroups ONE tile,
+# whose epilogue nothing overlaps.
+PW_LEPI = os.environ.get("ZS3_PW_LEPI", "0") == "1"
+PW_LEPI_MINK = int(os.environ.get("ZS3_PW_LEPI_MINK", "384")) # ... from this reduction length on (>= 384: 12 K steps per tile)
 WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"         # producer-split weight gradient of the 1x1 stride-1 layers
 HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
 
@@ -250,13 +256,17 @@ def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, s
                               prec, pw_epilogue, io)
     if prec == 0:   # exact fp32 (test mode): register-staged kernel only
         return tile_cfg if 0 < tile_cfg <= 14 else (14 if ncols <= 64 or ((m + 127) // 128) * ((ncols + 127) // 128) < 1000 else 11)
-    if tile_cfg in (51, 52) and not (pw_epilogue and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
-                                                           pad_w, tile_cfg)):
+    lepi_ok = pw_epilogue == 2 and tile_cfg == 52 and cin_pad >= 384 and ncols % 4 == 0
+    if tile_cfg in (51, 52) and not ((pw_epilogue == 1 or lepi_ok) and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
+                                                                        pad_w, tile_cfg)):
         tile_cfg = 0               # not a 1x1 stride-1 layer, or an epilogue the persistent kernel leaves to the others
-    if tile_cfg == 0 and PW and kh * kw == 1 and pw_epilogue:
+    if tile_cfg == 0 and PW and kh * kw == 1 and pw_epilogue == 1:
         cand = pick_pw_tile(m, ncols, min(cin_pad, cin_valid))
         if cand and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, cand):
             tile_cfg = cand
+    if tile_cfg == 0 and PW and PW_LEPI and kh * kw == 1 and pw_epilogue == 2 and m >= 8192 and ncols >= 128 and ncols % 4 == 0 and \
+            cin_pad >= PW_LEPI_MINK and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, 52):
+        tile_cfg = 52      # data-gradient launches with a loading epilogue: the producers run it (conv_pw.hip, LEPI)
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
         if HALO and tile_cfg == 31 and kh * kw > 1:
@@ -272,9 +282,13 @@ def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, s
     return tile_cfg
 
 
-PW16 = os.environ.get("ZS3_PW16", "1") == "1"        # persistent pointwise kernel on bf16-stored tensors
+# persistent pointwise kernel on bf16-stored tensors (A16 producers, DPP-packed bf16 stores): correct and OFF -- with 64-channel K
+# steps the register-staged kernel is the faster one for plain-bf16 1x1 layers (same-box A/B: 32.80 / 32.81 ms per step with the
+# persistent kernel, 32.25 / 32.23 without; tools/probe/r4i.sh): eight MFMAs per wave and barrier leave its K loop latency-bound
+PW16 = os.environ.get("ZS3_PW16", "0") == "1"
 HALO16 = os.environ.get("ZS3_HALO16", "1") == "1"    # strip-resident kernel on bf16-stored tensors
-PW16_LOAD_EPI = os.environ.get("ZS3_PW16_EPI", "1") == "1"   # ... including the data-gradient launches whose epilogue loads per element
+PW16_LOAD_EPI = os.environ.get("ZS3_PW16_EPI", "0") == "1"   # ... including the data-gradient launches whose epilogue loads per element (OFF: 35.3-35.6 ms per step with, 34.0-34.4 without)
+PW16_EPI_MINK = int(os.environ.get("ZS3_PW16_EPI_MINK", "256"))   # ... from this reduction length on (>= 256: 8 K steps per tile)
 
 
 def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec,
@@ -284,11 +298,14 @@ def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw,
     and the register-staged kernel takes everything else."""
     x16 = bool(io & 1)
     vec8 = ldx % 8 == 0 and cin_valid % 8 == 0
+    # 1x1 launches on the persistent kernel: store-only epilogues, or -- both sides bf16, >= 8 K steps per tile -- a loading one
+    pw_able = PW16_CAPABLE and (not x16 or vec8) and ncols % 2 == 0 and (
+        pw_epilogue == 1 or (pw_epilogue == 2 and PW16_LOAD_EPI and io == 3 and cin_pad >= PW16_EPI_MINK and ncols % 8 == 0 and
+                             tile_cfg in (0, 52)))
     if tile_cfg in (41, 42) and not (kh * kw == 9 and (not x16 or (vec8 and prec == 1)) and halo_ok(
             xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg)):
         tile_cfg = 0
-    if tile_cfg in (51, 52) and not (PW16_CAPABLE and (pw_epilogue or PW16_LOAD_EPI) and (not x16 or vec8) and ncols % 2 == 0 and pw_ok(
-            xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, tile_cfg)):
+    if tile_cfg in (51, 52) and not (pw_able and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, tile_cfg)):
         tile_cfg = 0
     if tile_cfg == 31:
         tile_cfg = 0
@@ -299,15 +316,15 @@ def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw,
         for c in (cand, 42 if cand == 41 else 41):
             if halo_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, c):
                 return c
-    if PW16 and PW16_CAPABLE and kh * kw == 1 and (pw_epilogue or PW16_LOAD_EPI) and m >= 8192 and ncols >= 128 and ncols % 2 == 0 and \
-            (not x16 or vec8) and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, 52):
+    if PW16 and pw_able and kh * kw == 1 and m >= 8192 and ncols >= 128 and \
+            pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, 52):
         return 52
     if ncols <= 64:
         return 14
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 512 else 14
 
 
-PW16_CAPABLE = False   # set once conv_pw.hip serves bf16-stored tensors (this build: see zs3_conv_pw_caps)
+PW16_CAPABLE = True    # conv_pw.hip serves bf16-stored tensors (A16 producers, bf16 direct stores, the producers' loading epilogue)
 
 
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
@@ -332,13 +349,16 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if io & 1 and prec != 1:
         raise ValueError("a bf16-stored input needs plain-bf16 products (prec = 1)")
     m = n * ho * wo
-    pw_epilogue = res is None and not accumulate and bn_bwd is None and res_mask_bits is None   # no per-element loads
+    # 1: store-only epilogue (no per-element loads); 2: a loading epilogue the persistent pointwise kernel's producer waves can run
+    # (residual OR accumulate, the fused BatchNorm-backward sums; no affine / activation / forward statistics); 0: neither
+    pw_epilogue = 1 if (res is None and not accumulate and bn_bwd is None and res_mask_bits is None) else (
+        2 if (scale is None and shift is None and act == 0 and not want_stats and not (res is not None and accumulate)) else 0)
     # the kernel / tile choice depends on the launch geometry only: decided once per distinct launch (a training step repeats
     # ~60 geometries 230 times; the eligibility questions below are C calls)
     if tile_cfg in (141, 142):      # round-3 spelling of "tile_cfg 41 / 42 on a bf16-stored input"
         tile_cfg -= 100
     key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
-           HALO, HALO_BM, PW, PW_FORCE, io, PW16, HALO16, PW16_LOAD_EPI, PW16_CAPABLE)
+           HALO, HALO_BM, PW, PW_FORCE, io, PW16, HALO16, PW16_LOAD_EPI, PW16_CAPABLE, PW_LEPI, PW_LEPI_MINK, PW16_EPI_MINK)
     cached = _TILE_CHOICE.get(key)
     if cached is not None:
         tile_cfg = cached
