@@ -62,6 +62,10 @@ def parse():
                          "`image.cuda(), target.cuda()` does, base_trainer.py:13): the copy of step i+1 is queued on a copy stream "
                          "while step i computes.  Not the headline number (that one has its inputs resident in HBM); DESIGN.md "
                          "section 7 quotes this PCIe-inclusive rate")
+    ap.add_argument("--read-loss", type=int, default=1,
+                    help="1 (default): every timed step's loss value is read on the host, one step behind (what BaseTrainer does); 0: never")
+    ap.add_argument("--bf16-steps", type=int, default=10,
+                    help="timed steps of the 2-byte mode reported as the `bf16` object of the default line; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -170,7 +174,15 @@ def main():
         loss = crit(out, lab)
         loss.backward()
         opt.step()
+        # the trainer reads the loss of every iteration (zs3_amd/base_trainer.py; the reference: base_trainer.py:21,24).  Read the way
+        # the trainer reads it: copied to pinned host memory behind the step, looked at one iteration later -- every value is read,
+        # no step waits for its own
+        if loss_log is not None:
+            loss_log.push(loss)
         return loss
+
+    from zs3_amd.base_trainer import LossLog
+    loss_log = LossLog(dev) if args.read_loss else None
 
     def run(step, steps, warmup):
         for i in range(warmup):
@@ -253,51 +265,72 @@ def main():
                                                  "'boundary' row: eager = hipGraph); the per-update figure also carries the "
                                                  "classifier's CE / SGD launches of the step"}}}
 
+    def measure_supervised(steps, warmup, roofline):
+        """warm-up + timed supervised steps -> (seconds, last loss, event records of the timed steps, of the last warm-up step,
+        instrumented step count)"""
+        if not roofline:
+            dt, last = run(supervised_step, steps, warmup)
+            return dt, last, [], [], 0
+        # warm-up steps: HIP events around every conv launch (per-kernel table, picks the dominant kernel);
+        # timed steps: events around the dominant kernel's launches only -- an event pair is a kernel boundary the
+        # GPU cannot overlap, and 450 of them per step cost ~3 % of the step
+        ops.PROFILE = []
+        for i in range(warmup):
+            if i == warmup - 1:
+                ops.PROFILE = []
+            supervised_step(i)
+        warm_prof = ops.PROFILE
+        torch.cuda.synchronize()
+        by_cfg = {}
+        for tag, flops, e0, e1, cfg in warm_prof:
+            by_cfg[cfg] = by_cfg.get(cfg, 0.0) + e0.elapsed_time(e1)
+        for group in ({41, 42},):      # both tile heights of the strip-resident kernel are one kernel
+            tot = sum(by_cfg.pop(c, 0.0) for c in group)
+            if tot:
+                by_cfg[min(group)] = tot
+        best = max(by_cfg, key=by_cfg.get) if by_cfg else None
+        ops.PROFILE_CFGS = ({41, 42} if best == 41 else {best}) if best is not None else None
+        timed_prof = []
+
+        def instrument(i):
+            return i % 5 == 4 or (steps < 5 and i == steps - 1)
+
+        STRIDE = 4     # ... and in such a step every 4th launch of the dominant kernel, the phase rotating from one
+        nth = [0]      # instrumented step to the next: 127 launches per step, so four instrumented steps cover each
+                       # launch exactly once.  (An event pair is ~50-100 us of host time and a kernel boundary the
+                       # GPU cannot overlap: 127 pairs in a step made that step ~25 ms longer.)
+
+        def sampled_step(i):
+            if instrument(i):
+                ops.PROFILE = timed_prof
+                ops.PROFILE_SAMPLE = [STRIDE, nth[0] % STRIDE, -1]
+                nth[0] += 1
+            else:
+                ops.PROFILE, ops.PROFILE_SAMPLE = None, None
+            return supervised_step(i)
+        dt, last = run(sampled_step, steps, 0)
+        ops.PROFILE, ops.PROFILE_CFGS, ops.PROFILE_SAMPLE = None, None, None
+        return dt, last, timed_prof, warm_prof, sum(1 for i in range(steps) if instrument(i))
+
+    bf16_info = None
     if args.workload == "supervised":
-        if not args.no_roofline:
-            # warm-up steps: HIP events around every conv launch (per-kernel table, picks the dominant kernel);
-            # timed steps: events around the dominant kernel's launches only -- an event pair is a kernel boundary the
-            # GPU cannot overlap, and 450 of them per step cost ~3 % of the step
-            ops.PROFILE = []
-            for i in range(args.warmup):
-                if i == args.warmup - 1:
-                    ops.PROFILE = []
-                supervised_step(i)
-            warm_prof = ops.PROFILE
-            torch.cuda.synchronize()
-            by_cfg = {}
-            for tag, flops, e0, e1, cfg in warm_prof:
-                by_cfg[cfg] = by_cfg.get(cfg, 0.0) + e0.elapsed_time(e1)
-            for group in ({41, 42},):      # both tile heights of the strip-resident kernel are one kernel
-                tot = sum(by_cfg.pop(c, 0.0) for c in group)
-                if tot:
-                    by_cfg[min(group)] = tot
-            best = max(by_cfg, key=by_cfg.get) if by_cfg else None
-            ops.PROFILE_CFGS = ({41, 42} if best == 41 else {best}) if best is not None else None
-            timed_prof = []
-
-            def instrument(i):
-                return i % 5 == 4 or (args.steps < 5 and i == args.steps - 1)
-
-            STRIDE = 4     # ... and in such a step every 4th launch of the dominant kernel, the phase rotating from one
-            nth = [0]      # instrumented step to the next: 127 launches per step, so four instrumented steps cover each
-                           # launch exactly once.  (An event pair is ~50-100 us of host time and a kernel boundary the
-                           # GPU cannot overlap: 127 pairs in a step made that step ~25 ms longer.)
-
-            def sampled_step(i):
-                if instrument(i):
-                    ops.PROFILE = timed_prof
-                    ops.PROFILE_SAMPLE = [STRIDE, nth[0] % STRIDE, -1]
-                    nth[0] += 1
-                else:
-                    ops.PROFILE, ops.PROFILE_SAMPLE = None, None
-                return supervised_step(i)
-            dt, last = run(sampled_step, args.steps, 0)
-            prof, ops.PROFILE, ops.PROFILE_CFGS, ops.PROFILE_SAMPLE = timed_prof, None, None, None
-            instrumented = sum(1 for i in range(args.steps) if instrument(i))
-        else:
-            dt, last = run(supervised_step, args.steps, args.warmup)
-            prof, warm_prof = [], []
+        dt, last, prof, warm_prof, instrumented = measure_supervised(args.steps, args.warmup, not args.no_roofline)
+        if args.bf16_steps > 0 and world == 1 and args.dtype == "bf16x3":
+            # the 2-byte mode (BASELINE configs[4] "bf16"; VERDICT r3 #2) on the same model, optimizer and batch: activations and
+            # inter-layer gradients stored as bf16, plain bf16 products
+            prev_prec = ops.PREC_DEFAULT
+            ops.set_storage(torch.bfloat16)
+            bdt, _, bprof, bwarm, binst = measure_supervised(args.bf16_steps, 3, not args.no_roofline)
+            ops.set_storage(torch.float32)
+            ops.PREC_DEFAULT = prev_prec
+            bval = args.batch * args.bf16_steps / bdt
+            bf16_info = {"value": bval, "unit": "images/sec", "ms_per_step": 1e3 * bdt / args.bf16_steps, "steps": args.bf16_steps,
+                         "warmup": 3, "dtype": DTYPE_NOTE["bf16"],
+                         "workload": "the supervised step of `value` (same model, optimizer, batch) in the 2-byte mode",
+                         "model_tflops": bval * TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7) / 1e3,
+                         "model_frac_of_bf16_peak": bval * TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7) / 1e3 / PEAK_BF16_TF}
+            if bprof:
+                bf16_info["roofline"] = roofline_of(bprof, bwarm, binst, "bf16")
         gflop_img = TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7)
         sync = getattr(model, "_zs3_grad_sync", None)      # armed by the model's first training forward when world > 1
         sync_bytes = sync.bytes_reduced if sync is not None else None
@@ -307,7 +340,7 @@ def main():
             gmmn_info = gmmn_report(build_gmmn(), args.gmmn_steps)
     else:
         gstep = build_gmmn()
-        prof, warm_prof = [], []
+        prof, warm_prof, instrumented = [], [], 0
         dt, last = run(gstep, args.steps, args.warmup)
         gflop_img = 193.5
 
@@ -334,39 +367,10 @@ def main():
         result["rccl_bytes_per_rank_per_step"] = sync_bytes // max(1, args.steps + args.warmup)
     if gmmn_info:
         result["gmmn"] = gmmn_info
+    if bf16_info:
+        result["bf16"] = bf16_info
     if rank == 0 and prof:
-        torch.cuda.synchronize()
-        def aggregate(records):
-            agg = {}
-            for tag, flops, e0, e1, _cfg in records:
-                a = agg.setdefault(tag, [0, 0.0, 0.0])
-                a[0] += 1
-                a[1] += flops
-                a[2] += e0.elapsed_time(e1) * 1e-3
-            return agg
-        agg, warm = aggregate(prof), aggregate(warm_prof)
-        # the strip-resident kernel is ONE source kernel (csrc/conv_halo.hip) in several template instantiations (tile height,
-        # strip passes per step): the roofline prices the family, `instantiations` lists each under its rocprof name
-        fam = {k: v for k, v in agg.items() if k.startswith("conv_halo_kernel<")}
-        if fam:
-            agg = {k: v for k, v in agg.items() if k not in fam}
-            agg["conv_halo<%d>" % (3 if args.dtype == "bf16x3" else 1)] = [sum(v[i] for v in fam.values()) for i in range(3)]
-        tag = max(agg, key=lambda k: agg[k][2])
-        n, fl, sec = agg[tag]
-        ach = fl / sec / 1e12
-        traffic, traffic_src = pmc_traffic(tag)
-        result["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TF,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
-            "instrumented_timed_steps": instrumented,
-            "instantiations": ({k: {"launches": v[0], "avg_launch_us": 1e6 * v[2] / v[0], "tflops": v[1] / v[2] / 1e12}
-                                for k, v in sorted(fam.items())} if fam and tag.startswith("conv_halo<") else None),
-            "note": "achieved = algorithmic 2*M*N*K flops of the sampled launches / their HIP-event time (events around every "
-                    "4th launch of this kernel, rotating phase, in every 5th timed step)" + ("; each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation "
-                    "is 3x this fraction" if args.dtype == "bf16x3" else "; one bf16 MFMA per product"),
-            "all_conv_igemm_last_warmup_step": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms": 1e3 * v[2]}
-                                                for k, v in warm.items()},
-        }
+        result["roofline"] = roofline_of(prof, warm_prof, instrumented, args.dtype)
     if cpu_info is not None:
         result["cpu_baseline"] = cpu_info
     if rank == 0:
@@ -375,12 +379,50 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(tag):
+
+def roofline_of(prof, warm_prof, instrumented, dtype):
+    """`roofline` object of one measured configuration: the dominant conv kernel's algorithmic flops / HIP-event time inside the
+    timed steps against the dense bf16 MFMA peak, with the HBM bytes per launch from the committed rocprofv3 PMC passes"""
+    torch.cuda.synchronize()
+
+    def aggregate(records):
+        agg = {}
+        for tag, flops, e0, e1, _cfg in records:
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += e0.elapsed_time(e1) * 1e-3
+        return agg
+    agg, warm = aggregate(prof), aggregate(warm_prof)
+    # the strip-resident kernel is ONE source kernel (csrc/conv_halo.hip) in several template instantiations (tile height,
+    # strip passes per step): the roofline prices the family, `instantiations` lists each under its rocprof name
+    fam = {k: v for k, v in agg.items() if k.startswith("conv_halo_kernel<")}
+    if fam:
+        agg = {k: v for k, v in agg.items() if k not in fam}
+        agg["conv_halo<%d>" % (3 if dtype == "bf16x3" else 1)] = [sum(v[i] for v in fam.values()) for i in range(3)]
+    tag = max(agg, key=lambda k: agg[k][2])
+    n, fl, sec = agg[tag]
+    ach = fl / sec / 1e12
+    traffic, traffic_src = pmc_traffic(tag, "bf16" if dtype == "bf16" else "")
+    return {
+        "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TF, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TF,
+        "traffic": traffic, "traffic_source": traffic_src, "kernel": tag, "launches": n, "avg_launch_us": 1e6 * sec / n,
+        "instrumented_timed_steps": instrumented,
+        "instantiations": ({k: {"launches": v[0], "avg_launch_us": 1e6 * v[2] / v[0], "tflops": v[1] / v[2] / 1e12}
+                            for k, v in sorted(fam.items())} if fam and tag.startswith("conv_halo<") else None),
+        "note": "achieved = algorithmic 2*M*N*K flops of the sampled launches / their HIP-event time (events around every "
+                "4th launch of this kernel, rotating phase, in every 5th timed step)" + ("; each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation "
+                "is 3x this fraction" if dtype == "bf16x3" else "; one bf16 MFMA per product"),
+        "all_conv_igemm_last_warmup_step": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms": 1e3 * v[2]}
+                                            for k, v in warm.items()},
+    }
+
+def pmc_traffic(tag, variant=""):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/r1_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled per the
     gfx950 note of MI355X_MICROARCH.md).  PMC collection cannot run inside the timed process, hence the file."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic%s.json" % ("_" + variant if variant else ""))))
     if not found:
         return None, None
     path = found[-1]            # the latest round's passes

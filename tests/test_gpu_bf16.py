@@ -157,8 +157,11 @@ def test_train_step_bf16_close_to_bf16x3(dev, bf16_mode):
         assert e < 0.3, (k, e)
 
 
-def test_gcn_context_step_60_classes_bf16(dev, bf16_mode):
-    """BASELINE configs[4] as stated: train_context_GMMN_GCNcontext.py's step on the 60-class Pascal-Context head with the
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_gcn_context_step_60_classes_bf16(dev, bf16_mode, storage):
+    """(storage = "bf16": the 2-byte mode -- activations of the frozen feature pass stored as bf16, cast once to fp32 where the
+    generator loop takes over; storage = "fp32": plain-bf16 products on fp32 tensors, the rounds 2-3 form.)
+    BASELINE configs[4] as stated: train_context_GMMN_GCNcontext.py's step on the 60-class Pascal-Context head with the
     convolutions in bf16 (frozen feature pass, generator and graph-generator updates, cluster CE).  Checked against the
     oracle's fp32 step at bf16 tolerance: features feed the MMD losses, so the generator losses move by O(1e-2)."""
     import zs3_oracle as zo
@@ -167,8 +170,11 @@ def test_gcn_context_step_60_classes_bf16(dev, bf16_mode):
     from zs3_amd.modeling.gmmn import GMMNnetwork, GMMNnetwork_GCN
     from zs3_amd.optim import SGD, Adam
     from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd import ops
     classes, unseen = 60, [5, 17]
     seen = [c for c in range(classes) if c not in unseen]
+    if storage == "bf16":
+        ops.set_storage(torch.bfloat16)
     torch.manual_seed(1)
     m = DeepLab(num_classes=classes, pretrained=False, global_avg_pool_bn=False)
     for name, mod in m.named_modules():
@@ -205,17 +211,24 @@ def test_gcn_context_step_60_classes_bf16(dev, bf16_mode):
                                             b["image"], b["label"], b["label_emb"], seen=seen, unseen=unseen,
                                             gcn_weight=0.1, gcn_avg_feat=False, context_aware=False)
     torch.manual_seed(41)
-    gl, gcl, cl, out = step(b["image"].to(dev), b["label"].to(dev), b["label_emb"].to(dev))
-    print("bf16 gcn-context 60 classes:", (gl, gl_r), (gcl, gcl_r), (cl, cl_r))
+    try:
+        gl, gcl, cl, out = step(b["image"].to(dev), b["label"].to(dev), b["label_emb"].to(dev))
+    finally:
+        ops.set_storage(torch.float32)
+    print(f"bf16 gcn-context 60 classes ({storage} storage):", (gl, gl_r), (gcl, gcl_r), (cl, cl_r))
     assert out.shape == (4, classes, 65, 65) and step.last_num_clusters > 100
-    assert abs(gl - gl_r) < 3e-2 * abs(gl_r) and abs(gcl - gcl_r) < 3e-2 * abs(gcl_r) and abs(cl - cl_r) < 3e-2 * abs(cl_r)
+    # (bf16 storage: the classifier's CE sees features that carry the 2-byte mode's few-percent noise -- test_gpu_bf16_storage.py:
+    # class scores 6.5e-2 relative L2 on a randomly initialised network -- delivered 1.5-3.3e-2 on the loss; the generator losses,
+    # which compare distributions, stay within 1e-3)
+    assert abs(gl - gl_r) < 3e-2 * abs(gl_r) and abs(gcl - gcl_r) < 3e-2 * abs(gcl_r)
+    assert abs(cl - cl_r) < (8e-2 if storage == "bf16" else 3e-2) * abs(cl_r)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("geom", [(2, 33, 33, 256, 256, 1), (1, 65, 65, 128, 128, 1), (1, 33, 33, 512, 512, 2), (1, 33, 33, 304, 256, 1),
                                   (1, 129, 129, 64, 64, 1)])
 def test_strip_kernel_reads_bf16_stored_input(geom):
-    """tile_cfg 141 / 142: the strip-resident kernel with its input STORED as bf16 (the producers copy instead of converting).
+    """tile_cfg 141 / 142 (round 3's spelling; since round 4 simply tile_cfg 41 / 42 on a bf16 tensor): the strip-resident kernel with its input STORED as bf16 (the producers copy instead of converting).
     The fp32-input kernel in plain-bf16 mode rounds the same values to the same bf16 operands and multiplies them in the same
     order, so on bf16-representable inputs the two must agree bit for bit -- forward with BN sums and the fused epilogue, and the
     data gradient with accumulation.  Anything else (fp32 storage, bf16x3, a layer the strip kernel does not serve) is refused."""
@@ -250,5 +263,9 @@ def test_strip_kernel_reads_bf16_stored_input(geom):
     assert ran >= 1
     with pytest.raises(ValueError):
         ops.conv2d_fwd(xb, wp, 1, d, d, tile_cfg=141, prec=3)          # bf16x3 needs the fp32 values
-    with pytest.raises(ValueError):
-        ops.conv2d_fwd(xb, wp, 1, d, d, tile_cfg=41, prec=1)           # the fp32-input kernels do not read bf16 storage
+    # round 4: the element type travels with the tensor (`io` argument), so tile_cfg 41 on a bf16-stored input IS the same launch
+    ya, _ = ops.conv2d_fwd(xb, wp, 1, d, d, tile_cfg=41 if ops.halo_ok(xb.shape, h, w, wp.cin_pad, min(ops._round_up(ci, 4), ops._check_nhwc(xb)),
+                                                                      ops._check_nhwc(xb), 3, 3, 1, d, d, d, False, 1, 41) else 42, prec=1)
+    yb, _ = ops.conv2d_fwd(xb.float(), wp, 1, d, d, prec=1, tile_cfg=41 if ops.halo_ok(
+        xb.shape, h, w, wp.cin_pad, min(ops._round_up(ci, 4), ops._check_nhwc(xb)), ops._check_nhwc(xb), 3, 3, 1, d, d, d, False, 1, 41) else 42)
+    assert torch.equal(ya, yb)

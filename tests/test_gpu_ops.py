@@ -1028,6 +1028,9 @@ def test_pointwise_kernel_runs_loading_epilogues_in_its_producer_waves(dev, stor
     skipg = rnd(n, h, w, cols)
     sbits = torch.randint(0, 256, (n * h * w * cols // 4,), device=dev, generator=g, dtype=torch.uint8)
     prev_storage, prev_prec = ops.ACT_DTYPE, ops.PREC_DEFAULT
+    prev_flags = (ops.PW_LEPI, ops.PW16_LOAD_EPI)
+    ops.PW_LEPI = ops.PW16_LOAD_EPI = True      # off by default (slower inside the step: ops.py); the path stays tested
+    ops._TILE_CHOICE.clear()
     if bf:
         ops.set_storage(torch.bfloat16)
     old = lib().zs3_conv_pw_set_wgs(wgs)
@@ -1049,6 +1052,8 @@ def test_pointwise_kernel_runs_loading_epilogues_in_its_producer_waves(dev, stor
         assert ops._TILE_CHOICE and any(v == 52 for v in ops._TILE_CHOICE.values()), "tile_cfg 52 was not honoured for this launch"
     finally:
         lib().zs3_conv_pw_set_wgs(old)
+        ops.PW_LEPI, ops.PW16_LOAD_EPI = prev_flags
+        ops._TILE_CHOICE.clear()
         if bf:
             ops.set_storage(prev_storage)
             ops.PREC_DEFAULT = prev_prec

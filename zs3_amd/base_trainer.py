@@ -4,7 +4,51 @@ inject model / optimizer / criterion / scheduler / loaders / writer / summary / 
 Behaviour kept: single-sample batches are skipped (:11), the LR schedule is applied before every step (:15), the
 step is zero_grad -> forward -> loss -> backward -> step (:16-20), the scalar loss is logged per iteration (:23-25),
 an image dump happens ten times per epoch (:28-38), and with `no_val` a checkpoint is written every epoch (:46-57).
-The loss value is read back once per iteration (the reference syncs twice)."""
+Every iteration's loss value is read on the host (the reference reads it twice per iteration, each a device synchronisation,
+base_trainer.py:21,24) -- one iteration LATE: `LossLog` copies the 4 bytes to pinned memory behind the step and looks at them
+when the next step has been queued, so no step waits for its own loss and the host keeps running ahead of the GPU.  Every
+value still reaches the running sum, the progress bar and `train/total_loss_iter` under its own iteration number."""
+import torch
+
+
+class LossLog:
+    """Loss values of consecutive iterations, read without stalling the iteration that produced them: push(loss) queues an
+    asynchronous copy of the 0-dim device tensor into a pinned slot and returns the (index, value) pairs that have ARRIVED --
+    normally the previous iteration's; flush() waits for the rest."""
+
+    def __init__(self, device=None, depth=2):
+        self.depth = depth
+        self.buf = torch.zeros(depth, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(depth)
+        self.pending = []      # (index, slot, event)
+        self.count = 0
+
+    def push(self, loss):
+        out = []
+        if len(self.pending) >= self.depth - 1:      # the slot about to be reused must have been read
+            out.extend(self._take(len(self.pending) - (self.depth - 2)))
+        slot = self.count % self.depth
+        if loss.is_cuda:
+            self.buf[slot:slot + 1].copy_(loss.detach().reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            self.buf[slot] = float(loss)
+            ev = None
+        self.pending.append((self.count, slot, ev))
+        self.count += 1
+        return out
+
+    def _take(self, n):
+        got = []
+        for _ in range(n):
+            idx, slot, ev = self.pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            got.append((idx, float(self.buf[slot])))
+        return got
+
+    def flush(self):
+        return self._take(len(self.pending))
 
 
 class BaseTrainer:
@@ -21,7 +65,7 @@ class BaseTrainer:
         loss = self.criterion(prediction, target)
         loss.backward()
         self.optimizer.step()
-        return prediction, loss.item()
+        return prediction, loss
 
     def _epoch_end(self, epoch, running, seen_images):
         self.writer.add_scalar("train/total_loss_epoch", running, epoch)
@@ -44,6 +88,14 @@ class BaseTrainer:
         per_epoch = len(self.train_loader)
         dump_every = per_epoch // 10
         running, last_index, last_batch = 0.0, -1, 0
+        log, steps_of = LossLog(), {}
+
+        def account(pairs):
+            nonlocal running
+            for k, value in pairs:
+                running += value
+                self.writer.add_scalar("train/total_loss_iter", value, steps_of.pop(k))
+
         for index, sample in enumerate(iterator):
             last_index = index
             if len(sample["image"]) <= 1:
@@ -51,12 +103,13 @@ class BaseTrainer:
             image, target = self._to_device(sample)
             last_batch = image.shape[0]
             self.scheduler(self.optimizer, index, epoch, self.best_pred)
-            prediction, value = self._train_iteration(image, target)
-            running += value
+            prediction, loss = self._train_iteration(image, target)
             step = index + per_epoch * epoch
+            steps_of[log.count] = step
+            account(log.push(loss))          # (the previous iteration's value: this one's is still being computed)
             if hasattr(iterator, "set_description"):
                 iterator.set_description("Train loss: %.3f" % (running / (index + 1)))
-            self.writer.add_scalar("train/total_loss_iter", value, step)
             if index % dump_every == 0:   # ZeroDivisionError for loaders shorter than 10 batches, like the reference
                 self.summary.visualize_image(self.writer, self.args.dataset, image, target, prediction, step)
+        account(log.flush())
         self._epoch_end(epoch, running, last_index * self.args.batch_size + last_batch)

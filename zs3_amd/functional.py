@@ -24,7 +24,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 WGRAD_SIDE_STREAM = True
 # Side streams inside a hipGraph capture (GraphedStep): the side stream joins the capture through its wait on the capturing stream
 # and is joined back by the end-of-backward callback, so the captured graph keeps the dgrad / wgrad overlap of the eager step.
-CAPTURE_SIDE_STREAMS = os.environ.get("ZS3_CAPTURE_SIDE", "1") == "1"
+CAPTURE_SIDE_STREAMS = os.environ.get("ZS3_CAPTURE_SIDE", "0") == "1"   # (probe: tools/probe/graph_probe.py -- 36.2 ms with, 36.8 without for fwd + bwd in the 2-byte mode: hipGraph replay does not overlap the branches; off)
 FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
 DROPOUT_FUSED = os.environ.get("ZS3_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind conv+BN+ReLU inside the BN-apply pass
 # BN-apply + ReLU in the sole consumer's operand path (conv_bn_act: next_conv).  Same-box A/B, ms per step: off 46.64 / 46.87, on
@@ -279,7 +279,11 @@ class _ConvBnAct(torch.autograd.Function):
             # ReLU here as the stored pass the producer skipped, and carry on as if nothing had been deferred
             x = ops.affine_act(x, in_aff[0], in_aff[1], act=ACT_RELU)
             in_aff = None
-        odt = cfg.get("out_dtype")   # element type of this layer's output (None: ops.ACT_DTYPE; the class scores stay fp32)
+        # element type of this layer's output: the caller's (the class scores stay fp32), else the input's own -- the stem (fp32
+        # image in) is where the storage type ops.ACT_DTYPE enters the network, everything behind it inherits it, and the
+        # generators (nn.Linear / GraphConvolution on fp32 rows, whose kernels -- csrc/gmmn.hip, gcn.hip, the MMD loss -- and
+        # whose products-used-as-weights are fp32) stay fp32 in either mode
+        odt = cfg.get("out_dtype") or (ops.ACT_DTYPE if geom is not None else x.dtype)
         conv = (lambda **k: ops.conv2d_fwd(x, wp, stride, pad, dil, prec=prec, in_affine=in_aff, out_dtype=odt, **k)) if geom is None else (
             lambda **k: ops.conv_igemm(x, wp.f_pk, prec=prec, out_dtype=odt, **geom, **k))
         defer = bool(cfg.get("defer_out"))
@@ -547,7 +551,8 @@ def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
     cout, _, kh, kw = weight.shape if weight.dim() == 4 else (*weight.shape, 1, 1)
     oshape = (n, ops.conv_out_size(h, kh, stride, pad, dil), ops.conv_out_size(w_, kw, stride, pad, dil), cout)
     key = (oshape, tuple(next_conv.weight.shape), next_conv.stride[0], next_conv.padding[0], next_conv.dilation[0],
-           next_conv.bias is None, prec, ops.PREC_DEFAULT, ops.HALO, ops.HALO_BM, ops.PW, ops.PW_FORCE, ops.WGRAD_STRIP, ops.WGRAD_PW)
+           next_conv.bias is None, prec, ops.PREC_DEFAULT, ops.HALO, ops.HALO_BM, ops.PW, ops.PW_FORCE, ops.WGRAD_STRIP, ops.WGRAD_PW,
+           ops.ACT_DTYPE)
     hit = _defer_choice.get(key)
     if hit is None:
         nw = next_conv.weight

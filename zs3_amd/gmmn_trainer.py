@@ -426,7 +426,9 @@ class GMMNStep:
     # ------------------------------------------------------------------ frozen-backbone feature pass, pipelined
     def _features(self, image):
         with torch.no_grad():
-            return ops.nhwc(self.model.forward_before_class_prediction(image))          # [B, fh, fw, D]
+            # [B, fh, fw, D]; in the 2-byte mode the backbone hands over bf16 features: the generator loop, the MMD kernels and the
+            # cluster graphs work on fp32 rows (273 MB at B = 16: one cast pass, ~0.1 ms)
+            return ops.cast(ops.nhwc(self.model.forward_before_class_prediction(image)), torch.float32)
 
     def prefetch(self, image):
         """Start the feature pass of the NEXT batch on a side stream.  The backbone is frozen in this step (only `pred_conv`

@@ -226,6 +226,8 @@ class WeightPlanes:
 def prep_weight(w, need_t=True, cin_pad=None):
     """w: [Cout, Cin, KH, KW] parameter (any strides) or [Cout, Cin] linear weight -> bf16 hi/lo planes."""
     require_gpu(w)
+    if w.dtype != torch.float32:
+        raise TypeError(f"weights are fp32 (master copies): got {w.dtype}")
     if w.dim() == 2:
         w = w[:, :, None, None]
     cout, cin, kh, kw = w.shape
