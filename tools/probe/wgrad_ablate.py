@@ -7,6 +7,8 @@ import torch
 from zs3_amd import ops, functional as Fz
 from zs3_amd.modeling.deeplab import DeepLab
 from zs3_amd.utils.loss import SegmentationLosses
+if os.environ.get("ZS3_STORAGE") == "bf16":
+    ops.set_storage(torch.bfloat16)
 dev = torch.device("cuda:0")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 torch.manual_seed(1)

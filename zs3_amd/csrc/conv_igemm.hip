@@ -260,6 +260,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       if (more) store_tile(s0, cur ^ 1);
       __syncthreads();
     }
+  } else if (PIPE == 3) {
+    // three register stages (round 4, bf16-stored input): a tile's global loads are issued FOUR K steps before its MFMAs, and the
+    // steady state contains NO branch around a load or an LDS write: hipcc waits vmcnt(0) at the join of a branch that holds a
+    // load, which turns the two-deep prefetch of the PIPE 2 form into none at all once a K step is only
+    // 256-512 matrix-pipe cycles (plain bf16: measured 2.3 us per K step whatever the prefetch depth).  Requests past the last
+    // step re-read the last step (the step counter stops advancing; the data is never multiplied).  Step j lives in LDS stage
+    // j & 1 and travels through register set j % 3.
+    Stage s0, s1, s2;
+    int requested = 0;                       // K step of the most recent request
+    auto next_step = [&]() {                 // scalar state only: no load lives under this branch
+      if (requested + 1 < KT) {
+        advance();
+        ++requested;
+      }
+    };
+    load_tile(s0);
+    next_step();
+    load_tile(s1);
+    next_step();
+    load_tile(s2);
+    store_tile(s0, 0);
+    next_step();
+    load_tile(s0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 3 <= KT; kt += 3) {
+      compute(kt & 1);                       // step kt;     next: step kt + 1 from s1, reload s1 with step kt + 4
+      store_tile(s1, (kt + 1) & 1);
+      next_step();
+      load_tile(s1);
+      __syncthreads();
+      compute((kt + 1) & 1);                 // step kt + 1; next: step kt + 2 from s2, reload s2 with step kt + 5
+      store_tile(s2, kt & 1);
+      next_step();
+      load_tile(s2);
+      __syncthreads();
+      compute(kt & 1);                       // step kt + 2; next: step kt + 3 from s0, reload s0 with step kt + 6
+      store_tile(s0, (kt + 1) & 1);
+      next_step();
+      load_tile(s0);
+      __syncthreads();
+    }
+    if (kt < KT) {                           // one or two steps left: step kt is in LDS, step kt + 1 (if any) in s1
+      compute(kt & 1);
+      if (kt + 1 < KT) {
+        store_tile(s1, (kt + 1) & 1);
+        __syncthreads();
+        compute((kt + 1) & 1);
+      }
+    }
   } else {
     // two register stages: a tile's global loads are issued two K steps before they are written to LDS
     Stage s0, s1;
@@ -803,6 +853,16 @@ int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
   return prec == 1 ? launch_dma_prec<1>(a, grid, st) : launch_dma_prec<3>(a, grid, st);
 }
 
+// tile_cfg 11 / 14 run the three-stage branch-free prefetch loop (PIPE 3) since round 4: the two-stage loop keeps its loads under
+// `if (more steps)` branches, and hipcc waits vmcnt(0) where such a branch joins -- the ISA of the PIPE 2 kernel waits for the
+// loads it has just issued before every LDS write, i.e. no prefetch at all (tools/probe: the L / vmcnt pattern of conv_igemm.s).
+// Same-box A/B of the fp32-storage step: 46.02 / 46.03 ms with PIPE 2, 43.57 / 43.54 with PIPE 3 (tools/probe/r4n.sh).
+// ZS3_IGEMM_PIPE=2 restores the old loop.
+static bool pipe3() {
+  static const bool v = !(getenv("ZS3_IGEMM_PIPE") && atoi(getenv("ZS3_IGEMM_PIPE")) == 2);
+  return v;
+}
+
 template <int BM, int BN, int PIPE>
 int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   int mt = (a.M + BM - 1) / BM, nt = (a.ncols + BN - 1) / BN;
@@ -810,9 +870,11 @@ int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   if (a.x_bf16) {   // bf16-stored input: plain-bf16 products on the two-deep-prefetch form of the tile
     if (prec != 1) return -7;
     static const bool k64 = getenv("ZS3_IGEMM16_K64") ? atoi(getenv("ZS3_IGEMM16_K64")) != 0 : true;
-    if (k64 && (a.cin_pad & 63) == 0 && (a.cin_valid & 7) == 0 && (a.ldx & 7) == 0)
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true, 64>), grid, block, 0, st, a);
-    else
+    static const int pipe16 = getenv("ZS3_IGEMM16_PIPE") ? atoi(getenv("ZS3_IGEMM16_PIPE")) : 2;   // (3: isolated 46.5 us against 43.9 on 256 -> 1024 @33^2, in-step level: tools/probe/r4k.sh, r4m.sh)
+    if (k64 && (a.cin_pad & 63) == 0 && (a.cin_valid & 7) == 0 && (a.ldx & 7) == 0) {
+      if (pipe16 == 3) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 3, true, 64>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true, 64>), grid, block, 0, st, a);
+    } else
       hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true>), grid, block, 0, st, a);
   } else if (prec == 1)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, PIPE>), grid, block, 0, st, a);
@@ -889,10 +951,10 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 2: return launch_cfg<128, 64, 1>(a, prec, st);
     case 3: return launch_cfg<64, 128, 1>(a, prec, st);
     case 4: return launch_cfg<64, 64, 1>(a, prec, st);
-    case 11: return launch_cfg<128, 128, 2>(a, prec, st);
+    case 11: return pipe3() && prec != 0 ? launch_cfg<128, 128, 3>(a, prec, st) : launch_cfg<128, 128, 2>(a, prec, st);
     case 12: return launch_cfg<128, 64, 2>(a, prec, st);
     case 13: return launch_cfg<64, 128, 2>(a, prec, st);
-    case 14: return launch_cfg<64, 64, 2>(a, prec, st);
+    case 14: return pipe3() && prec != 0 ? launch_cfg<64, 64, 3>(a, prec, st) : launch_cfg<64, 64, 2>(a, prec, st);
     case 31: return launch_dma(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);
