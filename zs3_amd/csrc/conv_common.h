@@ -59,10 +59,18 @@ namespace {
 // Rows [0, nrows) of an LDS-staged output tile -> global memory as dwordx4 per lane, with the fused epilogue (affine,
 // residual, activation, accumulate).  `c4`/`r0` = this thread's column quad / first row, RPP = rows per pass.  When
 // p.bs_partial is set the thread also accumulates the BN-backward sums of its 4 columns over the rows it stores.
-template <int RPP>
-__device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* ctile, int ldc, int row_base, int nrows,
-                                                int col, int c4, int r0, f32x4 sc, f32x4 sh, bool affine, bool vec,
-                                                f32x4& bs_s, f32x4& bs_q) {
+//
+// Round 4: epilogues that LOAD per element (residual, accumulate, the BN-backward operand: every data-gradient launch) fetch the
+// operands of EPI_U rows at once through branch-free addresses (an absent operand or a row past M reads the zero page) and
+// only then combine and store.  The round-3 form loaded each operand under `if (p.res) ...` inside the row loop, and hipcc waits
+// vmcnt(0) wherever a branch that holds a load joins: its ISA was `load, wait, store` per row -- up to 16 dependent HBM round
+// trips per thread and tile (the strip-resident kernel's data-gradient launches: tools/probe, the L / vmcnt pattern of conv_halo.s).
+// Y16: the element type of y / res / bn_y is a template argument for the same reason (two load widths under one run-time test).
+template <int RPP, bool Y16, int EPI_U>
+__device__ __forceinline__ void store_tile_rows_t(const ConvArgs& p, const float* ctile, int ldc, int row_base, int nrows,
+                                                  int col, int c4, int r0, f32x4 sc, f32x4 sh, bool affine, bool vec,
+                                                  f32x4& bs_s, f32x4& bs_q) {
+  using YT = std::conditional_t<Y16, bf16_t, float>;
   f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f}, msc = {0.f, 0.f, 0.f, 0.f}, msh = {0.f, 0.f, 0.f, 0.f};
   const bool bstat = p.bs_partial != nullptr && vec && col < p.ncols;
   if (bstat) {
@@ -73,67 +81,118 @@ __device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* 
       msh = *reinterpret_cast<const f32x4*>(p.bs_msh + col);
     }
   }
-  const int y16 = p.y_bf16;
+  YT* const yp = reinterpret_cast<YT*>(p.y);
+  auto act_of = [&](f32x4 v) {
+    if (p.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
+    }
+    return v;
+  };
+  const bool loading = vec && (p.res != nullptr || p.accumulate || bstat);
+  if (vec && !loading) {
+    // store-only epilogue (every forward layer): nothing to wait for
+    for (int rr = r0; rr < nrows; rr += RPP) {
+      const int row = row_base + rr;
+      if (row >= p.M || col >= p.ncols) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
+      if (affine) v = v * sc + sh;
+      st4<YT>(yp + (size_t)row * p.ldy + col, act_of(v));
+    }
+    return;
+  }
+  if (loading) {
+    const YT* const zero = reinterpret_cast<const YT*>(p.zero);
+    const unsigned char* const zb = reinterpret_cast<const unsigned char*>(p.zero);
+    const YT* const resp = reinterpret_cast<const YT*>(p.res);
+    const YT* const byp = reinterpret_cast<const YT*>(p.bs_y);
+    const int mstride = p.ncols >> 2, mcol = col >> 2;
+    for (int rr0 = r0; rr0 < nrows; rr0 += EPI_U * RPP) {
+      f32x4 rv[EPI_U], ov[EPI_U], yv[EPI_U];
+      unsigned rmb[EPI_U], bmb[EPI_U];
+      bool ok[EPI_U];
+      // ---- every operand of EPI_U rows requested before any of them is used; selects, not branches
+#pragma unroll
+      for (int u = 0; u < EPI_U; ++u) {
+        const int rr = rr0 + u * RPP, row = row_base + rr;
+        ok[u] = rr < nrows && row < p.M && col < p.ncols;
+        const size_t rowc = ok[u] ? (size_t)row : 0;
+        rv[u] = ld4<YT>((ok[u] && resp) ? resp + rowc * p.ldr + col : zero);
+        ov[u] = ld4<YT>((ok[u] && p.accumulate) ? yp + rowc * p.ldy + col : zero);
+        yv[u] = ld4<YT>((ok[u] && bstat) ? byp + rowc * p.bs_ldy + col : zero);
+        rmb[u] = *((ok[u] && p.res_mbits) ? p.res_mbits + rowc * mstride + mcol : zb);
+        bmb[u] = *((ok[u] && p.bs_mbits) ? p.bs_mbits + rowc * mstride + mcol : zb);
+      }
+#pragma unroll
+      for (int u = 0; u < EPI_U; ++u) {
+        const int rr = rr0 + u * RPP, row = row_base + rr;
+        if (!ok[u]) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
+        if (affine) v = v * sc + sh;
+        if (p.res) {
+          f32x4 r = rv[u];
+          if (p.res_mbits) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (rmb[u] >> e) & 1u ? r[e] : 0.f;
+          }
+          v = v + r;
+        }
+        v = act_of(v);
+        if (p.accumulate) v = v + ov[u];
+        if constexpr (Y16) {
+          // the BatchNorm-backward sums below are taken over the values the next kernel will read: the stored, rounded ones
+          const u32x2 pk = f32x4_to_bf16(v);
+          *reinterpret_cast<u32x2*>(yp + (size_t)row * p.ldy + col) = pk;
+          v = bf16x4_to_f32(pk);
+        } else {
+          *reinterpret_cast<f32x4*>(yp + (size_t)row * p.ldy + col) = v;
+        }
+        if (bstat) {
+          f32x4 dz = v;
+          if (p.bs_mbits) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = (bmb[u] >> e) & 1u ? dz[e] : 0.f;
+          } else if (p.bs_msc) {
+            const f32x4 av = yv[u] * msc + msh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dz[e] = av[e] > 0.f ? dz[e] : 0.f;
+          }
+          bs_s += dz;
+          bs_q += dz * ((yv[u] - mu) * is);
+        }
+      }
+    }
+    return;
+  }
+  // scalar tail form: channel counts / strides that are not multiples of four (the 21- and 60-class heads)
   for (int rr = r0; rr < nrows; rr += RPP) {
     const int row = row_base + rr;
     if (row >= p.M || col >= p.ncols) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(ctile + rr * ldc + c4 * 4);
     if (affine) v = v * sc + sh;
     const size_t di = (size_t)row * p.ldy + col;
-    if (vec) {
-      if (p.res) {
-        f32x4 rv = ld4_rt(p.res, (size_t)row * p.ldr + col, y16);
-        if (p.res_mbits) {
-          const unsigned mb = p.res_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rv[e] = (mb >> e) & 1u ? rv[e] : 0.f;
-        }
-        v = v + rv;
+    for (int e = 0; e < 4; ++e)
+      if (col + e < p.ncols) {
+        float t = v[e];
+        if (p.res) t += ld1<YT>(reinterpret_cast<const YT*>(p.res) + (size_t)row * p.ldr + col + e);
+        if (p.act == 1) t = fmaxf(t, 0.f);
+        else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
+        if (p.accumulate) t += ld1<YT>(yp + di + e);
+        st1<YT>(yp + di + e, t);
       }
-      if (p.act == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.leak;
-      }
-      if (p.accumulate) v = v + ld4_rt(p.y, di, y16);
-      if (y16) {
-        // the BatchNorm-backward sums below are taken over the values the next kernel will read: the stored, rounded ones
-        const u32x2 pk = f32x4_to_bf16(v);
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.y) + di) = pk;
-        v = bf16x4_to_f32(pk);
-      } else {
-        *reinterpret_cast<f32x4*>(p.y + di) = v;
-      }
-      if (bstat) {
-        const f32x4 yv = ld4_rt(p.bs_y, (size_t)row * p.bs_ldy + col, y16);
-        f32x4 dz = v;
-        if (p.bs_mbits) {
-          const unsigned mb = p.bs_mbits[(size_t)row * (p.ncols >> 2) + (col >> 2)];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dz[e] = (mb >> e) & 1u ? dz[e] : 0.f;
-        } else if (p.bs_msc) {
-          const f32x4 av = yv * msc + msh;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dz[e] = av[e] > 0.f ? dz[e] : 0.f;
-        }
-        bs_s += dz;
-        bs_q += dz * ((yv - mu) * is);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (col + e < p.ncols) {
-          float t = v[e];
-          if (p.res) t += ld1_rt(p.res, (size_t)row * p.ldr + col + e, y16);
-          if (p.act == 1) t = fmaxf(t, 0.f);
-          else if (p.act == 2) t = t > 0.f ? t : t * p.leak;
-          if (p.accumulate) t += ld1_rt(p.y, di + e, y16);
-          st1_rt(p.y, di + e, t, y16);
-        }
-    }
   }
+}
+// EPI_U: rows whose operands are in flight together (4; 2 where the caller still holds live accumulators: conv_halo.hip's 256-row tiles)
+template <int RPP, int EPI_U = 4>
+__device__ __forceinline__ void store_tile_rows(const ConvArgs& p, const float* ctile, int ldc, int row_base, int nrows,
+                                                int col, int c4, int r0, f32x4 sc, f32x4 sh, bool affine, bool vec,
+                                                f32x4& bs_s, f32x4& bs_q) {
+  if (p.y_bf16) store_tile_rows_t<RPP, true, EPI_U>(p, ctile, ldc, row_base, nrows, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
+  else store_tile_rows_t<RPP, false, EPI_U>(p, ctile, ldc, row_base, nrows, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
 }
 
 // Block reduction of the per-thread BN-backward sums (fixed order: deterministic) and store of this row tile's partials.

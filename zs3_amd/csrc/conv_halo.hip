@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
           }
     }
     __syncthreads();
-    store_tile_rows<RPP>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
+    store_tile_rows<RPP, (BM == 256 ? 2 : 4)>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
   }
   if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
 }

@@ -121,6 +121,9 @@ def pick_halo_tile(m, ncols, dgrad=False):
     return 42 if cost(192) < cost(256) else 41
 
 
+DMA_RULE = os.environ.get("ZS3_DMA", "1") == "1"   # the LDS-DMA kernel (tile_cfg 31) for the long-K wide layers (0: the 128x128 register-staged kernel)
+
+
 def pick_tile(m, ncols, k=0):
     """Tile / kernel choice for the implicit-GEMM conv (zs3_conv_igemm tile_cfg): 1x = register-staged 4-wave kernel
     (11: 128x128, 14: 64x64 block tile), 31 = wave-specialised 256x128 kernel fed by LDS-DMA."""
@@ -137,7 +140,7 @@ def pick_tile(m, ncols, k=0):
     if ncols <= 64:
         return 14
     if m >= 8192 and k >= 512 and ncols >= 256:
-        return 31
+        return 31 if DMA_RULE else 11
     if ncols >= 256 and 128 <= k <= 256:
         return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
@@ -360,7 +363,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if tile_cfg in (141, 142):      # round-3 spelling of "tile_cfg 41 / 42 on a bf16-stored input"
         tile_cfg -= 100
     key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
-           HALO, HALO_BM, PW, PW_FORCE, io, PW16, HALO16, PW16_LOAD_EPI, PW16_CAPABLE, PW_LEPI, PW_LEPI_MINK, PW16_EPI_MINK)
+           HALO, HALO_BM, PW, PW_FORCE, DMA_RULE, io, PW16, HALO16, PW16_LOAD_EPI, PW16_CAPABLE, PW_LEPI, PW_LEPI_MINK, PW16_EPI_MINK)
     cached = _TILE_CHOICE.get(key)
     if cached is not None:
         tile_cfg = cached
