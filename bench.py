@@ -325,6 +325,7 @@ def main():
             ops.PREC_DEFAULT = prev_prec
             bval = args.batch * args.bf16_steps / bdt
             bf16_info = {"value": bval, "unit": "images/sec", "ms_per_step": 1e3 * bdt / args.bf16_steps, "steps": args.bf16_steps,
+                         "last_loss": float(_.detach().float().item()),
                          "warmup": 3, "dtype": DTYPE_NOTE["bf16"],
                          "workload": "the supervised step of `value` (same model, optimizer, batch) in the 2-byte mode",
                          "model_tflops": bval * TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7) / 1e3,
@@ -351,6 +352,9 @@ def main():
                      "step (configs[2]) is reported in full under `gmmn`" if args.workload == "supervised" else args.workload + " step"),
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # the last timed step's loss: a dead network (all-zero activations) runs the same kernels 10-45 % faster on this chip (lower
+        # switching power, higher clocks: found in round 4), so the line carries the evidence that it was alive
+        "last_loss": float(last.detach().float().item()) if torch.is_tensor(last) else (float(last[1]) if isinstance(last, tuple) else None),
         "dtype": DTYPE_NOTE[args.dtype], "data": "synthetic",
         "config": {"workload": ("train_pascal.py supervised step: DeepLabv3+ ResNet-101 fwd+CE+bwd+SGD (BASELINE configs[1]); the +GMMN step (configs[2]) is the `gmmn` object of this line"
                                 if args.workload == "supervised" else

@@ -4,7 +4,7 @@ import json, os, sys
 rnd = int(sys.argv[1])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles")
-base = "python bench.py --no-cpu-baseline"
+base = "python bench.py --no-cpu-baseline --bf16-steps 0"
 runs = {"sup": ("supervised", base + " --steps 5 --warmup 2 --gmmn-steps 0", "7 steps in the trace: 2 warm-up + 5 timed"),
         "bf16": ("supervised_bf16", base + " --steps 5 --warmup 2 --gmmn-steps 0 --dtype bf16", "7 steps in the trace: 2 warm-up + 5 timed"),
         "gmmn": ("gmmn", base + " --workload gmmn --steps 4 --warmup 2 --no-roofline", "6 steps in the trace: 2 warm-up + 4 timed")}
@@ -19,6 +19,17 @@ for key, (name, cmd, note) in runs.items():
     body = open(os.path.join(src, f"kt_{key}.md")).read()
     open(os.path.join(dst, f"r{rnd}_{name}_kernel_stats.md"), "w").write(head + "\n\n" + body)
 open(os.path.join(dst, f"r{rnd}_pmc_traffic.json"), "w").write(open(os.path.join(src, "pmc_traffic.json")).read())
+if os.path.exists(os.path.join(src, "pmc_traffic_bf16.json")):     # the 2-byte mode's passes (round 4)
+    db = json.load(open(os.path.join(src, "pmc_traffic_bf16.json")))
+    fam16 = [v for k, v in db["kernels"].items() if k.startswith("conv_halo_kernel<1,")]
+    n16 = sum(v["launches"] for v in fam16)
+    if n16:
+        db["conv_halo_family"] = {"launches": n16,
+                                  "read_bytes_per_launch": sum(v["read_bytes_per_launch"] * v["launches"] for v in fam16) / n16,
+                                  "write_bytes_per_launch": sum(v["write_bytes_per_launch"] * v["launches"] for v in fam16) / n16}
+    db["command"] = ("rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, a separate pass) --kernel-trace -- python bench.py --no-cpu-baseline "
+                     f"--bf16-steps 0 --steps 2 --warmup 1 --gmmn-steps 0 --no-roofline --dtype bf16 (tools/refresh_profiles.sh, round {rnd})")
+    json.dump(db, open(os.path.join(dst, f"r{rnd}_pmc_traffic_bf16.json"), "w"), indent=1)
 old = open(os.path.join(dst, f"r{rnd}_pmc_mfma.md")).read() if os.path.exists(os.path.join(dst, f"r{rnd}_pmc_mfma.md")) else ""
 head = old.split("\ncounters:")[0] if "\ncounters:" in old else f"# r{rnd}_pmc_mfma\n"
 new = open(os.path.join(src, "pmc_mfma.md")).read()

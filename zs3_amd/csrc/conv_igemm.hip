@@ -853,13 +853,15 @@ int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
   return prec == 1 ? launch_dma_prec<1>(a, grid, st) : launch_dma_prec<3>(a, grid, st);
 }
 
-// tile_cfg 11 / 14 run the three-stage branch-free prefetch loop (PIPE 3) since round 4: the two-stage loop keeps its loads under
-// `if (more steps)` branches, and hipcc waits vmcnt(0) where such a branch joins -- the ISA of the PIPE 2 kernel waits for the
-// loads it has just issued before every LDS write, i.e. no prefetch at all (tools/probe: the L / vmcnt pattern of conv_igemm.s).
-// Same-box A/B of the fp32-storage step: 46.02 / 46.03 ms with PIPE 2, 43.57 / 43.54 with PIPE 3 (tools/probe/r4n.sh).
-// ZS3_IGEMM_PIPE=2 restores the old loop.
+// ZS3_IGEMM_PIPE=3: tile_cfg 11 / 14 on the three-stage branch-free prefetch loop (round 4).  The two-stage loop keeps its loads
+// under `if (more steps)` branches and hipcc waits vmcnt(0) where such a branch joins -- its ISA waits for the loads it has just
+// issued before every LDS write, i.e. no prefetch inside one workgroup; PIPE 3 fixes that (counted waits, 24 loads in flight).
+// Inside the training step it buys nothing: 45.5-45.7 ms against 44.9-45.1 for PIPE 2, same box (tools/probe/r4v.sh) -- two to four
+// resident workgroups per CU already cover each other's latency.  (The first A/B of this switch showed 43.5 against 46.0 ms: that
+// build's stem raced -- see lone_tail in conv_igemm_impl -- its output was zero, and a network of zeros runs every kernel 10-45 %
+// faster on this chip.  bench.py prints the last loss since.)  Default: PIPE 2.
 static bool pipe3() {
-  static const bool v = !(getenv("ZS3_IGEMM_PIPE") && atoi(getenv("ZS3_IGEMM_PIPE")) == 2);
+  static const bool v = getenv("ZS3_IGEMM_PIPE") && atoi(getenv("ZS3_IGEMM_PIPE")) == 3;
   return v;
 }
 
@@ -944,6 +946,15 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     cfg = bn == 128 ? (small ? 3 : 1) : (small ? 4 : 2);
   }
   if (in_scale && cfg != 41 && cfg != 42 && cfg != 51 && cfg != 52) return -7;   // only the producer-converting kernels transform x
+  // The multi-stage loops of the register-staged kernel peel their last K step(s) without a closing barrier, and the BatchNorm
+  // sums of the epilogue are staged in the first bytes of LDS stage 0: when the LAST step sits in stage 0 (an odd step count
+  // that is not a multiple of the unroll: the 7-tap stem) a fast wave can overwrite operands a slow wave is still multiplying.
+  // Found in round 4 with the three-stage loop, where the stem's output came out as zeros (a test failure that depended on
+  // what had run before it); the two-stage loop has the same window for odd step counts.  Such launches take the one-stage
+  // loop, where every K step ends with a barrier.  (Same-box A/B runs of kernel-side fixes looked 3 ms per step SLOWER than the
+  // racy build -- because the racy build's network was dead and a dead network is fast: tools/probe/r4r.sh .. r4v.sh.)
+  const int kt_steps = KH * KW * (cin_pad / 32);
+  const bool lone_tail = stat_partial != nullptr && (kt_steps & 1) && !a.x_bf16;
   if (prec == 0 && cfg > 14) return -7;   // the exact-fp32 test mode exists on the register-staged kernel only
   if (a.x_bf16 && cfg == 31) return -7;   // the LDS-DMA kernel moves raw fp32 rows
   switch (cfg) {
@@ -951,10 +962,13 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 2: return launch_cfg<128, 64, 1>(a, prec, st);
     case 3: return launch_cfg<64, 128, 1>(a, prec, st);
     case 4: return launch_cfg<64, 64, 1>(a, prec, st);
-    case 11: return pipe3() && prec != 0 ? launch_cfg<128, 128, 3>(a, prec, st) : launch_cfg<128, 128, 2>(a, prec, st);
-    case 12: return launch_cfg<128, 64, 2>(a, prec, st);
-    case 13: return launch_cfg<64, 128, 2>(a, prec, st);
-    case 14: return pipe3() && prec != 0 ? launch_cfg<64, 64, 3>(a, prec, st) : launch_cfg<64, 64, 2>(a, prec, st);
+    // (lone_tail: see below -- such launches take the one-stage loop, which ends every K step with a barrier)
+    case 11: return lone_tail ? launch_cfg<128, 128, 1>(a, prec, st)
+                    : pipe3() && prec != 0 ? launch_cfg<128, 128, 3>(a, prec, st) : launch_cfg<128, 128, 2>(a, prec, st);
+    case 12: return lone_tail ? launch_cfg<128, 64, 1>(a, prec, st) : launch_cfg<128, 64, 2>(a, prec, st);
+    case 13: return lone_tail ? launch_cfg<64, 128, 1>(a, prec, st) : launch_cfg<64, 128, 2>(a, prec, st);
+    case 14: return lone_tail ? launch_cfg<64, 64, 1>(a, prec, st)
+                    : pipe3() && prec != 0 ? launch_cfg<64, 64, 3>(a, prec, st) : launch_cfg<64, 64, 2>(a, prec, st);
     case 31: return launch_dma(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);
