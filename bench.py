@@ -5,7 +5,7 @@
 
 Workload (config.workload): configs[1] of BASELINE.json -- the supervised DeepLabv3+ ResNet-101 training step of
 train_pascal.py (forward, CE, backward, SGD; base_trainer.py:16-20) on synthetic 513x513 batches, 16 images per GPU,
-21 classes, fp32 semantics computed as bf16x3 splits on the MFMA cores.  Weak scaling: every rank owns 16 images;
+21 classes, fp32 semantics computed as three-product 16-bit hi/lo splits on the MFMA cores (forward fp16 halves, backward bf16 halves).  Weak scaling: every rank owns 16 images;
 gradients are SUM all-reduced over RCCL while backward runs (zs3_amd.parallel.GradSync).  The GMMN step
 (configs[2], train_pascal_GMMN.py:139-268) is timed after the main loop and reported under "gmmn".
 
@@ -28,7 +28,8 @@ import torch.distributed as dist  # noqa: E402
 
 FWD_GFLOP_PER_IMG = {21: 185.64, 60: 185.97}          # BASELINE.md section 3 (2*MAC, convs only)
 TRAIN_GFLOP_PER_IMG = {21: 555.7, 60: 556.7}          # fwd + dgrad + wgrad, no dgrad for the stem
-DTYPE_NOTE = {"bf16x3": "bf16x3 (fp32 split into bf16 hi+lo, 3 MFMA products, fp32 accumulate; fp32 storage)",
+DTYPE_NOTE = {"bf16x3": "x3 split (fp32 operands as 16-bit hi+lo, 3 MFMA products per pair, fp32 accumulate; fp32 storage): forward "
+                        "convolutions f16x3 (fp16 hi/lo, 2^-22-class products), data / weight gradients bf16x3 (bf16 hi/lo, 2^-16-class)",
               "bf16": "bf16 (activations and inter-layer gradients stored as bf16, plain bf16 MFMA products, fp32 accumulate; fp32 master "
                       "weights, weight gradients, BN statistics, class scores)",
               "bf16f32": "bf16 products on fp32 storage (plain bf16 MFMA products, fp32 accumulate; every tensor fp32 in HBM)"}
@@ -415,7 +416,7 @@ def roofline_of(prof, warm_prof, instrumented, dtype):
         "instantiations": ({k: {"launches": v[0], "avg_launch_us": 1e6 * v[2] / v[0], "tflops": v[1] / v[2] / 1e12}
                             for k, v in sorted(fam.items())} if fam and tag.startswith("conv_halo<") else None),
         "note": "achieved = algorithmic 2*M*N*K flops of the sampled launches / their HIP-event time (events around every "
-                "4th launch of this kernel, rotating phase, in every 5th timed step)" + ("; each product costs 3 bf16 MFMAs (bf16x3), so MFMA-issue utilisation "
+                "4th launch of this kernel, rotating phase, in every 5th timed step)" + ("; each product costs 3 16-bit MFMAs (f16x3 forward / bf16x3 backward), so MFMA-issue utilisation "
                 "is 3x this fraction" if dtype == "bf16x3" else "; one bf16 MFMA per product"),
         "all_conv_igemm_last_warmup_step": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms": 1e3 * v[2]}
                                             for k, v in warm.items()},
@@ -435,7 +436,8 @@ def pmc_traffic(tag, variant=""):
     src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     hm = re.match(r"conv_halo<(\d)>", tag)
     if hm:   # the strip-resident kernel is one source kernel in several instantiations (tile height, strip passes per step)
-        fam = [v for k, v in kernels.items() if k.startswith(f"conv_halo_kernel<{hm.group(1)},")]
+        precs = ("3", "4") if hm.group(1) == "3" else (hm.group(1),)     # <3>: the x3 family = bf16x3 (data gradient) + f16x3 (forward) instantiations
+        fam = [v for k, v in kernels.items() if any(k.startswith(f"conv_halo_kernel<{q},") for q in precs)]
         n = sum(v["launches"] for v in fam)
         if not n:
             return None, None

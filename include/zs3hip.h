@@ -37,8 +37,16 @@ int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout, int taps, 
  * reference's default-init train-mode goldens through it. */
 int zs3_prep_weight_f32(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
                         void* stream);
+/* Operands of a layer whose FORWARD launches run prec = 4 ("f16x3": fp16 hi/lo halves, three v_mfma_f32_32x32x16_f16 per
+ * operand pair, 2^-22-class products -- the default arithmetic of the fp32-storage forward pass since round 4, because it puts
+ * the default-initialised train step at 1.3x / 1.6x / 1.4x the reference's own fp32 error where bf16x3 sat at 22x / 31x / 5.6x):
+ * f_pk holds fp16 hi/lo in the same [row][K/32][{hi,lo}][32] layout, t_pk (data-gradient operand, prec = 3) bf16 hi/lo.
+ * fp16 has the precision but not the range for back-propagated gradients, so data- and weight-gradient launches stay bf16x3. */
+int zs3_prep_weight_f16fwd(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
+                           void* stream);
 /* the same for many weights in ONE launch (after an optimizer step): table[e] = {w, f_pk, t_pk, cout, taps, cin, cin_pad,
- * cout_pad} as 8 int64 (device memory), blockmap[b] = {entry, chunk} as 2 int32 with chunk in
+ * cout_pad} as 8 int64 (device memory; bit 32 of the `taps` word set = the entry's forward plane is fp16 hi/lo as written by
+ * zs3_prep_weight_f16fwd), blockmap[b] = {entry, chunk} as 2 int32 with chunk in
  * [0, zs3_prep_chunks(cout_pad, taps, cin_pad)) (one tap x 32 output channels x <= 256 input channels each). */
 int zs3_prep_chunks(int cout_pad, int taps, int cin_pad);
 int zs3_prep_weight_multi(const long* table, const int* blockmap, int nblocks, void* stream);
@@ -53,7 +61,9 @@ int zs3_nchw3_to_nhwc4(const float* img, float* out, int N, int H, int W, int Wp
  * sums of squares of the raw conv output (BatchNorm batch statistics), mtiles = zs3_conv_igemm_mtiles.
  * dgrad=1: rows are input-gradient pixels (N x Ho x Wo = the conv's input extent), x is dy (N x H x W
  * = the conv's output extent), w_pk is the t_pk operand.
- * act: 0 none, 1 ReLU, 2 LeakyReLU(leak).  prec: 3 = bf16x3 split (fp32-class), 1 = plain bf16, 0 = exact fp32 (test mode:
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(leak).  prec: 3 = bf16x3 split (2^-16-class products, fp32 exponent range), 4 = f16x3 split
+ * (2^-22-class products, fp16 exponent range: |x| <= 65504, full precision for |x| >= 1e-4 or so; w_pk from
+ * zs3_prep_weight_f16fwd; store-only epilogues, i.e. forward launches), 1 = plain bf16, 0 = exact fp32 (test mode:
  * w_pk from zs3_prep_weight_f32, tile_cfg 1-4 / 11-14 only, -7 otherwise).
  * tile_cfg: 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64 (+10: two-deep register prefetch).  zero_page: >= 256 bytes of
  * device zeros (16-byte aligned) that masked loads are redirected to; stride must be a power of two.

@@ -483,21 +483,38 @@ def _report(tag, e):
 
 def test_default_init_train_step_vs_reference_goldens(dev, golden):
     """The reference's OWN train-mode outputs for the default-initialised network: logits, loss, the classifier and stem weight
-    gradients and the 226 BatchNorm running statistics -- the goldens no other GPU test touches.
+    gradients and the 226 BatchNorm running statistics -- the goldens no other GPU test touches -- on the product's default
+    arithmetic: forward convolutions f16x3 (fp16 hi/lo operands, 2^-22-class products), data / weight gradients bf16x3.
 
     This configuration is ill-conditioned: batch statistics over 2 x 5 x 5 positions in 101 layers amplify a rounding
-    difference ~1e4-fold (the reference's own fp32 result sits 1.7e-3 (logits) to several 1e-2 (early-layer gradients) away
-    from its fp64 evaluation -- measured below, not assumed).  bf16x3 products carry 2^-16..2^-18 instead of fp32's 2^-24, so
-    the same amplification gives a few 1e-2.  That the gap IS arithmetic and not structure is what the next test shows: the same
-    step with every product on the exact-fp32 MFMA lands at the reference's own distance from fp64.  Assertions here:
-    (1) against the reference's goldens, 3x what the kernels deliver (delivered: logits 3.6e-2, loss 3.6e-4, classifier
-        gradient 3.5e-2, running statistics 2.5e-3);
-    (2) against the fp64 oracle, every error in units of the reference's own fp32 error: at most 64x for the logits and the
-        classifier gradient (2^8 = 256 would be the pure round-off ratio; delivered 22x / 31x), at most 16x for the stem
-        gradient (delivered 5.6x; the stem bound of earlier rounds against the goldens, 1.1, bounded nothing and is gone).
-    The well-conditioned variants of this step (bn3 gains 0.1, as in a trained ResNet) are held to 1e-3 / 2e-3 above."""
+    difference ~1e4-fold -- the reference's own fp32 result sits 1.7e-3 (logits) to 6e-2 (stem gradient) away from its fp64
+    evaluation (measured below, not assumed), so two correct fp32-class evaluations differ by about that much.  The amplification
+    is all in the FORWARD pass (the backward is linear in the forward's activations): with bf16x3 forward products (2^-16-class,
+    rounds 1-3) the same step sat 3.6e-2 from the goldens = 22x / 31x / 5.6x the reference's own error (next test); with the
+    fp16 split it sits where a second fp32 evaluation would (tools/probe/split_emulation.py predicted 1.3x / 1.6x / 1.4x on the CPU).
+    Delivered: logits 3.2e-3 from the goldens (was 3.6e-2), loss 7.2e-5, classifier gradient 3.2e-3, running statistics 2.0e-4;
+    against fp64 1.8x / 2.1x / 1.4x the reference's own fp32 error (logits / classifier gradient / stem gradient).
+    Assertions: against the fp64 oracle at most 4x the reference's own fp32 error for logits and both gradients; against the
+    goldens 4x that error as well (each evaluation is ~1 such error from fp64); loss and running statistics at 3x delivered."""
     e = _default_init_train_step(dev, golden)
-    _report("bf16x3", e)
+    _report("f16x3 forward, bf16x3 backward (default)", e)
+    assert e["our_logits"] < 4 * e["ref_logits"]
+    assert e["our_pred"] < 4 * e["ref_pred"]
+    assert e["our_stem"] < 4 * e["ref_stem"]
+    assert e["logits"] < 4 * e["ref_logits"]
+    assert e["pred"] < 4 * e["ref_pred"]
+    assert e["loss"] < 2.2e-4        # 3 x delivered (7.2e-5)
+    assert e["run"] < 6e-4           # 3 x delivered (1.95e-4)
+
+
+def test_default_init_train_step_with_bf16x3_forward(dev, golden, monkeypatch):
+    """The same step with the forward products on the bf16 split (ZS3_FWD_F16=0, the arithmetic of rounds 1-3): kept as the
+    measured comparison.  Delivered: logits 3.6e-2 from the goldens, loss 3.6e-4, classifier gradient 3.5e-2, running
+    statistics 2.5e-3; against fp64 22x / 31x / 5.6x the reference's own fp32 error.  Bounds: 3x delivered, and 64x / 64x / 16x."""
+    from zs3_amd import ops
+    monkeypatch.setattr(ops, "FWD_F16", False)
+    e = _default_init_train_step(dev, golden)
+    _report("bf16x3 forward and backward", e)
     assert e["logits"] < 0.11        # 3 x delivered (3.6e-2)
     assert e["loss"] < 1.1e-3        # 3 x delivered (3.6e-4); the north-star 1e-3 is met
     assert e["pred"] < 0.11          # 3 x delivered (3.5e-2)
@@ -505,6 +522,7 @@ def test_default_init_train_step_vs_reference_goldens(dev, golden):
     assert e["our_logits"] < 64 * e["ref_logits"]
     assert e["our_pred"] < 64 * e["ref_pred"]
     assert e["our_stem"] < 16 * e["ref_stem"]
+    assert e["our_logits"] > 4 * e["ref_logits"]     # (and it IS the forward products: this run does not meet the default's bound)
 
 
 def test_default_init_train_step_in_exact_fp32_matches_the_references_own_error(dev, golden):

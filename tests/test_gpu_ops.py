@@ -87,6 +87,52 @@ def test_conv_exact_fp32_mode(dev, case):
     assert max(errs) < 5e-6
 
 
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 31, 41, 42, 51, 52])
+def test_conv_forward_f16x3(dev, cfg):
+    """prec = 4 (round 4, the forward arithmetic of the fp32-storage network): fp16 hi/lo operands, three
+    v_mfma_f32_32x32x16_f16 per pair, on every kernel family behind zs3_conv_igemm -- ragged M / channel tails, stride 2,
+    dilation, 1x1, BatchNorm partial sums, the fused scale / shift / residual / ReLU epilogue (a LOADING epilogue: the
+    persistent pointwise kernel refuses it in this precision and the rules route around).  Against fp64 in the maximum norm:
+    5e-6 of the output scale, the bound of `test_conv_exact_fp32_mode` (delivered 1.0-1.6e-6, 3.1e-6 at K = 18432: the chained
+    fp32 accumulation of the MFMA, not the operands; bf16x3 delivers 4.5-4.9e-6 on the same operands), and in the L2 norm at most
+    0.4x the bf16x3 error (delivered 0.15-0.22x: 0.7-1.0e-6 against 4.4-4.5e-6; what is left is the accumulator's own rounding,
+    sqrt(3 K / 16) x 2^-24 ~ 1.2e-6 at K = 2304 -- the exact-fp32 instantiation carries the same term), 0.7x at K = 18432 where
+    that rounding (2.6e-6) is most of either error."""
+    from zs3_amd import ops
+    shapes = [(2, 33, 31, 256, 256, 3, 1, 1), (1, 35, 33, 304, 256, 3, 1, 1), (2, 33, 33, 128, 128, 3, 2, 1),
+              (1, 17, 17, 2048, 256, 3, 1, 6), (2, 20, 20, 256, 21, 1, 1, 1), (3, 17, 19, 64, 256, 1, 1, 1),
+              (8, 33, 33, 256, 1024, 1, 1, 1)]
+    for (n, h, w, ci, co, k, s, d) in shapes:
+        g = torch.Generator().manual_seed(cfg * 131 + h + ci)
+        x = torch.randn(n, ci, h, w, generator=g)
+        x[:, : ci // 4] *= 1e-3                      # a quarter of the channels three decades down: fp16's subnormal lo halves
+        wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+        pad = d * (k // 2)
+        ref = F.conv2d(x.double(), wt.double(), stride=s, padding=pad, dilation=d)
+        xg = x.to(dev).permute(0, 2, 3, 1).contiguous()
+        wp16 = ops.prep_weight(wt.to(dev), f16_forward=True)
+        wp = ops.prep_weight(wt.to(dev))
+        assert wp16.f_fmt == 1 and wp.f_fmt == 0
+        y, st = ops.conv2d_fwd(xg, wp16, s, pad, d, want_stats=True, tile_cfg=cfg)       # conv2d_fwd turns the plane format into prec 4
+        y3, _ = ops.conv2d_fwd(xg, wp, s, pad, d, want_stats=True, tile_cfg=cfg)
+        e16, e3 = rel(y.permute(0, 3, 1, 2), ref), rel(y3.permute(0, 3, 1, 2), ref)
+        l16, l3 = ((y.permute(0, 3, 1, 2).double().cpu() - ref).norm() / ref.norm()).item(), \
+                  ((y3.permute(0, 3, 1, 2).double().cpu() - ref).norm() / ref.norm()).item()
+        print(f"[f16x3 cfg {cfg} {ci}->{co} k{k}] max-norm {e16:.1e} (bf16x3 {e3:.1e}), L2 {l16:.1e} (bf16x3 {l3:.1e})")
+        assert e16 < 5e-6 and l16 < (0.7 if k * k * ci > 8192 else 0.4) * l3, (cfg, ci, co, e16, e3, l16, l3)
+        ssum, qsum = st[:, 0].double().sum(0).cpu(), st[:, 1].double().sum(0).cpu()
+        assert ((ssum - ref.sum((0, 2, 3))).abs().max() / ref.abs().sum((0, 2, 3)).max()).item() < 2e-6
+        assert ((qsum - ref.square().sum((0, 2, 3))).abs().max() / ref.square().sum((0, 2, 3)).max()).item() < 2e-6
+        sc, sh = torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)
+        res = torch.randn(ref.shape, generator=g)
+        z, _ = ops.conv2d_fwd(xg, wp16, s, pad, d, scale=sc.to(dev), shift=sh.to(dev), act=1, tile_cfg=cfg,
+                              res=res.to(dev).permute(0, 2, 3, 1).contiguous())
+        zref = torch.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double())
+        assert rel(z.permute(0, 3, 1, 2), zref) < 5e-6, (cfg, ci, co)
+    with pytest.raises(ValueError):      # an fp16 plane under a plain-bf16 launch would multiply garbage: refused
+        ops.conv2d_fwd(xg, wp16, s, pad, d, prec=1)
+
+
 @pytest.mark.parametrize("cfg", [11, 12, 13, 14, 31, 41, 42])
 def test_conv_every_tile_config(dev, cfg):
     """every kernel variant behind zs3_conv_igemm (register-staged tiles, wave-specialised, LDS-DMA) on ragged shapes:
@@ -345,9 +391,11 @@ def test_fused_upsample_argmax_confusion(dev, classes, hw, HW):
     assert abs(Evaluator(classes).Pixel_Accuracy() != 0)   # nan on an empty matrix, like the reference
 
 
-def test_refresh_planes_equals_per_weight_split(dev):
+@pytest.mark.parametrize("f16_forward", [True, False])
+def test_refresh_planes_equals_per_weight_split(dev, f16_forward):
     """zs3_prep_weight_multi (one launch after the optimizer step, LDS-transposed tiles) writes exactly the planes that
-    zs3_prep_weight produces per weight -- ragged channel counts, 1x1 / 3x3 / 7x7-like taps, padded K"""
+    zs3_prep_weight / zs3_prep_weight_f16fwd produce per weight -- ragged channel counts, 1x1 / 3x3 / 7x7-like taps, padded K;
+    both forward-plane formats (fp16 hi/lo for the f16x3 forward launches, bf16 hi/lo)"""
     from zs3_amd import functional as Fz, ops
     g = torch.Generator().manual_seed(11)
     ws = []
@@ -355,14 +403,22 @@ def test_refresh_planes_equals_per_weight_split(dev):
                         (256, 2048, 3), (40, 36, 5)]:
         w = torch.nn.Parameter(torch.randn(co, ci, k, k, generator=g).to(dev).contiguous(memory_format=torch.channels_last))
         ws.append(w)
-        Fz.weight_planes(w, need_t=True)              # creates the cached plane buffers
+        Fz.weight_planes(w, need_t=True, f16=f16_forward)   # creates the cached plane buffers
     for w in ws:
         w.data.mul_(1.7).add_(0.01)                   # "optimizer step" through .data: the version counter does not move
     Fz.refresh_planes(*ws)
     for w in ws:
-        got = Fz.weight_planes(w, need_t=True)        # cache hit: the refreshed buffers
-        want = ops.prep_weight(w, need_t=True)
-        assert torch.equal(got.f_pk, want.f_pk) and torch.equal(got.t_pk, want.t_pk), tuple(w.shape)
+        got = Fz.weight_planes(w, need_t=True, f16=f16_forward)   # cache hit: the refreshed buffers
+        want = ops.prep_weight(w, need_t=True, f16_forward=f16_forward)
+        assert got.f_fmt == want.f_fmt == int(f16_forward)
+        assert torch.equal(got.f_pk.view(torch.int16), want.f_pk.view(torch.int16)) and torch.equal(got.t_pk, want.t_pk), tuple(w.shape)
+        # the fp16 forward plane really is hi + lo of the weight: hi + lo reproduces it to 2^-22 (bf16 planes: 2^-16)
+        co, ci, k, _ = w.shape
+        pl = got.f_pk.view(torch.float16 if f16_forward else torch.bfloat16).view(co, -1, 2, 32).float()
+        rec = (pl[:, :, 0] + pl[:, :, 1]).reshape(co, k * k, -1)[:, :, :ci]
+        ref = w.detach().permute(0, 2, 3, 1).reshape(co, k * k, ci)
+        err = ((rec - ref).abs().max() / ref.abs().max()).item()
+        assert err < (6e-7 if f16_forward else 2e-5), (tuple(w.shape), err)
 
 
 def test_cluster_graph_matches_reference_goldens(dev):

@@ -38,7 +38,7 @@ print("installed", sorted(f for f in os.listdir(dst) if f.startswith(f"r{rnd}_")
 # the strip kernel's instantiations as one family (what bench.py's roofline.traffic quotes), and the command
 p = os.path.join(dst, f"r{rnd}_pmc_traffic.json")
 d = json.load(open(p))
-fam = [v for k, v in d["kernels"].items() if k.startswith("conv_halo_kernel<3,")]
+fam = [v for k, v in d["kernels"].items() if k.startswith("conv_halo_kernel<3,") or k.startswith("conv_halo_kernel<4,")]   # bf16x3 (dgrad) + f16x3 (forward)
 n = sum(v["launches"] for v in fam)
 d["conv_halo_family"] = {"launches": n, "read_bytes_per_launch": sum(v["read_bytes_per_launch"] * v["launches"] for v in fam) / n,
                          "write_bytes_per_launch": sum(v["write_bytes_per_launch"] * v["launches"] for v in fam) / n}

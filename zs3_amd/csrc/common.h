@@ -29,11 +29,40 @@ __device__ __forceinline__ unsigned pack_hi_trunc(float a, float b) {
 }
 __device__ __forceinline__ float trunc_bf16_f32(float a) { return __uint_as_float(__float_as_uint(a) & 0xFFFF0000u); }
 
+// ---- split-fp16 ("f16x3", PREC = 4) --------------------------------------------------------------------------------------
+// The same three products on v_mfma_f32_32x32x16_f16 (same rate as the bf16 instruction: 2460 vs 2375 TF in a register-only
+// loop, tools/probe/f16/f16_probe.hip) with hi = fp16(x), lo = fp16(x - hi), both round-to-nearest-even (v_cvt_pk_f16_f32):
+// 11 + 11 significand bits instead of 8 + 8, the dropped lo*lo term <= 2^-22 |a b| -- fp32-class products (one layer against
+// fp64: 2.4e-7 .. 4.7e-7 relative, the fp32 accumulation floor, where the bf16 split gives 4.5e-6; tools/probe/fp16_split_eval.py).
+// What fp16 does not have is range: lo is subnormal for |x| < 0.12 (the conversion produces and the MFMA consumes subnormals
+// unflushed -- probed) and gone below |x| ~ 1e-4 (absolute error 3e-8), and |x| > 65504 overflows.  Forward operands (BatchNorm'd
+// activations, O(1); weights O(1e-2)) sit inside that window, back-propagated gradients (1e-3 .. 1e-9) do not: the FORWARD
+// convolutions run f16x3, data- and weight-gradient launches stay bf16x3 (exponent range of fp32).  DESIGN.md section 2.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {   // {fp16(a) low half, fp16(b) high half}, RNE
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// one MFMA of the 16-bit operand type PREC selects (fragments travel as 8 x 16 bit in four VGPRs either way)
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (PREC == 4)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 template <int PREC>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   if (PREC == 1) {
     hi = cvt_pk_bf16(a, b);
     lo = 0u;
+  } else if (PREC == 4) {
+    hi = cvt_pk_f16(a, b);
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, hi);
+    lo = cvt_pk_f16(a - (float)h[0], b - (float)h[1]);   // the remainder is exact in fp32
   } else {
     hi = cvt_pk_bf16(a, b);  // round-to-nearest hi: |x - hi| <= 2^-9 |x|, remainder exact in fp32
     lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));

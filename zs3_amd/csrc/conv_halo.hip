@@ -76,7 +76,7 @@ template <int PREC, int BM, int NPG, bool A16 = false, bool INAFF = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const HaloGeom g) {
   static_assert(!A16 || PREC == 1, "bf16-stored input: plain bf16 products only");
   static_assert(!(A16 && INAFF), "the input transform reads fp32 storage");
-  constexpr int BN = 128, TM = BM / 64, TN = 2, CH = PREC == 3 ? 16 : 32;
+  constexpr int BN = 128, TM = BM / 64, TN = 2, CH = PREC >= 3 ? 16 : 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     //            chunk c+1 is fetched in six groups of NPG passes during the intervals of chunk c: group k loaded in
     //            interval k, split to bf16 hi/lo and written in interval k+3.  A group that reaches past the strip's last
     //            pass repeats that pass (same data, same rows).
-    constexpr int NV = PREC == 3 ? 1 : 2;
+    constexpr int NV = PREC >= 3 ? 1 : 2;
     constexpr int DIST = 3, NGRP = 9 - DIST;
     const int pl = tid - 256, prow = pl >> 2, cq = pl & 3;
     const long Mtot = (long)p.N * p.H * p.W;
@@ -154,11 +154,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
         srcv[v] = srcv0[v];
         if constexpr (INAFF) srcv[v] = affine_relu4(srcv[v], aff_sc[v], aff_sh[v]);
       }
-      if (PREC == 3) {
+      if (PREC >= 3) {
         u32x2 hi, lo;
         unsigned h, l;
-        split_pair<3>(srcv[0][0], srcv[0][1], h, l); hi[0] = h; lo[0] = l;
-        split_pair<3>(srcv[0][2], srcv[0][3], h, l); hi[1] = h; lo[1] = l;
+        split_pair<PREC>(srcv[0][0], srcv[0][1], h, l); hi[0] = h; lo[0] = l;
+        split_pair<PREC>(srcv[0][2], srcv[0][3], h, l); hi[1] = h; lo[1] = l;
         const int o = (((cq >> 1) ^ sw) << 4) + (cq & 1) * 8;
         *reinterpret_cast<u32x2*>(row + o) = hi;
         *reinterpret_cast<u32x2*>(row + (o ^ 32)) = lo;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
       }
     };
     // weight tile: lane -> (tile row wr + 64 e, chunk cq), e = 0, 1; masked columns read the zero page
-    const int qoff = PREC == 3 ? (cq & 1) * 16 + (cq >> 1) * 64 : cq * 16;
+    const int qoff = PREC >= 3 ? (cq & 1) * 16 + (cq >> 1) * 64 : cq * 16;
     const unsigned char* wptr[2];
     int wstep[2];
     unsigned wdst[2];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
         ++c;
       }
       const int kofs = t * p.cin_pad + c * CH;
-      const int uoff = (kofs >> 5) * 128 + (PREC == 3 ? ((kofs >> 4) & 1) * 32 : 0);
+      const int uoff = (kofs >> 5) * 128 + (PREC >= 3 ? ((kofs >> 4) & 1) * 32 : 0);
 #pragma unroll
       for (int e = 0; e < 2; ++e) dstv[e] = *reinterpret_cast<const u32x4*>(wptr[e] + (size_t)uoff * wstep[e]);
     };
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     // (sched_barrier): hipcc otherwise hoists all LDS reads and issues the MFMAs as one clump.
     auto step = [&](auto setc) {
       constexpr int SET = decltype(setc)::value;
-      constexpr int NM = (PREC == 3 ? 3 : 2) * TN;
+      constexpr int NM = (PREC >= 3 ? 3 : 2) * TN;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (i == TM - 2) {
@@ -356,12 +356,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
           const int pr = m / TN, j = m % TN;
-          if (PREC == 3)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al : ah, pr == 1 ? b_lo[SET][j] : b_hi[SET][j],
-                                                                acc[i][j], 0, 0, 0);
+          if (PREC >= 3)
+            acc[i][j] = mfma16<PREC>(pr == 0 ? al : ah, pr == 1 ? b_lo[SET][j] : b_hi[SET][j], acc[i][j]);
           else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? ah : al, pr == 0 ? b_hi[SET][j] : b_lo[SET][j],
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<PREC>(pr == 0 ? ah : al, pr == 0 ? b_hi[SET][j] : b_lo[SET][j], acc[i][j]);
           // fillers of this gap.  Sub-step i fetches fragment (i + 2) % TM (its address was computed a sub-step ago) and
           // computes the address of fragment (i + 3) % TM; fragments fetched in sub-steps TM-2 and TM-1 belong to the next
           // step, so sub-step TM-3 computes its address from the NEXT window (a0n / tbitn, ready since sub-step 0).
@@ -495,7 +493,7 @@ bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   g.npass = g.s_pad / 64;
   g.npg = (g.npass + 5) / 6;   // six load groups per chunk (conv_halo_kernel: NGRP)
   if (g.npg > HALO_MAXP) return false;
-  const int ch = prec == 3 ? 16 : 32;
+  const int ch = prec >= 3 ? 16 : 32;
   g.nch = (a.cin_valid + ch - 1) / ch;
   if (g.nch * ch > a.cin_pad) return false;
   g.ns = (g.nch * T + 1) & ~1;
@@ -546,11 +544,15 @@ int zs3conv::launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   }
   if (a.in_scale) {   // input transform (the producing layer's BatchNorm-apply + ReLU) in the producer waves
     if (!a.in_shift) return -1;
-    if (bm == 256) return prec == 1 ? launch_halo_t<1, 256, false, true>(a, g, st) : launch_halo_t<3, 256, false, true>(a, g, st);
-    return prec == 1 ? launch_halo_t<1, 192, false, true>(a, g, st) : launch_halo_t<3, 192, false, true>(a, g, st);
+    if (bm == 256)
+      return prec == 1 ? launch_halo_t<1, 256, false, true>(a, g, st)
+             : prec == 4 ? launch_halo_t<4, 256, false, true>(a, g, st) : launch_halo_t<3, 256, false, true>(a, g, st);
+    return prec == 1 ? launch_halo_t<1, 192, false, true>(a, g, st)
+           : prec == 4 ? launch_halo_t<4, 192, false, true>(a, g, st) : launch_halo_t<3, 192, false, true>(a, g, st);
   }
-  if (bm == 256) return prec == 1 ? launch_halo_t<1, 256>(a, g, st) : launch_halo_t<3, 256>(a, g, st);
-  return prec == 1 ? launch_halo_t<1, 192>(a, g, st) : launch_halo_t<3, 192>(a, g, st);
+  if (bm == 256)
+    return prec == 1 ? launch_halo_t<1, 256>(a, g, st) : prec == 4 ? launch_halo_t<4, 256>(a, g, st) : launch_halo_t<3, 256>(a, g, st);
+  return prec == 1 ? launch_halo_t<1, 192>(a, g, st) : prec == 4 ? launch_halo_t<4, 192>(a, g, st) : launch_halo_t<3, 192>(a, g, st);
 }
 
 // Whether tile_cfg 41 / 42 can run this convolution (callers fall back to tile_cfg 31 otherwise): 0 = no, otherwise the number

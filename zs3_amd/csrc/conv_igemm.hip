@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       split_pair<PREC>(S.areg[i][2], S.areg[i][3], h, l); hi[1] = h; lo[1] = l;
       unsigned short* dst = As + (srow + 32 * i) * ROW + q * 4;
       *reinterpret_cast<u32x2*>(dst) = hi;
-      if (PREC == 3) *reinterpret_cast<u32x2*>(dst + 32) = lo;
+      if (PREC >= 3) *reinterpret_cast<u32x2*>(dst + 32) = lo;
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j)
@@ -215,30 +215,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         a_hi[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROW + kk * 16);
-        if (PREC == 3) a_lo[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROW + kk * 16 + 32);
+        if (PREC >= 3) a_lo[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROW + kk * 16 + 32);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         b_hi[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROW + kk * 16);
-        if (PREC == 3) b_lo[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROW + kk * 16 + 32);
+        if (PREC >= 3) b_lo[j] = *reinterpret_cast<const bf16x8*>(Bs + j * 32 * ROW + kk * 16 + 32);
       }
-      if (PREC == 3) {
+      if (PREC >= 3) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<PREC>(a_lo[i], b_hi[j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<PREC>(a_hi[i], b_lo[j], acc[i][j]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<PREC>(a_hi[i], b_hi[j], acc[i][j]);
     }
   };
 
@@ -743,19 +743,27 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       };
       auto read_b = [&](int kk, int j) {
         b_hi[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBh[kk]);
-        if (PREC == 3) b_lo[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBl[kk]);
+        if (PREC >= 3) b_lo[kk][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096 + offBl[kk]);
       };
       auto split_half = [&](int buf, int hp) {   // hp = 2*q + phase: values 2q, 2q+1 of the 8-wide fragment
         const int q = hp >> 1;
         const float a = q == 0 ? r0[0] : q == 1 ? r0[2] : q == 2 ? r1[0] : r1[2];
         const float b = q == 0 ? r0[1] : q == 1 ? r0[3] : q == 2 ? r1[1] : r1[3];
         if ((hp & 1) == 0) {
-          const unsigned h = cvt_pk_bf16(a, b);
-          uh[buf][q] = h;
-          ha = __uint_as_float(h << 16);
-          hb = __uint_as_float(h & 0xFFFF0000u);
+          if constexpr (PREC == 4) {
+            const unsigned h = cvt_pk_f16(a, b);
+            const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
+            uh[buf][q] = h;
+            ha = (float)hv[0];
+            hb = (float)hv[1];
+          } else {
+            const unsigned h = cvt_pk_bf16(a, b);
+            uh[buf][q] = h;
+            ha = __uint_as_float(h << 16);
+            hb = __uint_as_float(h & 0xFFFF0000u);
+          }
         } else {
-          ul[buf][q] = PREC == 3 ? cvt_pk_bf16(a - ha, b - hb) : 0u;
+          ul[buf][q] = PREC == 4 ? cvt_pk_f16(a - ha, b - hb) : PREC == 3 ? cvt_pk_bf16(a - ha, b - hb) : 0u;
         }
       };
       // sub-step s4 of the tile in the current ring slot; fillers prepare sub-step s4+1 (s4 == 3: sub-step 0 of the
@@ -765,12 +773,11 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
         const int nkk = ((s4 + 1) & 3) >> 1, ni = (s4 + 1) & 1;
         const bf16x8 a_hi = __builtin_bit_cast(bf16x8, uh[buf]);
         const bf16x8 a_lo = __builtin_bit_cast(bf16x8, ul[buf]);
-        if (PREC == 3) {
+        if (PREC >= 3) {
 #pragma unroll
           for (int g = 0; g < 12; ++g) {
             const int t = g >> 2, j = g & 3;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? a_lo : a_hi, t == 1 ? b_lo[kk][j] : b_hi[kk][j],
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<PREC>(t == 0 ? a_lo : a_hi, t == 1 ? b_lo[kk][j] : b_hi[kk][j], acc[i][j]);
 #ifndef ZS3_DMA_ABLATE
 #define ZS3_DMA_ABLATE 0
 #endif
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
         } else {
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi[kk][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<PREC>(a_hi, b_hi[kk][j], acc[i][j]);
             if (j == 0) read_a(nkk, ni);
             if (s4 == 0 || s4 == 3) read_b(s4 == 0 ? 1 : 0, j);
             __builtin_amdgcn_sched_barrier(0);
@@ -850,7 +857,7 @@ int launch_dma_prec(const ConvArgs& a, int grid, hipStream_t st) {
 
 int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
   const int grid = ((a.M + 255) / 256) * ((a.ncols + 127) / 128);
-  return prec == 1 ? launch_dma_prec<1>(a, grid, st) : launch_dma_prec<3>(a, grid, st);
+  return prec == 1 ? launch_dma_prec<1>(a, grid, st) : prec == 4 ? launch_dma_prec<4>(a, grid, st) : launch_dma_prec<3>(a, grid, st);
 }
 
 // ZS3_IGEMM_PIPE=3: tile_cfg 11 / 14 on the three-stage branch-free prefetch loop (round 4).  The two-stage loop keeps its loads
@@ -882,6 +889,8 @@ int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, PIPE>), grid, block, 0, st, a);
   else if (prec == 0)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 0, PIPE>), grid, block, 0, st, a);   // exact fp32 (w_pk from zs3_prep_weight_f32)
+  else if (prec == 4)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 4, PIPE>), grid, block, 0, st, a);   // fp16 hi/lo (w_pk prepared with f_fmt = 1)
   else
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 3, PIPE>), grid, block, 0, st, a);
   return ZS3_LAUNCH_CHECK();
@@ -911,7 +920,7 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
                            const float* bs_istd, const float* bs_msc, const float* bs_msh,
                            const unsigned char* bs_mbits, float* bs_partial, const unsigned char* res_mbits, int io,
                            const float* in_scale = nullptr, const float* in_shift = nullptr) {
-  if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 0 && prec != 1 && prec != 3)) return -1;
+  if (cin_pad % 32 != 0 || cin_valid % 4 != 0 || ldx % 4 != 0 || (prec != 0 && prec != 1 && prec != 3 && prec != 4)) return -1;
   if (stride < 1 || (stride & (stride - 1)) != 0 || zero_page == nullptr) return -1;
   if (((uintptr_t)x & 15) || ((uintptr_t)w_pk & 15) || ((uintptr_t)zero_page & 15)) return -2;
   if (bs_partial && (!bs_y || !bs_mean || !bs_istd || (bs_ldy & 3) || (ncols & 3) || (ldy & 3) || (res && (ldr & 3))))

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
   constexpr int STAGE = 2 * ASUB + PW_BSTAGE;
   constexpr int OFF_CT = 2 * STAGE;
   constexpr int OFF_EP = OFF_CT + PW_CTILE;         // (LEPI) BM x PW_LDC floats: the finished tile on its way to the producers
-  constexpr int NL = PREC == 3 ? 2 : 1;
+  constexpr int NL = PREC >= 3 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         split_pair<PREC>(v[2], v[3], h, l); hi[1] = h; lo[1] = l;
         const int o = (((cq >> 1) ^ sw) << 4) + (cq & 1) * 8;
         *reinterpret_cast<u32x2*>(sa + row * 64 + o) = hi;
-        if (PREC == 3) *reinterpret_cast<u32x2*>(sa + row * 64 + (o ^ 32)) = lo;
+        if (PREC >= 3) *reinterpret_cast<u32x2*>(sa + row * 64 + (o ^ 32)) = lo;
       }
       unsigned char* sb = dsm + stage * STAGE + 2 * ASUB;
 #pragma unroll
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     f32x16 acc[TM][TN];
     bf16x8 fa[2][TM][2], fb[2][TN][2];   // [register set][block][hi, lo]
     constexpr int NREAD = (TM + TN) * NL;
-    constexpr int NMF = TM * TN * (PREC == 3 ? 3 : 1);
+    constexpr int NMF = TM * TN * (PREC >= 3 ? 3 : 1);
     constexpr int RS = NMF / NREAD >= 1 ? NMF / NREAD : 1;      // one fragment read every RS MFMAs
     constexpr int RPER = (NREAD + NMF - 1) / NMF;               // (plain bf16: more reads than MFMAs)
     auto read_k = [&](auto setc, auto kc, const unsigned char* st, int sc) {
@@ -456,9 +456,9 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
       auto mf = [&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int pr = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
-        constexpr int ia = PREC == 3 ? (pr == 0 ? 1 : 0) : 0, ib = PREC == 3 ? (pr == 1 ? 1 : 0) : 0;
+        constexpr int ia = PREC >= 3 ? (pr == 0 ? 1 : 0) : 0, ib = PREC >= 3 ? (pr == 1 ? 1 : 0) : 0;
         if (!(ZS3_PW_ABLATE & 2))
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i][ia], fb[SET][j][ib], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<PREC>(fa[SET][i][ia], fb[SET][j][ib], acc[i][j]);
         if constexpr (RPER == 1) {
           if constexpr (m % RS == 0) read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, m / RS>{}, st, sc);
         } else {
@@ -627,6 +627,7 @@ int zs3conv::launch_pw(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   if (!direct_epilogue(a)) {   // residual / accumulate / fused BatchNorm-backward sums: the producers' epilogue
     if (!pw_lepi_ok(a, bm)) return -7;
     if (a.x_bf16 && a.y_bf16) return launch_pw_t<1, 128, false, true, true, true>(a, st);
+    if (prec == 4) return -7;   // f16x3 is the forward arithmetic; loading epilogues belong to data-gradient launches
     if (!a.x_bf16 && !a.y_bf16) return prec == 1 ? launch_pw_t<1, 128, false, false, true, false>(a, st)
                                                  : launch_pw_t<3, 128, false, false, true, false>(a, st);
     return -7;                 // mixed element types (the classifier's data gradient): the register-staged kernels
@@ -634,11 +635,12 @@ int zs3conv::launch_pw(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   if (a.x_bf16) return bm == 256 ? launch_pw_t<1, 256, false, true>(a, st) : launch_pw_t<1, 128, false, true>(a, st);
   if (a.in_scale) {   // input transform (the producing layer's BatchNorm-apply + ReLU) in the producer waves
     if (!a.in_shift) return -1;
-    if (bm == 256) return prec == 1 ? launch_pw_t<1, 256, true>(a, st) : launch_pw_t<3, 256, true>(a, st);
-    return prec == 1 ? launch_pw_t<1, 128, true>(a, st) : launch_pw_t<3, 128, true>(a, st);
+    if (bm == 256)
+      return prec == 1 ? launch_pw_t<1, 256, true>(a, st) : prec == 4 ? launch_pw_t<4, 256, true>(a, st) : launch_pw_t<3, 256, true>(a, st);
+    return prec == 1 ? launch_pw_t<1, 128, true>(a, st) : prec == 4 ? launch_pw_t<4, 128, true>(a, st) : launch_pw_t<3, 128, true>(a, st);
   }
-  if (bm == 256) return prec == 1 ? launch_pw_t<1, 256>(a, st) : launch_pw_t<3, 256>(a, st);
-  return prec == 1 ? launch_pw_t<1, 128>(a, st) : launch_pw_t<3, 128>(a, st);
+  if (bm == 256) return prec == 1 ? launch_pw_t<1, 256>(a, st) : prec == 4 ? launch_pw_t<4, 256>(a, st) : launch_pw_t<3, 256>(a, st);
+  return prec == 1 ? launch_pw_t<1, 128>(a, st) : prec == 4 ? launch_pw_t<4, 128>(a, st) : launch_pw_t<3, 128>(a, st);
 }
 
 // Whether tile_cfg 51 / 52 can run this convolution's GEOMETRY (1x1, stride 1, no padding; callers fall back to tile_cfg 31

@@ -13,9 +13,16 @@ namespace {
 __device__ __forceinline__ long packed_index(long row, long k, long ktot, int half) {
   return ((row * (ktot >> 5) + (k >> 5)) * 2 + half) * 32 + (k & 31);
 }
+// fp16 hi / lo of one value (the forward plane of the f16x3 arithmetic, common.h): both halves round to nearest even
+__device__ __forceinline__ void split_f16(float v, unsigned short& h, unsigned short& l) {
+  const _Float16 hh = (_Float16)v;
+  const _Float16 ll = (_Float16)(v - (float)hh);
+  h = __builtin_bit_cast(unsigned short, hh);
+  l = __builtin_bit_cast(unsigned short, ll);
+}
 __global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ f_pk,
                                    unsigned short* __restrict__ t_pk, int cout, int taps, int cin, int cin_pad,
-                                   int cout_pad) {
+                                   int cout_pad, int f_fmt) {
   const long nf = (long)cout * taps * cin_pad;
   const long nt = t_pk ? (long)cin * taps * cout_pad : 0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nt; i += (long)gridDim.x * blockDim.x) {
@@ -39,9 +46,15 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, unsigned short* 
       dh = t_pk + packed_index(ci, k, ktot, 0);
       dl = t_pk + packed_index(ci, k, ktot, 1);
     }
-    unsigned short h = f32_to_bf16_rne(v);
+    unsigned short h, l;
+    if (f_fmt == 1 && i < nf) {
+      split_f16(v, h, l);
+    } else {
+      h = f32_to_bf16_rne(v);
+      l = f32_to_bf16_rne(v - bf16_bits_to_f32(h));
+    }
     *dh = h;
-    *dl = f32_to_bf16_rne(v - bf16_bits_to_f32(h));
+    *dl = l;
   }
 }
 
@@ -83,7 +96,8 @@ __global__ __launch_bounds__(256) void prep_weight_multi_kernel(const long* __re
   const float* w = reinterpret_cast<const float*>(t[0]);
   unsigned short* f_pk = reinterpret_cast<unsigned short*>(t[1]);
   unsigned short* t_pk = reinterpret_cast<unsigned short*>(t[2]);
-  const int cout = (int)t[3], taps = (int)t[4], cin = (int)t[5], cin_pad = (int)t[6], cout_pad = (int)t[7];
+  const int cout = (int)t[3], taps = (int)(t[4] & 0xffffffffL), f_fmt = (int)(t[4] >> 32), cin = (int)t[5], cin_pad = (int)t[6],
+            cout_pad = (int)t[7];
   const int ngrp = (cin_pad + PREP_CI_GROUP - 1) / PREP_CI_GROUP, nco = cout_pad / 32;
   const int grp = chunk % ngrp; chunk /= ngrp;
   const int cot = chunk % nco;
@@ -116,8 +130,14 @@ __global__ __launch_bounds__(256) void prep_weight_multi_kernel(const long* __re
       const long k = (long)tap * cin_pad + ci;
       unsigned short* dh = f_pk + packed_index(co, k, kf_tot, 0);
       unsigned short* dl = f_pk + packed_index(co, k, kf_tot, 1);
-      *reinterpret_cast<u32x2*>(dh) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-      *reinterpret_cast<u32x2*>(dl) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+      unsigned short fh[4], fl[4];
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        if (f_fmt == 1) split_f16(v[k4], fh[k4], fl[k4]);   // fp16 hi / lo: the forward convolutions' f16x3 operand
+        else { fh[k4] = h[k4]; fl[k4] = l[k4]; }
+      }
+      *reinterpret_cast<u32x2*>(dh) = u32x2{(unsigned)fh[0] | ((unsigned)fh[1] << 16), (unsigned)fh[2] | ((unsigned)fh[3] << 16)};
+      *reinterpret_cast<u32x2*>(dl) = u32x2{(unsigned)fl[0] | ((unsigned)fl[1] << 16), (unsigned)fl[2] | ((unsigned)fl[3] << 16)};
     }
     if (t_pk) {
       __syncthreads();   // previous tile's readers are done
@@ -171,7 +191,20 @@ extern "C" int zs3_prep_weight(const float* w, void* f_pk, void* t_pk, int cout,
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) return 0;
   hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)f_pk,
-                     (unsigned short*)t_pk, cout, taps, cin, cin_pad, cout_pad);
+                     (unsigned short*)t_pk, cout, taps, cin, cin_pad, cout_pad, 0);
+  return ZS3_LAUNCH_CHECK();
+}
+
+// The planes of a layer whose FORWARD runs f16x3 (prec = 4 of zs3_conv_igemm): forward plane fp16 hi / lo, transposed (data-
+// gradient) plane bf16 hi / lo as above.
+extern "C" int zs3_prep_weight_f16fwd(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad,
+                                      int cout_pad, void* stream) {
+  long total = (long)cout * taps * cin_pad + (t_pk ? (long)cin * taps * cout_pad : 0);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)f_pk,
+                     (unsigned short*)t_pk, cout, taps, cin, cin_pad, cout_pad, 1);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -71,17 +71,29 @@ def join_wgrad_stream():
 _planes = {}
 
 
-def weight_planes(w, need_t=True):
-    """bf16 hi/lo planes of a parameter, recomputed only when the parameter changed (optimizer step,
-    load_state_dict): keyed on (storage pointer, autograd version counter)."""
+def forward_is_f16x3(prec, bn):
+    """Does this fused layer's forward convolution run f16x3 (fp16 hi/lo operands, prec 4)?  Under the default three-product
+    arithmetic, when the layer normalises with BATCH statistics: then its input is the output of a batch-normalised layer (or the
+    image) -- O(1) by construction, inside fp16's exponent range -- and this is the mode whose conditioning needs the 2^-22
+    products.  Eval-mode / frozen BatchNorm and layers without one keep bf16x3 forward products: an
+    untrained network in eval() mode lets activations grow to 1e4 and beyond (running statistics 0 / 1 normalise nothing), which
+    fp16 cannot hold, and eval mode is well-conditioned anyway (logits 3e-5 from the reference)."""
+    return bool(ops.fwd_f16() and prec in (None, 3, 4) and bn is not None and bn["training"])
+
+
+def weight_planes(w, need_t=True, f16=False):
+    """hi/lo planes of a parameter, recomputed only when the parameter changed (optimizer step,
+    load_state_dict): keyed on (storage pointer, autograd version counter).  f16: the forward plane as fp16 hi/lo (the layer's
+    forward launches run prec 4, `forward_is_f16x3`); the data-gradient plane is bf16 hi/lo either way."""
     key = id(w)
-    ver = (w.data_ptr(), w._version, tuple(w.shape), need_t)
+    fmt = 1 if f16 else 0
+    ver = (w.data_ptr(), w._version, tuple(w.shape), need_t, fmt)
     hit = _planes.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is w:
         return hit[1]
-    if hit is not None and hit[0][:3] == ver[:3] and hit[0][3] and not need_t and hit[2]() is w:
+    if hit is not None and hit[0][:3] == ver[:3] and hit[0][3] and not need_t and hit[0][4] == fmt and hit[2]() is w:
         return hit[1]
-    wp = ops.prep_weight(w, need_t=need_t)
+    wp = ops.prep_weight(w, need_t=need_t, f16_forward=bool(fmt))
     _planes[key] = (ver, wp, weakref.ref(w, lambda _r, k=key: _planes.pop(k, None)))
     return wp
 
@@ -172,13 +184,14 @@ def refresh_planes(*params):
     if not todo:
         return
     dev = todo[0][0].device
-    key = (dev.index,) + tuple((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr()) for w, wp, _ in todo)
+    key = (dev.index,) + tuple((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr(), wp.f_fmt) for w, wp, _ in todo)
     tab = _refresh_tables.get(dev.index)
     if tab is None or tab[0] != key:
         recs, bmap = [], []
         for e, (w, wp, _) in enumerate(todo):
             taps = wp.kh * wp.kw
-            recs.append((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr(), wp.cout, taps, wp.cin, wp.cin_pad, wp.cout_pad))
+            recs.append((w.data_ptr(), wp.f_pk.data_ptr(), wp.t_pk.data_ptr(), wp.cout, taps | ((1 << 32) if wp.f_fmt == 1 else 0),
+                         wp.cin, wp.cin_pad, wp.cout_pad))   # bit 32 of the taps word: forward plane as fp16 hi/lo
             bmap.extend((e, c) for c in range(ops.lib().zs3_prep_chunks(ops.I(wp.cout_pad), ops.I(taps), ops.I(wp.cin_pad))))
         table = torch.tensor(recs, dtype=torch.int64).to(dev)
         blockmap = torch.tensor(bmap, dtype=torch.int32).to(dev)
@@ -187,7 +200,7 @@ def refresh_planes(*params):
     ops.check(ops.lib().zs3_prep_weight_multi(ops.P(tab[1]), ops.P(tab[2]), ops.I(tab[3]), ops.stream()),
               "zs3_prep_weight_multi")
     for w, wp, ref in todo:
-        _planes[id(w)] = ((w.data_ptr(), w._version, tuple(w.shape), True), wp, ref)
+        _planes[id(w)] = ((w.data_ptr(), w._version, tuple(w.shape), True, 1 if wp.f_fmt == 1 else 0), wp, ref)
 
 
 # ---------------------------------------------------------------------------------- RNG for dropout
@@ -263,13 +276,13 @@ class _ConvBnAct(torch.autograd.Function):
         require_gpu(x, weight)
         x = _dense_rows(x)
         need_grad = cfg.get("need_grad", True)  # grad mode is always off inside Function.forward: decided by the caller
-        wp = weight_planes(weight, need_t=True)
+        bn = cfg.get("bn")
+        wp = weight_planes(weight, need_t=True, f16=forward_is_f16x3(cfg.get("prec"), bn))
         stride, pad, dil, act = cfg["stride"], cfg["pad"], cfg["dil"], cfg["act"]
         geom = cfg.get("geom")  # explicit (n,h,w,ldx,...) for the stem's overlapping-window view
-        bn = cfg.get("bn")
         out = cfg.get("out")
         leak = cfg.get("leak", 0.2)
-        prec = cfg.get("prec")
+        prec = 4 if wp.f_fmt == 1 else cfg.get("prec")    # forward products: f16x3 where the plane was prepared for it
         drop = cfg.get("drop")   # (p, seed): nn.Dropout behind this layer's activation, fused into affine_act / bn_act_bwd
         y = a = st = mbits = None
         in_aff = cfg.get("in_affine")   # x is the RAW conv output of the producing layer: its BN-apply + ReLU runs in our producers
@@ -355,7 +368,7 @@ class _ConvBnAct(torch.autograd.Function):
         leak, prec, geom = cfg.get("leak", 0.2), cfg.get("prec"), cfg.get("geom")
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dA = _dense_rows(dA)
-        wp = weight_planes(weight, need_t=True)
+        wp = weight_planes(weight, need_t=True, f16=forward_is_f16x3(prec, cfg.get("bn")))   # (the forward's planes: no re-split)
         dgamma = dbeta = dbias = dres = None
         lazy = ctx.lazy_dres and ctx.has_bn and ctx.needs_input_grad[5] and ops._rows(dA)[2] == dA.shape[-1]
         if ctx.has_res and ctx.needs_input_grad[5] and not lazy:
@@ -556,9 +569,10 @@ def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
     hit = _defer_choice.get(key)
     if hit is None:
         nw = next_conv.weight
+        f16 = bool(ops.fwd_f16() and prec in (None, 3, 4))   # (asked by a layer that normalises with batch statistics: its consumer does too)
         hit = _defer_choice[key] = bool(
             nw.dim() == 4 and next_conv.bias is None and nw.shape[1] == cout and cout % 4 == 0 and
-            ops.consumer_applies_bn(oshape, cout, weight_planes(nw, need_t=True), next_conv.stride[0], next_conv.padding[0],
+            ops.consumer_applies_bn(oshape, cout, weight_planes(nw, need_t=True, f16=f16), next_conv.stride[0], next_conv.padding[0],
                                     next_conv.dilation[0], prec))
     return hit
 
