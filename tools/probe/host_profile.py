@@ -25,3 +25,29 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(steps): step()
 pr.disable(); torch.cuda.synchronize()
 st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+
+# ---- the backward pass runs in the autograd engine's device thread, which the profile above does not see: a second profiler
+# is switched on INSIDE every fused layer's backward (cProfile profiles the calling thread), so its table is the python time of
+# the backward functions themselves (engine overhead between nodes excluded)
+from zs3_amd import functional as Fz
+prb = cProfile.Profile()
+orig = Fz._ConvBnAct.backward
+import time
+spent = [0.0, 0]
+def wrapped(ctx, *a):
+    t0 = time.perf_counter()
+    prb.enable()
+    try:
+        return orig(ctx, *a)
+    finally:
+        prb.disable()
+        spent[0] += time.perf_counter() - t0; spent[1] += 1
+Fz._ConvBnAct.backward = staticmethod(wrapped)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps): step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print(f"\n==== backward of the fused layers: {spent[1] // steps} nodes per step, {1e3 * spent[0] / steps:.2f} ms per step inside them (profiled); "
+      f"whole step host {1e3 * (t1 - t0) / steps:.2f} ms")
+pstats.Stats(prb).sort_stats("tottime").print_stats(30)

@@ -32,8 +32,21 @@ namespace {
 // A16: x is stored as bf16 (plain-bf16 products only): written to LDS as it arrives.  KS = 64 (A16 only): a K step is 64 channels
 // -- the LDS row's lo half holds channels 32..63 instead of a lo plane, a lane moves 16 bytes = 8 channels per row and only the
 // hi halves of two weight chunks -- so one barrier covers twice the MFMAs (the plain-bf16 K loop is latency-, not MFMA-bound).
+// Waves per SIMD the register allocation must leave room for (second __launch_bounds__ argument).  A 256-thread workgroup is one
+// wave per SIMD, so this is the number of workgroups a CU can hold: with short K loops (the 1x1 layers: 4-16 K steps) the only
+// thing that hides a tile's load latency and epilogue is ANOTHER workgroup's K loop.  hipcc left to itself allocates 136 registers
+// for the 64 x 64 tile (3 per CU) and 276 for the 128 x 128 tile on bf16-stored input with 64-channel steps (1 per CU).
+#ifndef ZS3_IGEMM_WPE64
+#define ZS3_IGEMM_WPE64 4
+#endif
+#ifndef ZS3_IGEMM_WPE128A16
+#define ZS3_IGEMM_WPE128A16 2
+#endif
+constexpr int igemm_wpe(int bm, int bn, int prec, int pipe, bool a16) {
+  return (bm == 64 && bn == 64 && prec != 0) ? ZS3_IGEMM_WPE64 : (bm == 128 && bn == 128 && a16 && pipe <= 2) ? ZS3_IGEMM_WPE128A16 : 1;
+}
 template <int BM, int BN, int PREC, int PIPE, bool A16 = false, int KS = 32>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, igemm_wpe(BM, BN, PREC, PIPE, A16)) void conv_igemm_kernel(const ConvArgs p) {
   static_assert(!A16 || PREC == 1, "bf16-stored input: plain bf16 products only");
   static_assert(KS == 32 || (KS == 64 && A16), "64-channel K steps: bf16-stored input only");
   constexpr int CPL = KS / 8;                                    // channels per lane and row: 8 lanes walk a row's K step
@@ -348,6 +361,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
   // ---- epilogue 1: per-channel partial sums of the raw conv output (BatchNorm batch statistics)
   if (p.stat_partial) {
+    // The sums are staged in the first bytes of LDS stage 0, and the multi-stage loops peel their last K step(s) WITHOUT a closing
+    // barrier: when the last step's operands sit in stage 0 (an odd step count: the 7-tap stem; with 64-channel steps every
+    // 64-channel 1x1 / 3x3 layer of layer 1) a fast wave would overwrite operands a slow wave is still multiplying.  Round 4 found
+    // it twice: the stem's output came out as zeros under the three-stage loop, and the 2-byte mode's step was not
+    // bit-reproducible (tools/probe/determinism.py; NaN-poisoned allocations, tools/probe/nanfill.py, put the first bad tensor at
+    // layer1.0.conv1, a ONE-step launch).  One barrier per tile; the launch-side routing of odd step counts to the one-stage loop
+    // that stood in for it is gone.
+    __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [wm][{sum,sumsq}][BN]; tiles are no longer read
     float s[TN], q[TN];
 #pragma unroll
@@ -865,7 +886,7 @@ int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
 // issued before every LDS write, i.e. no prefetch inside one workgroup; PIPE 3 fixes that (counted waits, 24 loads in flight).
 // Inside the training step it buys nothing: 45.5-45.7 ms against 44.9-45.1 for PIPE 2, same box (tools/probe/r4v.sh) -- two to four
 // resident workgroups per CU already cover each other's latency.  (The first A/B of this switch showed 43.5 against 46.0 ms: that
-// build's stem raced -- see lone_tail in conv_igemm_impl -- its output was zero, and a network of zeros runs every kernel 10-45 %
+// build's stem raced -- see the barrier in front of epilogue 1 -- its output was zero, and a network of zeros runs every kernel 10-45 %
 // faster on this chip.  bench.py prints the last loss since.)  Default: PIPE 2.
 static bool pipe3() {
   static const bool v = getenv("ZS3_IGEMM_PIPE") && atoi(getenv("ZS3_IGEMM_PIPE")) == 3;
@@ -955,15 +976,6 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     cfg = bn == 128 ? (small ? 3 : 1) : (small ? 4 : 2);
   }
   if (in_scale && cfg != 41 && cfg != 42 && cfg != 51 && cfg != 52) return -7;   // only the producer-converting kernels transform x
-  // The multi-stage loops of the register-staged kernel peel their last K step(s) without a closing barrier, and the BatchNorm
-  // sums of the epilogue are staged in the first bytes of LDS stage 0: when the LAST step sits in stage 0 (an odd step count
-  // that is not a multiple of the unroll: the 7-tap stem) a fast wave can overwrite operands a slow wave is still multiplying.
-  // Found in round 4 with the three-stage loop, where the stem's output came out as zeros (a test failure that depended on
-  // what had run before it); the two-stage loop has the same window for odd step counts.  Such launches take the one-stage
-  // loop, where every K step ends with a barrier.  (Same-box A/B runs of kernel-side fixes looked 3 ms per step SLOWER than the
-  // racy build -- because the racy build's network was dead and a dead network is fast: tools/probe/r4r.sh .. r4v.sh.)
-  const int kt_steps = KH * KW * (cin_pad / 32);
-  const bool lone_tail = stat_partial != nullptr && (kt_steps & 1) && !a.x_bf16;
   if (prec == 0 && cfg > 14) return -7;   // the exact-fp32 test mode exists on the register-staged kernel only
   if (a.x_bf16 && cfg == 31) return -7;   // the LDS-DMA kernel moves raw fp32 rows
   switch (cfg) {
@@ -971,13 +983,10 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 2: return launch_cfg<128, 64, 1>(a, prec, st);
     case 3: return launch_cfg<64, 128, 1>(a, prec, st);
     case 4: return launch_cfg<64, 64, 1>(a, prec, st);
-    // (lone_tail: see below -- such launches take the one-stage loop, which ends every K step with a barrier)
-    case 11: return lone_tail ? launch_cfg<128, 128, 1>(a, prec, st)
-                    : pipe3() && prec != 0 ? launch_cfg<128, 128, 3>(a, prec, st) : launch_cfg<128, 128, 2>(a, prec, st);
-    case 12: return lone_tail ? launch_cfg<128, 64, 1>(a, prec, st) : launch_cfg<128, 64, 2>(a, prec, st);
-    case 13: return lone_tail ? launch_cfg<64, 128, 1>(a, prec, st) : launch_cfg<64, 128, 2>(a, prec, st);
-    case 14: return lone_tail ? launch_cfg<64, 64, 1>(a, prec, st)
-                    : pipe3() && prec != 0 ? launch_cfg<64, 64, 3>(a, prec, st) : launch_cfg<64, 64, 2>(a, prec, st);
+    case 11: return pipe3() && prec != 0 ? launch_cfg<128, 128, 3>(a, prec, st) : launch_cfg<128, 128, 2>(a, prec, st);
+    case 12: return launch_cfg<128, 64, 2>(a, prec, st);
+    case 13: return launch_cfg<64, 128, 2>(a, prec, st);
+    case 14: return pipe3() && prec != 0 ? launch_cfg<64, 64, 3>(a, prec, st) : launch_cfg<64, 64, 2>(a, prec, st);
     case 31: return launch_dma(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);

@@ -41,6 +41,42 @@ _side_next = {}
 _join_armed = [False]
 
 
+# torch.cuda.current_stream() / `with torch.cuda.stream(s)` / Stream.wait_stream() spend 9-15 us each in device-index bookkeeping
+# and fresh Event objects; a weight-gradient launch used all three (4 ms of host time per training step, measured with
+# tools/probe/host_profile.py -- the 2-byte mode's step is host-bound).  The same calls on the raw bindings:
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+_raw_current = getattr(torch._C, "_cuda_getCurrentStream", None)
+_raw_set = getattr(torch._C, "_cuda_setStream", None)
+_stream_objs = {}      # (stream_id, device_index, device_type) -> torch.cuda.Stream
+_fork_events = {}      # id(side stream) -> the Event that carries "main has produced dy / x" over to it
+
+
+def _current_stream():
+    if _raw_current is None or _raw_device is None:
+        return torch.cuda.current_stream()
+    sd = _raw_current(_raw_device())
+    s = _stream_objs.get(sd)
+    if s is None:
+        s = _stream_objs[sd] = torch.cuda.Stream(stream_id=sd[0], device_index=sd[1], device_type=sd[2])
+    return s
+
+
+def _set_stream(s):
+    if _raw_set is None:
+        torch.cuda.set_stream(s)
+    else:
+        _raw_set(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+
+
+def _wait_for(waiter, producer):
+    """waiter.wait_stream(producer) with a reused Event (a wait refers to the record before it: re-recording later is safe)"""
+    ev = _fork_events.get(id(waiter))
+    if ev is None:
+        ev = _fork_events[id(waiter)] = torch.cuda.Event()
+    ev.record(producer)
+    waiter.wait_event(ev)
+
+
 def wgrad_streams(device):
     key = device.index
     if key not in _side:
@@ -474,13 +510,16 @@ class _ConvBnAct(torch.autograd.Function):
             side = wgrad_stream(dy.device) if (WGRAD_SIDE_STREAM and geom is None and (
                 CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())) else None
             if side is not None:
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)          # dy (and x) are ready on the main stream
+                main = _current_stream()
+                _wait_for(side, main)           # dy (and x) are ready on the main stream
                 dy.record_stream(side)          # keep their memory from being recycled while the side stream reads it
                 x.record_stream(side)
-                with torch.cuda.stream(side):
+                _set_stream(side)
+                try:
                     dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec,
                                           out=_bucket_out(weight, wp), x_affine=ctx.x_affine)
+                finally:
+                    _set_stream(main)
                 dw.record_stream(main)
                 first_side = _wgrad_side_of.get(id(weight))
                 if first_side is not None:
