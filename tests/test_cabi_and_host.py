@@ -259,3 +259,51 @@ def test_bench_refuses_to_run_without_the_devices_it_was_asked_for():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def test_io_argument_sits_before_the_stream_on_every_activation_entry_point():
+    """Round 4, the 2-byte mode at the C ABI: every entry point whose tensors are activations carries `int io` as its last
+    argument before `void* stream` (bit 0: inputs are bf16, bit 1: outputs are); entry points that only see fp32 state
+    (optimizers, finalizes, weight preparation, losses on fp32 class scores) do not."""
+    header = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "zs3hip.h")).read(), flags=re.S)
+    sigs = {name: [a.strip() for a in args.split(",")] for _, name, args in
+            re.findall(r"\b(int|long)\s+(zs3_\w+)\s*\(([^)]*)\)\s*;", header)}
+    with_io = {n for n, a in sigs.items() if len(a) >= 2 and a[-1] == "void* stream" and a[-2] == "int io"}
+    for name in ("zs3_conv_igemm", "zs3_conv_igemm_in", "zs3_conv_igemm_bnstats", "zs3_conv_wgrad", "zs3_conv_wgrad_strip",
+                 "zs3_conv_wgrad_pw", "zs3_affine_act", "zs3_bn_act_bwd", "zs3_bn_bwd_stats", "zs3_maxpool_fwd", "zs3_maxpool_bwd",
+                 "zs3_bilinear_fwd", "zs3_bilinear_bwd", "zs3_sum_n", "zs3_group_colsum", "zs3_colstats", "zs3_dropout"):
+        assert name in with_io, name
+    assert len(with_io) == 17
+    for name in ("zs3_sgd_multi", "zs3_adam_step", "zs3_bn_fwd_finalize", "zs3_bn_bwd_finalize", "zs3_prep_weight",
+                 "zs3_prep_weight_f16fwd", "zs3_prep_weight_f32", "zs3_mmd_fwd"):
+        assert name in sigs and name not in with_io, name
+    assert "#define ZS3_IO_IN16 1" in open(os.path.join(ROOT, "include", "zs3hip.h")).read()
+
+
+def test_forward_arithmetic_rule_and_loss_log():
+    """Host logic of round 4 that needs no GPU: (1) which fused layers multiply f16x3 in their forward pass -- batch-statistics
+    BatchNorm under the default arithmetic and fp32 storage, nothing else (functional.forward_is_f16x3); (2) LossLog hands every
+    loss value back exactly once, in order, one push late."""
+    from zs3_amd import functional as Fz, ops
+    from zs3_amd.base_trainer import LossLog
+    train, frozen = {"training": True}, {"training": False}
+    assert ops.PREC_DEFAULT == 3 and ops.ACT_DTYPE == torch.float32
+    assert Fz.forward_is_f16x3(None, train) and Fz.forward_is_f16x3(3, train)
+    assert not Fz.forward_is_f16x3(None, frozen) and not Fz.forward_is_f16x3(None, None) and not Fz.forward_is_f16x3(1, train)
+    old = ops.FWD_F16
+    try:
+        ops.FWD_F16 = False
+        assert not Fz.forward_is_f16x3(None, train)
+        ops.FWD_F16 = True
+        ops.PREC_DEFAULT = 1
+        assert not Fz.forward_is_f16x3(None, train)          # plain-bf16 products: nothing to split
+        ops.PREC_DEFAULT = 0
+        assert not Fz.forward_is_f16x3(None, train)          # exact-fp32 test mode
+    finally:
+        ops.FWD_F16, ops.PREC_DEFAULT = old, 3
+    log, seen = LossLog(), []
+    for i in range(7):
+        seen.extend(log.push(torch.tensor(float(i))))
+        assert [k for k, _ in seen] == list(range(max(0, i))) or [k for k, _ in seen] == list(range(i + 1))
+    seen.extend(log.flush())
+    assert seen == [(i, float(i)) for i in range(7)] and log.flush() == []
