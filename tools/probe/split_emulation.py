@@ -65,7 +65,8 @@ def rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def main():
+def evaluate(modes):
+    """[(name, forward split, backward split)] -> (reference's own errors, [(name, errors vs fp64, logits vs goldens)])"""
     g = np.load(os.path.join(ROOT, "tests", "golden", "deeplab_forward.npz"))
     torch.manual_seed(1)
     m = DeepLab(num_classes=21, pretrained=False)
@@ -82,16 +83,8 @@ def main():
     zo.SegmentationLosses(weight=w.double()).build_loss("ce")(r64, b["label"]).backward()
     gold, gp, gs = torch.from_numpy(g["train_logits"]), torch.from_numpy(g["grad_pred_w"]), torch.from_numpy(g["grad_stem_w"])
     e_ref = (rel(gold, r64), rel(gp, ref64.decoder.pred_conv.weight.grad), rel(gs, ref64.backbone.conv1.weight.grad[:8]))
-    print(f"reference fp32 (goldens) vs fp64: logits {e_ref[0]:.2e}, classifier gradient {e_ref[1]:.2e}, stem gradient {e_ref[2]:.2e}")
     plain = nn.Conv2d._conv_forward
-    bf, fh = torch.bfloat16, torch.float16
-    modes = [("plain fp32 convolutions (this CPU's summation order)", None, None),
-             ("bf16 hi/lo x3, forward and backward (the product's bf16x3)", (bf, False), (bf, False)),
-             ("fp16 hi/lo x3 forward (unscaled), bf16 hi/lo x3 backward", (fh, False), (bf, False)),
-             ("fp16 hi/lo x3 forward (unscaled) and backward (power-of-two scale per tensor)", (fh, False), (fh, True)),
-             ("fp16 hi/lo x3 forward and backward, both with a power-of-two scale per tensor", (fh, True), (fh, True))]
-    print("| arithmetic of the 114 convolutions | logits vs fp64 (x reference) | classifier gradient (x reference) | stem gradient (x reference) | logits vs goldens |")
-    print("|---|---|---|---|---|")
+    results = []
     for name, fwd, bwd in modes:
         MODE["fwd"], MODE["bwd"] = fwd, bwd
         net = copy.deepcopy(ref).train()
@@ -103,7 +96,25 @@ def main():
             nn.Conv2d._conv_forward = plain
         e = (rel(out, r64), rel(net.decoder.pred_conv.weight.grad, ref64.decoder.pred_conv.weight.grad),
              rel(net.backbone.conv1.weight.grad[:8], ref64.backbone.conv1.weight.grad[:8]))
-        print(f"| {name} | {e[0]:.2e} ({e[0] / e_ref[0]:.1f}x) | {e[1]:.2e} ({e[1] / e_ref[1]:.1f}x) | {e[2]:.2e} ({e[2] / e_ref[2]:.1f}x) | {rel(out, gold):.2e} |")
+        results.append((name, e, rel(out, gold)))
+    return e_ref, results
+
+
+BF, FH = torch.bfloat16, torch.float16
+MODES = [("plain fp32 convolutions (this CPU's summation order)", None, None),
+         ("bf16 hi/lo x3, forward and backward (the product's bf16x3)", (BF, False), (BF, False)),
+         ("fp16 hi/lo x3 forward (unscaled), bf16 hi/lo x3 backward", (FH, False), (BF, False)),
+         ("fp16 hi/lo x3 forward (unscaled) and backward (power-of-two scale per tensor)", (FH, False), (FH, True)),
+         ("fp16 hi/lo x3 forward and backward, both with a power-of-two scale per tensor", (FH, True), (FH, True))]
+
+
+def main():
+    e_ref, results = evaluate(MODES)
+    print(f"reference fp32 (goldens) vs fp64: logits {e_ref[0]:.2e}, classifier gradient {e_ref[1]:.2e}, stem gradient {e_ref[2]:.2e}")
+    print("| arithmetic of the 114 convolutions | logits vs fp64 (x reference) | classifier gradient (x reference) | stem gradient (x reference) | logits vs goldens |")
+    print("|---|---|---|---|---|")
+    for name, e, vs_gold in results:
+        print(f"| {name} | {e[0]:.2e} ({e[0] / e_ref[0]:.1f}x) | {e[1]:.2e} ({e[1] / e_ref[1]:.1f}x) | {e[2]:.2e} ({e[2] / e_ref[2]:.1f}x) | {vs_gold:.2e} |")
 
 
 if __name__ == "__main__":
