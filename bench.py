@@ -230,6 +230,8 @@ def main():
         return fn
 
     def gmmn_report(gstep, steps):
+        from zs3_amd import gmmn_trainer as _gt
+        NL = 6 if _gt.PREP_IN_FWD1 else 7      # launches of one generator update (zs3_gmmn_mlp_fwd1_table merges the first two)
         """configs[2]: the GMMN step as a first-class line -- images/s over `steps` timed steps plus where the time goes:
         the frozen-backbone feature pass (timed alone with HIP events) and the per-(image, class) generator updates."""
         gdt, _ = run(gstep, steps, 2)
@@ -258,11 +260,11 @@ def main():
                 "roofline": {
                     "backbone_forward": {"bound": "mfma", "achieved": args.batch * FWD_GFLOP_PER_IMG.get(args.classes, 185.64) / fwd_ms, "peak": PEAK_BF16_TF,
                                          "unit": "TFLOP/s", "frac": args.batch * FWD_GFLOP_PER_IMG.get(args.classes, 185.64) / fwd_ms / PEAK_BF16_TF},
-                    "generator_update": {"bound": "launch latency", "launches_per_update": 7,
+                    "generator_update": {"bound": "launch latency", "launches_per_update": NL,
                                          "us_per_update": (1e3 * (step_ms - fwd_ms) / upd) if upd else None,
-                                         "launch_floor_us": 7 * LAUNCH_BOUNDARY_US,
-                                         "frac_of_floor": (7 * LAUNCH_BOUNDARY_US / (1e3 * (step_ms - fwd_ms) / upd)) if upd else None,
-                                         "note": "floor = 7 dependent kernel boundaries x 1.45 us (MI355X_MICROARCH.md, "
+                                         "launch_floor_us": NL * LAUNCH_BOUNDARY_US,
+                                         "frac_of_floor": (NL * LAUNCH_BOUNDARY_US / (1e3 * (step_ms - fwd_ms) / upd)) if upd else None,
+                                         "note": f"floor = {NL} dependent kernel boundaries x 1.45 us (MI355X_MICROARCH.md, "
                                                  "'boundary' row: eager = hipGraph); the per-update figure also carries the "
                                                  "classifier's CE / SGD launches of the step"}}}
 

@@ -276,6 +276,15 @@ int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, const long*
                       int kchunks, const float* bias, float* x_out, int ldx, float* h, float* hd, int ldo, int M, int N,
                       float leak, float p_drop, unsigned long long seed_noise, unsigned long long seed_drop,
                       const void* seed_dev, void* stream);
+/* zs3_gmmn_prep + zs3_gmmn_mlp_fwd1 in ONE launch (round 4: six launches per generator update instead of seven): every workgroup of
+ * the first GEMM reads its sample indices from the update's table row itself (two dependent index loads ahead of its operand
+ * burst instead of a kernel boundary), the workgroups of the first column tile publish pix_global / key, workgroup 0 the Adam
+ * bias corrections.  Same draws, same results as the two-launch form (tests/test_gpu_gmmn_kernels.py). */
+int zs3_gmmn_mlp_fwd1_table(const long* table, int ld_table, const void* upd_dev, const long* order, const float* emb, int ld_emb,
+                            int Ca, int Cb, const void* w_pk, int kchunks, const float* bias, float* x_out, int ldx, float* h,
+                            float* hd, int ldo, int S, int N, float leak, float p_drop, unsigned long long seed_noise,
+                            unsigned long long seed_drop, const void* seed_dev, long* pix_global, long* key,
+                            const void* adam_step_dev, float b1, float b2, float* adam_bc, void* stream);
 int zs3_gmmn_mlp_fwd2(const float* hd, int lda, const void* w_pk, int kchunks, const float* bias, float* gen, int ldo, int M,
                       int N, int K, const float* real, int ld_real, const long* gidx, float* real_out, void* stream);
 int zs3_gmmn_mlp_dgrad(const float* dgen, int lda, const void* wt_pk, int kchunks, const float* h, int ldh, const long* key,

@@ -56,6 +56,17 @@ struct MlpArgs {
   float leak, p_drop;
   unsigned long long seed_noise, seed_drop;
   const unsigned long long* seed_dev;
+  // FWD1, table-driven (zs3_gmmn_mlp_fwd1_table: the work of gmmn_prep_kernel inside this launch): row u = upd[0] of `table`
+  // ([S sample indices | order offset | pixel base]) selects the update's (image, class); pix / key above are ignored
+  const long* table;
+  const long* upd;
+  const long* order;
+  long* pix_out;             // [S] row of the real features of every sample (FWD2's gather list)
+  long* key_out;             // [S] the sample indices as a plain array (DGRAD's dropout keys)
+  const long* adam_step;
+  float* adam_bc;
+  float b1, b2;
+  int ld_table, S;
 };
 
 constexpr int MLP_BM = 32, MLP_BN = 16, MLP_MAXCH = 20;   // <= 640 reduction elements per call
@@ -98,7 +109,24 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const MlpArgs p) {
     if (wok && piece < b16) bv[u] = *reinterpret_cast<const u32x4*>(wrow + piece * 8);
   }
   const float* arow = nullptr;
-  if (am < p.M)   // FWD1 without a row list reads row am itself (x already assembled by zs3_gmmn_prep: no dependent index load)
+  const long* keys = p.key;
+  if (MODE == MLP_FWD1 && p.table) {   // table-driven: the update's row of the step's device table holds the sample indices
+    const long* row = p.table + p.upd[0] * p.ld_table;
+    keys = row;
+    if (am < p.M) {
+      const long pixg = row[p.S + 1] + p.order[row[p.S] + row[am]];
+      arow = p.emb + pixg * p.ld_emb;
+      if (nbk == 0 && aq == 0) {
+        p.pix_out[am] = pixg;
+        p.key_out[am] = row[am];
+      }
+    }
+    if (p.adam_bc && blockIdx.x == 0 && tid == 0) {   // Adam's bias corrections of THIS update (torch: 1 - beta ** step in doubles)
+      const double st = (double)(p.adam_step[0] + 1);
+      p.adam_bc[0] = (float)(1.0 - pow((double)p.b1, st));
+      p.adam_bc[1] = (float)sqrt(1.0 - pow((double)p.b2, st));
+    }
+  } else if (am < p.M)   // FWD1 without a row list reads row am itself (x already assembled by zs3_gmmn_prep: no dependent index load)
     arow = MODE == MLP_FWD1 ? p.emb + (p.pix ? p.pix[am] : (long)am) * p.ld_emb : p.a + (size_t)am * p.lda;
   const int alim = MODE == MLP_FWD1 ? p.Ca : p.K;
 #pragma unroll
@@ -112,7 +140,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const MlpArgs p) {
     for (int u = 0; u < MAXA; ++u) {
       const int c = (aq + 8 * u) * 4;
       if (c >= p.Ca && c < p.Ca + p.Cb) {
-        const unsigned long long base = (unsigned long long)(p.key[am] * p.Cb + (c - p.Ca));
+        const unsigned long long base = (unsigned long long)(keys[am] * p.Cb + (c - p.Ca));
 #pragma unroll
         for (int e = 0; e < 4; ++e) av[u][e] = u01(s_noise, base + e);
       }
@@ -180,7 +208,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(const MlpArgs p) {
   for (int e = 0; e < 4; ++e) {
     const int m = m0 + rf * 16 + kg * 4 + e;   // C layout of the 16x16 MFMA: row = (lane >> 4) * 4 + e, col = lane & 15
     const int mc = m < p.M ? m : 0;
-    key_v[e] = masks ? p.key[mc] : 0;
+    key_v[e] = masks ? keys[mc] : 0;
     h_v[e] = MODE == MLP_DGRAD ? p.h[(size_t)mc * p.ldh + col] : 0.f;
   }
 #pragma unroll
@@ -485,6 +513,26 @@ extern "C" int zs3_gmmn_mlp_fwd1(const float* emb, int ld_emb, const long* pix, 
   a.kchunks = kchunks; a.emb = emb; a.pix = pix; a.key = key; a.x_out = x_out; a.ld_emb = ld_emb; a.Ca = Ca; a.Cb = Cb;
   a.ldx = ldx; a.leak = leak; a.p_drop = p_drop; a.seed_noise = seed_noise; a.seed_drop = seed_drop;
   a.seed_dev = (const unsigned long long*)seed_dev;
+  return launch_mlp<MLP_FWD1>(a, (hipStream_t)stream);
+}
+
+extern "C" int zs3_gmmn_mlp_fwd1_table(const long* table, int ld_table, const void* upd_dev, const long* order, const float* emb,
+                                       int ld_emb, int Ca, int Cb, const void* w_pk, int kchunks, const float* bias, float* x_out,
+                                       int ldx, float* h, float* hd, int ldo, int S, int N, float leak, float p_drop,
+                                       unsigned long long seed_noise, unsigned long long seed_drop, const void* seed_dev,
+                                       long* pix_global, long* key, const void* adam_step_dev, float b1, float b2, float* adam_bc,
+                                       void* stream) {
+  if (S <= 0 || N <= 0) return 0;
+  if ((Ca & 3) || (Cb & 3) || (ld_emb & 3) || (ldx & 3) || Ca + Cb > kchunks * 32 || (x_out && ldx > kchunks * 32) || ld_table < S + 2 ||
+      !table || !upd_dev || !order || !pix_global || !key || (adam_bc && !adam_step_dev))
+    return -1;
+  MlpArgs a = {};
+  a.w = (const unsigned short*)w_pk; a.bias = bias; a.out = h; a.out2 = hd; a.ldo = ldo; a.M = S; a.N = N; a.K = Ca + Cb;
+  a.kchunks = kchunks; a.emb = emb; a.x_out = x_out; a.ld_emb = ld_emb; a.Ca = Ca; a.Cb = Cb;
+  a.ldx = ldx; a.leak = leak; a.p_drop = p_drop; a.seed_noise = seed_noise; a.seed_drop = seed_drop;
+  a.seed_dev = (const unsigned long long*)seed_dev;
+  a.table = table; a.ld_table = ld_table; a.upd = (const long*)upd_dev; a.order = order; a.pix_out = pix_global; a.key_out = key;
+  a.S = S; a.adam_step = (const long*)adam_step_dev; a.b1 = b1; a.b2 = b2; a.adam_bc = adam_bc;
   return launch_mlp<MLP_FWD1>(a, (hipStream_t)stream);
 }
 

@@ -45,6 +45,7 @@ def _rows_gemm(x, wp, b, act=Fz.ACT_NONE, leak=0.2):
     return y.view(n, wp.cout)
 
 
+PREP_IN_FWD1 = os.environ.get("ZS3_GMMN_PREP_FUSED", "1") == "1"   # zs3_gmmn_mlp_fwd1_table: six launches per update instead of seven
 # Captured chains of generator updates (table mode): powers of two up to ZS3_GMMN_CHAIN.  A chain boundary costs a graph launch
 # (~100-200 us of idle queue when the host is not far enough ahead), so longer chains = fewer boundaries per step.
 CHAIN_MAX = max(1, int(os.environ.get("ZS3_GMMN_CHAIN", "32")))
@@ -228,7 +229,21 @@ class GMMNStep:
             hd = torch.empty((s, hid), dtype=torch.float32, device=dev)
             gen_s = torch.empty((s, d), dtype=torch.float32, device=dev)
             real_s = torch.empty((s, d), dtype=torch.float32, device=dev)
-            if device_noise and st.get("table_mode"):
+            if device_noise and st.get("table_mode") and PREP_IN_FWD1:
+                # table-driven, SIX launches per update: the first GEMM's workgroups read the update's row of the step's device
+                # table themselves (sample indices -> pixel -> embedding row + noise), publish pix_global / ridx for the later
+                # launches and the Adam bias corrections -- what zs3_gmmn_prep did in a launch of its own
+                check(lib().zs3_gmmn_mlp_fwd1_table(P(st["upd_table"]), I(st["upd_table"].stride(0)), P(st["slot_dev"]),
+                                                    P(st["order_flat"]), P(st["emb_all"]), I(st["emb_all"].stride(0)),
+                                                    I(self.embed_dim), I(self.noise_dim), P(wp1.f_pk), I(wp1.cin_pad // 32),
+                                                    P(lin1.bias), P(x), I(width), P(h), P(hd), I(hid), I(s), I(hid),
+                                                    F(lrelu.negative_slope), F(drop.p if use_drop else 0.0),
+                                                    ctypes.c_ulonglong(st["seed_base"]), ctypes.c_ulonglong(dseed), P(st["seed_dev"]),
+                                                    P(st["pix_global"]), P(st["ridx"]), P(st["step_dev"] if fused_adam else None),
+                                                    F(adam_b1), F(adam_b2), P(st["adam_bc"] if fused_adam else None), stream()),
+                      "zs3_gmmn_mlp_fwd1_table")
+                bc_ready = fused_adam
+            elif device_noise and st.get("table_mode"):
                 # table-driven: the update's (image, class) and sample indices come from row slot_dev[0] of the step's
                 # device table (no host argument, nothing to copy per update); x is assembled once, the GEMM reads it plain
                 check(lib().zs3_gmmn_prep(P(st["upd_table"]), I(st["upd_table"].stride(0)), P(st["slot_dev"]), P(st["order_flat"]),
