@@ -12,7 +12,8 @@
 //     (forward 1), bias + the gather of the sampled real features (forward 2), Dropout-backward * LeakyReLU' (dgrad).
 //   * mlp_wgrad_kernel: both layers' weight gradients dW[co][ci] = sum_r dY[r][co] X[r][ci] (reduction over the 128 rows)
 //     and both bias gradients in ONE launch of 64 x 64 tiles.
-// 16 launches per update become 8.  Arithmetic: every product is the bf16x3 split of common.h (fp32-class accuracy).
+// 16 launches per update became 8 (round 2), 7 with Adam inside the weight-gradient launch (round 3), 6 with the table-driven
+// first GEMM (round 4: zs3_gmmn_mlp_fwd1_table).  Arithmetic: every product is the bf16x3 split of common.h.
 #include "common.h"
 #include "zs3hip.h"
 

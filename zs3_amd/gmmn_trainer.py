@@ -104,8 +104,8 @@ class GMMNStep:
         from .optim import Adam
         self.fused_adam = isinstance(optimizer_generator, Adam)
         self.use_graph = use_graph and self.fused_adam
-        # the update's MLP forward / backward on the latency-shaped kernels of csrc/gmmn.hip (8 launches per update instead
-        # of 16); False keeps the general conv kernels (the A/B reference in tests)
+        # the update's MLP forward / backward on the latency-shaped kernels of csrc/gmmn.hip (6 launches per update in table mode
+        # with fused Adam, 16 on the general kernels); False keeps the general conv kernels (the A/B reference in tests)
         self.fused_mlp = bool(fused_mlp) and os.environ.get("ZS3_GMMN_FUSED", "1") != "0"   # env: same-box A/B runs
         self._st = None       # static buffers (allocated at first call)
         self._graph = None
