@@ -39,8 +39,10 @@ int zs3_prep_weight_f32(const float* w, void* f_pk, void* t_pk, int cout, int ta
                         void* stream);
 /* Operands of a layer whose FORWARD launches run prec = 4 ("f16x3": fp16 hi/lo halves, three v_mfma_f32_32x32x16_f16 per
  * operand pair, 2^-22-class products -- the default arithmetic of the fp32-storage forward pass since round 4, because it puts
- * the default-initialised train step at 1.3x / 1.6x / 1.4x the reference's own fp32 error where bf16x3 sat at 22x / 31x / 5.6x):
- * f_pk holds fp16 hi/lo in the same [row][K/32][{hi,lo}][32] layout, t_pk (data-gradient operand, prec = 3) bf16 hi/lo.
+ * the default-initialised train step at 0.8x / 1.3x / 0.9x the reference's own fp32 error where bf16x3 sat at 22x / 31x / 5.6x):
+ * f_pk holds fp16 hi/lo of 2^6 * w (the prec = 4 kernels scale their accumulators back: a typical weight's lo half would be
+ * an fp16 subnormal otherwise; |w| < 1023) in the same [row][K/32][{hi,lo}][32] layout, t_pk (data-gradient operand, prec = 3)
+ * bf16 hi/lo.
  * fp16 has the precision but not the range for back-propagated gradients, so data- and weight-gradient launches stay bf16x3. */
 int zs3_prep_weight_f16fwd(const float* w, void* f_pk, void* t_pk, int cout, int taps, int cin, int cin_pad, int cout_pad,
                            void* stream);

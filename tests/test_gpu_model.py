@@ -492,19 +492,21 @@ def test_default_init_train_step_vs_reference_goldens(dev, golden):
     is all in the FORWARD pass (the backward is linear in the forward's activations): with bf16x3 forward products (2^-16-class,
     rounds 1-3) the same step sat 3.6e-2 from the goldens = 22x / 31x / 5.6x the reference's own error (next test); with the
     fp16 split it sits where a second fp32 evaluation would (tools/probe/split_emulation.py predicted 1.3x / 1.6x / 1.4x on the CPU).
-    Delivered: logits 3.2e-3 from the goldens (was 3.6e-2), loss 7.2e-5, classifier gradient 3.2e-3, running statistics 2.0e-4;
-    against fp64 1.8x / 2.1x / 1.4x the reference's own fp32 error (logits / classifier gradient / stem gradient).
-    Assertions: against the fp64 oracle at most 4x the reference's own fp32 error for logits and both gradients; against the
-    goldens 4x that error as well (each evaluation is ~1 such error from fp64); loss and running statistics at 3x delivered."""
+    Delivered: logits 2.0e-3 from the goldens (bf16 split: 3.6e-2; the exact-fp32 instantiation: 2.1e-3), loss 3.0e-5, classifier
+    gradient 1.6e-3, running statistics 8.4e-6; against fp64 0.8x / 1.3x / 0.9x the reference's own fp32 error (logits / classifier
+    gradient / stem gradient) -- where the exact-fp32 instantiation sits (0.8x / 0.9x / 1.0x).  (Without the 2^6 weight scale of
+    the fp16 plane -- common.h: a typical weight's lo half is an fp16 subnormal otherwise -- 3.2e-3 and 1.8x / 2.1x / 1.4x.)
+    Assertions: against the fp64 oracle at most 2.5x the reference's own fp32 error for logits and both gradients; against the
+    goldens 2.5x that error as well (each evaluation is ~1 such error from fp64); loss and running statistics at 3x delivered."""
     e = _default_init_train_step(dev, golden)
     _report("f16x3 forward, bf16x3 backward (default)", e)
-    assert e["our_logits"] < 4 * e["ref_logits"]
-    assert e["our_pred"] < 4 * e["ref_pred"]
-    assert e["our_stem"] < 4 * e["ref_stem"]
-    assert e["logits"] < 4 * e["ref_logits"]
-    assert e["pred"] < 4 * e["ref_pred"]
-    assert e["loss"] < 2.2e-4        # 3 x delivered (7.2e-5)
-    assert e["run"] < 6e-4           # 3 x delivered (1.95e-4)
+    assert e["our_logits"] < 2.5 * e["ref_logits"]
+    assert e["our_pred"] < 2.5 * e["ref_pred"]
+    assert e["our_stem"] < 2.5 * e["ref_stem"]
+    assert e["logits"] < 2.5 * e["ref_logits"]
+    assert e["pred"] < 2.5 * e["ref_pred"]
+    assert e["loss"] < 1e-4          # 3 x delivered (3.0e-5)
+    assert e["run"] < 3e-5           # 3 x delivered (8.4e-6)
 
 
 def test_default_init_train_step_with_bf16x3_forward(dev, golden, monkeypatch):

@@ -38,6 +38,12 @@ __device__ __forceinline__ float trunc_bf16_f32(float a) { return __uint_as_floa
 // unflushed -- probed) and gone below |x| ~ 1e-4 (absolute error 3e-8), and |x| > 65504 overflows.  Forward operands (BatchNorm'd
 // activations, O(1); weights O(1e-2)) sit inside that window, back-propagated gradients (1e-3 .. 1e-9) do not: the FORWARD
 // convolutions run f16x3, data- and weight-gradient launches stay bf16x3 (exponent range of fp32).  DESIGN.md section 2.
+// Weights travel through the f16x3 forward multiplied by 2^6 (exact): a convolution weight of the usual size (|w| ~ 0.03) would
+// otherwise have a SUBNORMAL lo half (fp16 spacing 2^-24 below 6e-5: 1e-6 relative instead of 2^-22), which is the difference
+// between 1.3x and 0.6x the reference's own error on the default-init step in the emulation (tools/probe/split_emulation.py with
+// a fixed weight scale).  zs3_prep_weight_f16fwd scales, every PREC = 4 kernel multiplies its accumulators by 2^-6 (exact) before
+// anything reads them.  Headroom: |w| < 1023.
+#define ZS3_F16X3_WSCALE 64.0f
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {   // {fp16(a) low half, fp16(b) high half}, RNE
@@ -52,6 +58,15 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// undo the weight scale of the f16x3 forward on one accumulator fragment (no-op for every other precision)
+template <int PREC>
+__device__ __forceinline__ void unscale_acc(f32x16& acc) {
+  if constexpr (PREC == 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] *= (1.0f / ZS3_F16X3_WSCALE);
+  }
 }
 
 template <int PREC>

@@ -402,6 +402,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
 
   // ---------------------------------------------------------------------- epilogue (all eight waves store rows)
   __syncthreads();   // every DMA has landed and been consumed; nobody reads the operand LDS any more
+  if (!producer) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) unscale_acc<PREC>(acc[i][j]);   // (f16x3: the forward plane carries 2^6 w)
+  }
   float* ctile = reinterpret_cast<float*>(dsm);
   if (p.stat_partial) {
     float* red = ctile;

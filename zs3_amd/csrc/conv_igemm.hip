@@ -359,6 +359,11 @@ __global__ __launch_bounds__(256, igemm_wpe(BM, BN, PREC, PIPE, A16)) void conv_
     if (kt < KT) compute(0);
   }
 
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) unscale_acc<PREC>(acc[i][j]);   // (f16x3: the forward plane carries 2^6 w)
+
   // ---- epilogue 1: per-channel partial sums of the raw conv output (BatchNorm batch statistics)
   if (p.stat_partial) {
     // The sums are staged in the first bytes of LDS stage 0, and the multi-stage loops peel their last K step(s) WITHOUT a closing
@@ -857,6 +862,10 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
         o[0] = t_work; o[1] = 0; o[2] = t_bar;
       }
 #endif
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) unscale_acc<PREC>(acc[i][j]);   // (f16x3: the forward plane carries 2^6 w)
         finish_segment(std::false_type{}, acc);
     }
   }

@@ -516,6 +516,10 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         substep(std::integral_constant<int, 1>{}, nxt, 0);   // channels 16..31; fetch the next step's 0..15
       }
       // ---- epilogue of this tile (consumer waves only; the producers are already filling the next tile's stages)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) unscale_acc<PREC>(acc[i][j]);   // (f16x3: the forward plane carries 2^6 w)
       if (ZS3_PW_ABLATE & 1) {
         for (int e = 0; e < E; ++e) __builtin_amdgcn_s_barrier();
         if (m0 < 0) p.y[tid] = acc[0][0][0] + acc[TM - 1][1][5];

@@ -15,6 +15,7 @@ __device__ __forceinline__ long packed_index(long row, long k, long ktot, int ha
 }
 // fp16 hi / lo of one value (the forward plane of the f16x3 arithmetic, common.h): both halves round to nearest even
 __device__ __forceinline__ void split_f16(float v, unsigned short& h, unsigned short& l) {
+  v *= ZS3_F16X3_WSCALE;      // (exact; undone on the accumulators of every PREC = 4 kernel: common.h)
   const _Float16 hh = (_Float16)v;
   const _Float16 ll = (_Float16)(v - (float)hh);
   h = __builtin_bit_cast(unsigned short, hh);

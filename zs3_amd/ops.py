@@ -230,7 +230,7 @@ class WeightPlanes:
 
 
 # Forward convolutions of the fp32-storage network on the fp16 hi/lo split (prec = 4) instead of the bf16 one: same three MFMAs
-# at the same rate, 2^-22-class products.  Measured on the reference's default-init train-mode goldens: logits 2.1e-3 from the
+# at the same rate, 2^-22-class products.  Measured on the reference's default-init train-mode goldens: logits 2.0e-3 from the
 # goldens where bf16x3 sits at 3.6e-2 (tools/probe/split_emulation.py predicted it on the CPU, tests/test_gpu_model.py holds it).
 # Data- and weight-gradient launches stay bf16x3: gradients need fp32's exponent range.  ZS3_FWD_F16=0 restores bf16x3 forward.
 FWD_F16 = os.environ.get("ZS3_FWD_F16", "1") == "1"
