@@ -31,9 +31,15 @@ def split(x, dt, scaled):
 
 
 def prod3(fn, a, b, cfg):
+    """cfg: None (plain fp32) or (dtype, scaled): scaled False = operands as they are, True = a power-of-two scale per tensor on
+    both, a float = that fixed scale on the SECOND operand only (forward: the weights -- what the product's fp16 plane does)"""
     if cfg is None:
         return fn(a, b)
     dt, scaled = cfg
+    if isinstance(scaled, float):
+        ah, al, _ = split(a, dt, False)
+        bh, bl, _ = split(b * scaled, dt, False)
+        return (fn(al, bh) + fn(ah, bl) + fn(ah, bh)) / scaled
     ah, al, sa = split(a, dt, scaled)
     bh, bl, sb = split(b, dt, scaled)
     return (fn(al, bh) + fn(ah, bl) + fn(ah, bh)) / (sa * sb)
@@ -104,6 +110,7 @@ BF, FH = torch.bfloat16, torch.float16
 MODES = [("plain fp32 convolutions (this CPU's summation order)", None, None),
          ("bf16 hi/lo x3, forward and backward (the product's bf16x3)", (BF, False), (BF, False)),
          ("fp16 hi/lo x3 forward (unscaled), bf16 hi/lo x3 backward", (FH, False), (BF, False)),
+         ("fp16 hi/lo x3 forward with the weights carried as 2^6 w, bf16 hi/lo x3 backward (the product since round 4)", (FH, 64.0), (BF, False)),
          ("fp16 hi/lo x3 forward (unscaled) and backward (power-of-two scale per tensor)", (FH, False), (FH, True)),
          ("fp16 hi/lo x3 forward and backward, both with a power-of-two scale per tensor", (FH, True), (FH, True))]
 
