@@ -321,11 +321,9 @@ def main():
         if args.bf16_steps > 0 and world == 1 and args.dtype == "bf16x3":
             # the 2-byte mode (BASELINE configs[4] "bf16") on the same model, optimizer and batch: activations and
             # inter-layer gradients stored as bf16, plain bf16 products
-            prev_prec = ops.PREC_DEFAULT
             ops.set_storage(torch.bfloat16)
             bdt, _, bprof, bwarm, binst = measure_supervised(args.bf16_steps, 3, not args.no_roofline)
-            ops.set_storage(torch.float32)
-            ops.PREC_DEFAULT = prev_prec
+            ops.set_storage(torch.float32)      # (a round trip: arithmetic and weight-gradient kernel selection come back)
             bval = args.batch * args.bf16_steps / bdt
             bf16_info = {"value": bval, "unit": "images/sec", "ms_per_step": 1e3 * bdt / args.bf16_steps, "steps": args.bf16_steps,
                          "last_loss": float(_.detach().float().item()),

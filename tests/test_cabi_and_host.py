@@ -301,9 +301,86 @@ def test_forward_arithmetic_rule_and_loss_log():
         assert not Fz.forward_is_f16x3(None, train)          # exact-fp32 test mode
     finally:
         ops.FWD_F16, ops.PREC_DEFAULT = old, 3
+    # ops.set_storage is a round trip: the arithmetic and the weight-gradient kernel selection in force before the
+    # 2-byte mode come back with set_storage(float32), whatever they were; likewise the exact-fp32 test mode
+    from zs3_amd._lib import I, lib
+    for prec0, wk0 in ((3, 0), (1, 2), (3, 1)):
+        ops.PREC_DEFAULT = prec0
+        lib().zs3_conv_wgrad_set_kernel(I(wk0))
+        ops.set_storage(torch.bfloat16)
+        assert ops.ACT_DTYPE == torch.bfloat16 and ops.PREC_DEFAULT == 1 and not ops.fwd_f16()
+        ops.set_storage(torch.bfloat16)                        # entering twice must not forget the fp32 state
+        ops.set_storage(torch.float32)
+        assert ops.ACT_DTYPE == torch.float32 and ops.PREC_DEFAULT == prec0
+        assert lib().zs3_conv_wgrad_set_kernel(I(wk0)) == wk0  # (returns the selection that was in force)
+        ops.set_storage(torch.float32)                         # idempotent
+        assert ops.PREC_DEFAULT == prec0
+    ops.PREC_DEFAULT = 3
+    lib().zs3_conv_wgrad_set_kernel(I(2))
+    ops.set_exact_fp32(True)
+    assert ops.PREC_DEFAULT == 0 and not ops.HALO
+    ops.set_exact_fp32(False)
+    assert ops.PREC_DEFAULT == 3 and lib().zs3_conv_wgrad_set_kernel(I(0)) == 2 and ops.fwd_f16()
     log, seen = LossLog(), []
     for i in range(7):
         seen.extend(log.push(torch.tensor(float(i))))
         assert [k for k, _ in seen] == list(range(max(0, i))) or [k for k, _ in seen] == list(range(i + 1))
     seen.extend(log.flush())
     assert seen == [(i, float(i)) for i in range(7)] and log.flush() == []
+
+
+def test_modules_copy_and_pickle_without_their_process_state():
+    """the data-parallel arming of a model (GradSync: bucket tensors, hooks, a process group) and SyncBN's cached
+    process-group answer live on the module objects; copy.deepcopy / torch.save of the module must leave them behind."""
+    import copy
+    import io
+    from zs3_amd.modeling.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
+
+    bn = SynchronizedBatchNorm2d(8)
+    bn._sync_cache = ((True, False, True), _Unpicklable())
+    bn.sync_group = _Unpicklable()
+    twin = copy.deepcopy(bn)
+    assert twin._sync_cache is None and twin.sync_group is None and torch.equal(twin.weight, bn.weight)
+    torch.save(bn, io.BytesIO())
+    from zs3_amd.modeling.deeplab import DeepLab
+    m = DeepLab.__new__(DeepLab)
+    torch.nn.Module.__init__(m)
+    m.lin = torch.nn.Linear(2, 2)
+    object.__setattr__(m, "_zs3_grad_sync", _Unpicklable())
+    object.__setattr__(m, "_zs3_broadcast_done", True)
+    twin = copy.deepcopy(m)
+    assert getattr(twin, "_zs3_grad_sync", None) is None and not getattr(twin, "_zs3_broadcast_done", False)
+    assert torch.equal(twin.lin.weight, m.lin.weight) and m._zs3_grad_sync is not None
+    torch.save(m, io.BytesIO())
+
+
+class _Unpicklable:
+    def __reduce_ex__(self, protocol):
+        raise TypeError("process-local state must not be copied")
+
+
+def test_forward_inside_a_running_backward_keeps_the_backward_bookkeeping():
+    """conv_bn_act clears what a DEAD backward pass left behind when a new forward starts -- but a forward that runs
+    inside a live backward (activation checkpointing, double backward) must leave the bucket hand-out and the side-stream records
+    alone."""
+    from zs3_amd import functional as Fz
+    Fz._handed.add(12345)
+    Fz._handed_armed[0] = True
+    seen = {}
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            Fz._reset_backward_state()      # what a fused layer's forward would call while this backward is running
+            seen["inside"] = (12345 in Fz._handed, Fz._handed_armed[0])
+            return g * 2
+
+    x = torch.ones(2, requires_grad=True)
+    Probe.apply(x).sum().backward()
+    assert seen["inside"] == (True, True)
+    Fz._reset_backward_state()              # outside any autograd pass: the leftovers of a dead pass go
+    assert 12345 not in Fz._handed and not Fz._handed_armed[0]

@@ -127,6 +127,24 @@ def _worker(rank, world, port, q):
         # data parallelism by construction: what DeepLab.forward / patch_replication_callback call
         from zs3_amd import parallel
         assert parallel.resolve_group("auto") is True and parallel.resolve_group(None) is None and parallel.resolve_group(False) is None
+        # the criterion's "auto" group exchanges only for a logit that needs a gradient: a validation loss under no_grad (possibly on
+        # one rank only) is local and never touches torch.distributed
+        from zs3_amd.utils.loss import ce_group
+        z = torch.zeros(1, 3, 2, 2, requires_grad=True)
+        assert ce_group("auto", z) == "auto" and ce_group("auto", z.detach()) is None and ce_group(True, z.detach()) is True
+        with torch.no_grad():
+            assert ce_group("auto", z) is None
+        # broadcast_parameters over an explicit group other than the world must not create the world-wide SyncBN communicator
+        # (dist.new_group() is a collective over ALL ranks: with a true sub-group the ranks outside it would never arrive)
+        sub = dist.new_group([0, 1])
+        saved, parallel._bn_group = parallel._bn_group, None
+        torch.manual_seed(400 + rank)
+        sub_lin = torch.nn.Linear(2, 2)
+        broadcast_parameters(sub_lin, group=sub)
+        assert parallel._bn_group is None
+        torch.manual_seed(400)
+        assert torch.equal(sub_lin.weight, torch.nn.Linear(2, 2).weight)
+        parallel._bn_group = saved
         torch.manual_seed(200 + rank)     # different init per rank again: arming must hand every rank rank 0's parameters
         lin = torch.nn.Linear(6, 4)
         armed = parallel.ensure_data_parallel(lin)

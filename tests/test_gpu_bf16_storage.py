@@ -27,7 +27,7 @@ def bf16_mode():
     ops.set_storage(BF)
     yield ops
     ops.set_storage(torch.float32)
-    ops.PREC_DEFAULT = prev
+    assert ops.PREC_DEFAULT == prev      # set_storage is a round trip
 
 
 def rel(a, b):

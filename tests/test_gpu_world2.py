@@ -43,7 +43,7 @@ def _tamed_model(sync_bn):
     return m
 
 
-def _supervised(dev, image, label):
+def _supervised(dev, image, label, validate=None):
     """The body a reference training script has -- model, criterion, forward, loss, backward -- and nothing else: no gradient-sync
     object, no process-group argument, no SyncBN switch.  Under torch.distributed with two ranks the model arms its
     gradient all-reduce at this first training forward, SyncBN exchanges its sums, and the criterion normalises over both
@@ -67,6 +67,20 @@ def _supervised(dev, image, label):
                        if k in ("backbone.bn1.running_mean", "backbone.layer3.5.bn2.running_var", "aspp.bn1.running_var",
                                 "decoder.last_conv.1.running_mean")}}
     sync = getattr(m, "_zs3_grad_sync", None)     # what the model armed by itself (None in a single process)
+    if validate is not None:
+        # a validation pass on ONE rank only (train_pascal.py:115-172 runs model + criterion under no_grad; a script may well do it
+        # on rank 0 alone): eval-mode BatchNorm and the criterion without a gradient are local by construction -- no collective, no
+        # deadlock, this rank's own loss value -- and an armed model deep-copies / pickles (its GradSync stays behind)
+        import copy
+        import io
+        clone = copy.deepcopy(m)
+        assert getattr(clone, "_zs3_grad_sync", None) is None
+        torch.save(m, io.BytesIO())
+        m.eval()
+        with torch.no_grad():
+            res["val_loss"] = float(crit(m(validate[0]), validate[1]).item())
+            res["val_loss_clone"] = float(crit(clone.eval()(validate[0]), validate[1]).item())
+        m.train()
     if sync is not None:
         res["bytes"] = sync.bytes_reduced
         from zs3_amd.parallel import disarm_data_parallel
@@ -155,7 +169,8 @@ def _worker(rank, world, port, outdir):
     try:
         image, label, seen_only, table = _batch()
         sl = slice(2 * rank, 2 * rank + 2)
-        res = {"sup": _supervised(dev, image[sl].to(dev), label[sl].to(dev)),
+        val = (image[:2].to(dev), label[:2].to(dev)) if rank == 0 else None     # rank-0-only validation: must not hang
+        res = {"sup": _supervised(dev, image[sl].to(dev), label[sl].to(dev), validate=val),
                "gmmn": _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev)),
                "gcn": _gcn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev))}
         torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
@@ -178,7 +193,11 @@ def test_two_ranks_on_one_device_equal_the_single_process_step():
         mp.spawn(_worker, args=(2, _free_port(), td), nprocs=2, join=True)
         r = [torch.load(os.path.join(td, f"rank{k}.pt")) for k in range(2)]
     # ---------------- supervised: two shards + SyncBN + GradSync + global CE == one process on the whole batch
-    one = _supervised(dev, image.to(dev), label.to(dev))
+    one = _supervised(dev, image.to(dev), label.to(dev), validate=(image[:2].to(dev), label[:2].to(dev)))
+    # rank 0 validated alone (no collective, no hang) and got its own shard's loss: the value a single process computes on that shard
+    # (same parameters; running statistics after one synchronised training forward are the global ones)
+    assert abs(r[0]["sup"]["val_loss"] - one["val_loss"]) < 2e-4 * abs(one["val_loss"]), (r[0]["sup"]["val_loss"], one["val_loss"])
+    assert abs(r[0]["sup"]["val_loss_clone"] - r[0]["sup"]["val_loss"]) < 1e-6 * abs(one["val_loss"]) and "val_loss" not in r[1]["sup"]
     both = torch.cat([r[0]["sup"]["logits"], r[1]["sup"]["logits"]], 0)
     assert _rel(both, one["logits"]) < 2e-4                 # global BN statistics in every one of the 113 layers
     for k in range(2):

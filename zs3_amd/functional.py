@@ -162,11 +162,18 @@ def _end_of_backward():
     _handed_armed[0] = False
 
 
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+
+
 def _reset_backward_state():
     """The per-backward bookkeeping is normally cleared by engine callbacks at the end of the pass; those do not run when backward
-    raises (an out-of-memory error the caller catches and retries).  A fused layer's FORWARD means no backward pass of ours is in
-    flight, so it clears whatever a dead pass left behind -- otherwise grad_buffer() would answer None for every registered
-    parameter from then on and GradSync would silently fall back to its copy path."""
+    raises (an out-of-memory error the caller catches and retries).  A fused layer's FORWARD outside any autograd pass means no
+    backward of ours is in flight, so it clears whatever a dead pass left behind -- otherwise grad_buffer() would answer None for
+    every registered parameter from then on and GradSync would silently fall back to its copy path.  A forward that runs INSIDE a
+    live backward (activation checkpointing / recomputation, double backward) must leave the bookkeeping alone: clearing it
+    mid-pass would hand a shared weight's bucket slice out twice and drop the stream waits of its two launches."""
+    if _graph_task_id is not None and _graph_task_id() != -1:
+        return
     if _handed_armed[0] or _handed:
         _end_of_backward()
     if _join_armed[0]:

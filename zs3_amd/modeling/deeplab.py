@@ -32,6 +32,15 @@ class DeepLab(nn.Module):
         if freeze_bn:
             self.freeze_bn()
 
+    def __getstate__(self):
+        """copy.deepcopy / torch.save of the whole module (saver.py:24-67 saves state dicts, but scripts also deep-copy models):
+        the data-parallel arming of this process -- GradSync with its bucket tensors, hooks and process group -- stays behind;
+        a copy arms itself at its own first training forward."""
+        state = self.__dict__.copy()
+        state.pop("_zs3_grad_sync", None)
+        state.pop("_zs3_broadcast_done", None)
+        return state
+
     # ------------------------------------------------------------------ NHWC pipeline pieces
     def _encode(self, image):
         top, low = self.backbone.forward_nhwc(image)

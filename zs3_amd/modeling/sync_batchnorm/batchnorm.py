@@ -24,6 +24,15 @@ class SynchronizedBatchNorm2d(BatchNorm2d):
     sync_group = None
     _sync_cache = None   # (state the answer was computed under, answer); enable_sync_bn resets it
 
+    def __getstate__(self):
+        """copy.deepcopy / torch.save of a module that has trained under torch.distributed: the cached answer holds a
+        ProcessGroup (not picklable, not copyable) and is recomputed on first use anyway"""
+        state = self.__dict__.copy()
+        state.pop("_sync_cache", None)
+        if not isinstance(state.get("sync_group"), (type(None), bool)):
+            state.pop("sync_group", None)      # an explicit process group does not survive a copy: the class default (None) returns
+        return state
+
     @property
     def _zs3_sync_group(self):
         """What zs3_amd.functional reads -- in training mode only, so an eval forward never touches torch.distributed:

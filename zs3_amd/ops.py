@@ -16,6 +16,7 @@ PREC_DEFAULT = 3  # bf16x3 split; 1 = plain bf16 inputs; 0 = exact fp32 (test mo
 PROFILE = None    # set to a list to record (tag, algorithmic_flops, start_event, end_event, tile_cfg) per conv launch
 PROFILE_CFGS = None   # optional set of tile_cfg values to restrict the recording to (event pairs serialise kernel boundaries)
 PROFILE_SAMPLE = None  # optional [stride, phase, counter]: record every stride-th eligible launch (an event pair costs host time)
+PROFILE_GEOM = None    # optional list: one (m, ncols, k, taps, stride, dil, dgrad, epilogue kind, io) per PROFILE record (tools/probe/step_layers.py)
 
 
 WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"   # strip-resident weight gradient of the 3x3 stride-1 layers
@@ -46,23 +47,41 @@ def _same_type(ref, *others):
             raise TypeError(f"activation tensors of one call must share an element type: {t.dtype} next to {ref.dtype}")
 
 
+_fp32_state = None   # (PREC_DEFAULT, weight-gradient kernel selection) in force when the 2-byte mode was entered
+
+
 def set_storage(dtype):
     """Element type of the activation tensors the fused layers allocate: torch.float32 (BASELINE configs[1-3]) or torch.bfloat16
     -- the 2-byte mode of configs[4]: conv outputs, BatchNorm-applied activations and every gradient between layers are
     bf16 in HBM (half the bytes of every HBM-bound pass and of every conv operand), products are plain bf16 (prec = 1),
-    accumulation / statistics / parameters / weight gradients stay fp32.  Image input and class scores stay fp32."""
-    global ACT_DTYPE, PREC_DEFAULT
+    accumulation / statistics / parameters / weight gradients stay fp32.  Image input and class scores stay fp32.
+    set_storage(torch.float32) restores the arithmetic (PREC_DEFAULT) and the weight-gradient kernel selection that were in
+    force when the 2-byte mode was entered: a round trip is the identity."""
+    global ACT_DTYPE, PREC_DEFAULT, _fp32_state
     from . import functional as Fz
     if dtype not in (torch.float32, BF16):
         raise ValueError("activation storage is torch.float32 or torch.bfloat16")
-    ACT_DTYPE = dtype
-    if dtype == BF16:
+    if dtype == BF16 and ACT_DTYPE != BF16:
+        # (zs3_conv_wgrad_set_kernel returns the previous selection: ask by setting, the value is overwritten just below)
+        _fp32_state = (PREC_DEFAULT, int(lib().zs3_conv_wgrad_set_kernel(I(1))))
         PREC_DEFAULT = 1
-    lib().zs3_conv_wgrad_set_kernel(I(1 if dtype == BF16 else 0))   # the LDS-DMA weight-gradient kernel moves raw fp32 rows
+        lib().zs3_conv_wgrad_set_kernel(I(1))      # the LDS-DMA weight-gradient kernel moves raw fp32 rows
+    elif dtype == torch.float32 and ACT_DTYPE == BF16:
+        prec, wk = _fp32_state if _fp32_state is not None else (3, 0)
+        PREC_DEFAULT = prec
+        lib().zs3_conv_wgrad_set_kernel(I(wk))
+        _fp32_state = None
+    ACT_DTYPE = dtype
     _TILE_CHOICE.clear()
     _WGRAD_PLAN.clear()
+    _MTILES.clear()
+    Fz._planes.clear()          # forward planes are fp16 hi/lo in fp32 storage (f16x3), bf16 in the 2-byte mode
+    Fz._refresh_tables.clear()
     Fz._defer_choice.clear()
     Fz._in_affine_choice.clear()
+
+
+_exact_state = None   # weight-gradient kernel selection in force when the exact-fp32 test mode was entered
 
 
 def set_exact_fp32(on=True):
@@ -70,22 +89,27 @@ def set_exact_fp32(on=True):
     the bf16 rate) -- the arithmetic of the reference's own fp32 convolutions, summation order aside.  It answers one question:
     is a difference from the reference bf16x3 arithmetic or structure?  (tests/test_gpu_model.py runs the reference's default-init
     train-mode goldens through it.)  Switches the producer-converting kernel families off, since they exist in bf16 only."""
-    global PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW
+    global PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW, _exact_state
     from . import functional as Fz
     if on:
+        if _exact_state is None:
+            _exact_state = int(lib().zs3_conv_wgrad_set_kernel(I(1)))
         PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW = 0, False, False, False, False
+        lib().zs3_conv_wgrad_set_kernel(I(1))
     else:
         PREC_DEFAULT = 3
         HALO = os.environ.get("ZS3_HALO", "1") == "1"
         PW = os.environ.get("ZS3_PW", "1") == "1"
         WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"
         WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"
-    lib().zs3_conv_wgrad_set_kernel(I(1 if on else 0))
+        lib().zs3_conv_wgrad_set_kernel(I(_exact_state if _exact_state is not None else 0))
+        _exact_state = None
     _TILE_CHOICE.clear()
     _WGRAD_PLAN.clear()
     _MTILES.clear()
     Fz._planes.clear()
     Fz._defer_choice.clear()
+    Fz._in_affine_choice.clear()
     Fz._refresh_tables.clear()
 
 
@@ -437,6 +461,11 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
                         "conv_pw_kernel<%d, %d>" % (prec, 256 if tile_cfg == 51 else 128) if tile_cfg in (51, 52) else
                         "conv_igemm_dma<256,128,%d>" % prec if tile_cfg == 31 else f"conv_igemm<{('128,128', '128,64', '64,128', '64,64')[tile_cfg % 10 - 1]},{prec},pipe{1 + tile_cfg // 10}>",
                         2.0 * m * ncols * kh * kw * min(cin_pad, cin_valid), e0, e1, tile_cfg))
+        if PROFILE_GEOM is not None:
+            PROFILE_GEOM.append((m, ncols, min(cin_pad, cin_valid), kh * kw, stride, dil, int(dgrad),
+                                 ("stats" if want_stats else "store") if pw_epilogue == 1 else
+                                 "+".join(n for n, on in (("res", res is not None), ("acc", accumulate), ("bnbwd", bn_bwd is not None),
+                                                          ("aff", scale is not None or shift is not None)) if on), io))
     return out, stat
 
 

@@ -228,7 +228,11 @@ def broadcast_parameters(module, src=0, group=None):
     # writes through .data do not bump the autograd version counter the bf16 weight-plane cache is keyed on
     from . import functional as Fz
     Fz.invalidate_planes(*module.parameters())
-    bn_group()   # a point every rank reaches together: create the SyncBN communicator here rather than in some forward
+    if group is None or group is dist.group.WORLD:
+        # a point every rank of the WORLD reaches together: create the SyncBN communicator here rather than in some forward.
+        # (dist.new_group() is a collective over all ranks: under an explicit sub-group -- GMMNStep(group=pg) -- only that
+        # group's ranks are here, and creating it would hang the others.)
+        bn_group()
 
 
 def all_reduce_tensors(tensors, group=None, average=False, force=False):

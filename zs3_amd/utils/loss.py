@@ -60,10 +60,25 @@ def global_ce_normalise(loss_ws, batch, group):
     return loss_ws[2] / loss_ws[1] / (batch if batch > 0 else 1), batch
 
 
+def ce_group(group, logit):
+    """the `group` a criterion call really uses: "auto" is local (None) unless the call is part of a training step -- gradient mode
+    on and a logit that requires a gradient (see cross_entropy_2d)"""
+    if isinstance(group, str) and group == "auto" and not (torch.is_grad_enabled() and logit.requires_grad):
+        return None
+    return group
+
+
 def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True, group="auto"):
     """group: "auto" (normalise over every rank's shard as soon as torch.distributed runs with more than one rank: the loss of
     the gathered batch that nn.DataParallel hands the reference's criterion) | None (this process only) | True (default process
-    group) | a torch.distributed group."""
+    group) | a torch.distributed group.
+
+    The criterion is a COLLECTIVE when it exchanges: every rank of the group has to call it at the same point.  "auto" therefore
+    exchanges only where the training step needs it -- gradient mode on and a logit that requires a gradient -- and is local
+    everywhere else: a validation loss under torch.no_grad() (train_pascal.py:125-128 calls the same criterion) is this rank's own
+    value and never touches torch.distributed, so a rank-0-only validation or validation loaders of unequal length cannot
+    deadlock, exactly like eval-mode BatchNorm.  Pass True / a group to get the globally normalised value there too."""
+    group = ce_group(group, logit)
     if weight is not None:
         weight = weight.to(device=logit.device, dtype=torch.float32).contiguous()
     batch = logit.shape[0] if batch_average else 0
