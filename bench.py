@@ -67,6 +67,14 @@ def parse():
                     help="1 (default): every timed step's loss value is read on the host, one step behind (what BaseTrainer does); 0: never")
     ap.add_argument("--bf16-steps", type=int, default=10,
                     help="timed steps of the 2-byte mode reported as the `bf16` object of the default line; 0 = skip")
+    ap.add_argument("--shard-steps", type=int, default=10,
+                    help="timed steps of `shard`: what ONE rank of BASELINE configs[3] runs (B = 8 images, 60 classes); 0 = skip")
+    ap.add_argument("--ddp-steps", type=int, default=10,
+                    help="timed steps of `ddp_one_rank`: the supervised step on the N > 1 code path with a one-rank RCCL group and "
+                         "SyncBN (gradient buckets, 208 SyncBN all-reduces, global CE), run as a child process; 0 = skip")
+    ap.add_argument("--script-steps", type=int, default=3,
+                    help="timed iterations of `gmmn.script_loop`: the reference's own per-image x per-class loop body "
+                         "(train_pascal_GMMN.py:139-268) on the drop-in modules; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -204,7 +212,7 @@ def main():
             dt = float(t.item())
         return dt, last
 
-    gmmn_info = None
+    gmmn_info = shard_info = None
 
     def build_gmmn():
         gen = GMMNnetwork(300, 300, 256, 256).to(dev).train()
@@ -226,7 +234,7 @@ def main():
         # next_image: the trainers look one batch ahead and start its frozen-backbone feature pass next to this batch's
         # generator loop (GMMNStep.prefetch); the synthetic loader returns the same batch every time
         fn = lambda i: stepper(gb["image"], gb["label"], gb["label_emb"], next_image=gb["image"] if args.gmmn_pipeline else None)
-        fn.stepper, fn.image = stepper, gb["image"]
+        fn.stepper, fn.image, fn.batch = stepper, gb["image"], gb
         return fn
 
     def gmmn_report(gstep, steps):
@@ -247,7 +255,25 @@ def main():
         fwd_ms = e0.elapsed_time(e1) / 3
         step_ms = 1e3 * gdt / steps
         upd = int(getattr(gstep.stepper, "last_updates", 0))
-        return {"value": args.batch * steps / gdt, "unit": "images/sec", "ms_per_step": step_ms, "steps": steps,
+        script = None
+        if args.script_steps > 0 and args.workload != "gcn_context":
+            # the reference's own loop body on the drop-in modules (same model, batch, class split; its own generator / optimizers)
+            from zs3_amd.utils.loss import GMMNLoss
+            torch.manual_seed(7)
+            gen_s = GMMNnetwork(300, 300, 256, 256).to(dev).train()
+            opt_s = Adam(gen_s.parameters(), lr=2e-4)
+            w_s = torch.ones(args.classes, device=dev)
+            w_s[unseen] = 100.0
+            crit_s, crit_gs = SegmentationLosses(weight=w_s, cuda=True).build_loss("ce"), GMMNLoss(cuda=True).build_loss()
+            fn = lambda i: script_style_gmmn_iteration(model, gen_s, opt, opt_s, crit_s, crit_gs, gstep.batch, set(float(c) for c in seen),
+                                                       set(float(c) for c in unseen))
+            sdt, slast = run(fn, args.script_steps, 1)
+            script = {"ms_per_step": 1e3 * sdt / args.script_steps, "value": args.batch * args.script_steps / sdt, "unit": "images/sec",
+                      "steps": args.script_steps, "generator_updates_per_step": slast[2], "last_classifier_loss": slast[1],
+                      "note": "train_pascal_GMMN.py:139-268 as written -- eager GMMNnetwork on every pixel of a class, boolean masks, "
+                              "autograd through GMMNLoss, CPU noise / sample indices, .item() per (image, class) -- on the drop-in modules; "
+                              "`GMMNStep` (ms_per_step of this object) is the same iteration as fixed-shape captured updates"}
+        return {"value": args.batch * steps / gdt, "unit": "images/sec", "ms_per_step": step_ms, "steps": steps, "script_loop": script,
                 "workload": "train_pascal_GMMN.py step (BASELINE configs[2]): frozen DeepLabv3+ feature pass + per-(image, class) "
                             "GMMN/MMD/Adam updates + pred_conv CE/SGD, device noise",
                 "breakdown": {"backbone_forward_ms": fwd_ms, "generator_updates_per_step": upd,
@@ -340,6 +366,31 @@ def main():
             from zs3_amd.parallel import disarm_data_parallel
             disarm_data_parallel(model)   # (--ddp-selftest: the GMMN step exchanges pred_conv's gradients itself)
             gmmn_info = gmmn_report(build_gmmn(), args.gmmn_steps)
+        if args.shard_steps > 0 and world == 1 and not args.ddp_selftest and args.dtype == "bf16x3":
+            # what ONE rank of BASELINE configs[3] runs (train_context_GMMN.py at global B = 64 on 8 GPUs): 8 images, 60 classes
+            # (59 + background, datasets/context.py:22) -- every tile rule sees M = 8 712 / 33 800 / 133 128 rows instead of B = 16's
+            sb, sc = 8, 60
+            torch.manual_seed(1)
+            smodel = DeepLab(num_classes=sc, pretrained=False, sync_bn=False).to(dev).train()
+            sopt = SGD([{"params": smodel.get_1x_lr_params(), "lr": 0.007}, {"params": smodel.get_10x_lr_params(), "lr": 0.07}],
+                       momentum=0.9, weight_decay=5e-4, nesterov=False)
+            sbatch = make_batch(sb, args.size, sc, unseen, seed=11, device=dev)
+
+            def shard_step(i):
+                sched(sopt, i, 0, 0.0)
+                sopt.zero_grad()
+                loss_ = crit(smodel(sbatch["image"]), sbatch["label"])
+                loss_.backward()
+                sopt.step()
+                return loss_
+            sdt, slast = run(shard_step, args.shard_steps, 3)
+            shard_info = {"value": sb * args.shard_steps / sdt, "unit": "images/sec", "ms_per_step": 1e3 * sdt / args.shard_steps,
+                          "steps": args.shard_steps, "warmup": 3, "last_loss": float(slast.detach().float().item()),
+                          "batch_per_gpu": sb, "classes": sc,
+                          "model_tflops": sb * args.shard_steps / sdt * TRAIN_GFLOP_PER_IMG[60] / 1e3,
+                          "workload": "the supervised step on one rank's shard of BASELINE configs[3] (global B = 64 on 8 GPUs -> 8 images "
+                                      "per rank, 60 classes), same arithmetic as `value`, no collectives (one process)"}
+            del smodel, sopt, sbatch
     else:
         gstep = build_gmmn()
         prof, warm_prof, instrumented = [], [], 0
@@ -374,15 +425,92 @@ def main():
         result["gmmn"] = gmmn_info
     if bf16_info:
         result["bf16"] = bf16_info
+    if shard_info:
+        result["shard"] = shard_info
     if rank == 0 and prof:
         result["roofline"] = roofline_of(prof, warm_prof, instrumented, args.dtype)
     if cpu_info is not None:
         result["cpu_baseline"] = cpu_info
+    if rank == 0 and world == 1 and args.ddp_steps > 0 and not args.ddp_selftest and args.workload == "supervised" and \
+            args.dtype == "bf16x3":
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        result["ddp_one_rank"] = ddp_one_rank(args, result["ms_per_step"])
     if rank == 0:
         print(json.dumps(result))
     if world > 1 or args.ddp_selftest:
         dist.destroy_process_group()
 
+
+
+def script_style_gmmn_iteration(model, generator, optimizer, optimizer_generator, criterion, criterion_generator, batch, seen, unseen,
+                                noise_dim=300, embed_dim=300, feature_dim=256, batch_size_generator=128):
+    """One iteration written the way the reference's script writes it (train_pascal_GMMN.py:139-268; the loop
+    tests/test_gpu_dropin.py drives against the oracle) and using nothing but the drop-in surface: the model's split forwards, eager
+    `GMMNnetwork` calls on EVERY pixel of a class, boolean-mask indexing, autograd through `GMMNLoss`, the optimizers' own `step`,
+    CPU-drawn noise and sample indices, `.item()` per (image, class).  north_star says the build "drops into
+    train_pascal_GMMN.py unchanged": this is what such an unchanged script costs per iteration, next to `GMMNStep`."""
+    import torch.nn.functional as F
+    image, target, embedding = batch["image"], batch["label"], batch["label_emb"]
+    with torch.no_grad():
+        real = model.forward_before_class_prediction(image)
+    fake = torch.zeros(real.shape, device=real.device)
+    fh, fw = real.shape[2:]
+    g_total, updates = 0.0, 0
+    for n in range(image.shape[0]):
+        feats = real[n].permute(1, 2, 0).reshape(-1, feature_dim)
+        labels = F.interpolate(target[n].view(1, 1, *target.shape[1:]), size=(fh, fw), mode="nearest").view(-1)
+        emb = F.interpolate(embedding[n].unsqueeze(0), size=(fh, fw), mode="nearest")[0].permute(1, 2, 0).reshape(-1, embed_dim)
+        generated = torch.zeros_like(feats)
+        present = labels.unique()
+        has_unseen = bool(sum(float(c) in unseen for c in present))
+        running = 0.0
+        for c in present:
+            if float(c) == 255:
+                continue
+            optimizer_generator.zero_grad()
+            where = labels == c
+            count = int(where.sum().item())
+            noise = torch.rand((count, noise_dim)).cuda()
+            made = generator(emb[where], noise.float())
+            if float(c) in seen and not has_unseen:
+                pick = torch.randint(low=0, high=count, size=(batch_size_generator,)).cuda()
+                g_loss = criterion_generator(made[pick], feats[where][pick])
+                running += g_loss.item()
+                g_loss.backward()
+                optimizer_generator.step()
+                updates += 1
+            generated[where] = made.detach()
+        g_total += running / len(present)
+        fake[n] = (feats if not has_unseen else generated).reshape(fh, fw, feature_dim).permute(2, 0, 1)
+    optimizer.zero_grad()
+    out = model.forward_class_prediction(fake.detach(), image.shape[2:])
+    loss = criterion(out, target)
+    loss.backward()
+    optimizer.step()
+    return g_total, loss.item(), updates
+
+
+def ddp_one_rank(args, plain_ms):
+    """The supervised step on the N > 1 CODE PATH, observed by the driver: a child `bench.py --ddp-selftest --sync-bn 1` with a
+    one-rank RCCL process group -- GradSync's bucketed all-reduce (237 MB per step, launched from the weight-gradient stream),
+    one fp64 all-reduce per SynchronizedBatchNorm2d layer and direction (208 per step) and the CE's global weight sum all run,
+    with nobody to talk to.  What the number is: the launch / stream / collective-call overhead of the path every rank of an
+    8-GPU run executes; what it is not: link time.  (No >= 2-rank run exists on this pool's one-GPU boxes.)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--ddp-selftest", "--sync-bn", "1", "--steps", str(args.ddp_steps), "--warmup", "3",
+           "--no-cpu-baseline", "--gmmn-steps", "0", "--bf16-steps", "0", "--shard-steps", "0", "--ddp-steps", "0", "--no-roofline",
+           "--batch", str(args.batch), "--size", str(args.size), "--classes", str(args.classes)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:
+        return {"ms_per_step": None, "error": f"{type(e).__name__}"}
+    return {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": "images/sec", "steps": d["steps"], "last_loss": d.get("last_loss"),
+            "plain_ms_per_step": plain_ms, "overhead_ms": d["ms_per_step"] - plain_ms,
+            "rccl_bytes_per_rank_per_step": d.get("rccl_bytes_per_rank_per_step"), "sync_bn": True, "ranks": 1,
+            "workload": "the supervised step of `value` through the N > 1 path: one-rank RCCL group, GradSync buckets (in-place all-reduce "
+                        "from the weight-gradient stream), 208 SyncBN all-reduces, globally normalised CE; child process, same GPU"}
 
 
 def roofline_of(prof, warm_prof, instrumented, dtype):
@@ -492,7 +620,9 @@ def cpu_baseline(args):
             "kind": "port", "wall_s": time.perf_counter() - t0,
             "sample": f"oracle supervised step (fwd+CE+bwd+SGD), B={d['bsz']} at {args.size}x{args.size}, 1 warm-up + 3 timed "
                       f"steps, median; torch CPU fp32 with {threads} threads on a host with {usable} usable cores "
-                      f"({os.cpu_count()} logical); run before the GPU phase of this same bench.py process"}
+                      f"({os.cpu_count()} logical); run before the GPU phase of this same bench.py process.  Why not one thread per "
+                      "core (BASELINE.md section 4): on the 256-core hosts of this pool torch's thread pool oversubscribes B = 2 "
+                      "convolutions -- 256 threads did not finish four steps in 45 s in rounds 1-2, 64 is the fastest setting found"}
 
 
 if __name__ == "__main__":

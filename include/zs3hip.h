@@ -187,7 +187,10 @@ int zs3_bn_sync_pack(const float* partial, int chunks, int C, double count, doub
 int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                         float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
-                        long* num_batches_tracked, void* stream);
+                        long* num_batches_tracked, int* range_flag, void* stream);
+/* range_flag (optional, device int32, sticky): set to 1 when a channel's batch sums are not finite -- what an operand beyond fp16's
+   range does to an f16x3 (prec 4) forward convolution; the running statistics are then left untouched.  zs3_sgd_multi skips its
+   update while the flag it is given is up (zs3_amd.functional.check_forward_range lowers it and switches the forward to bf16x3). */
 int zs3_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, int C, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                        void* stream);
@@ -364,7 +367,8 @@ int zs3_sgd_step(float* p, const float* g, float* buf, long n, float lr, float m
 /* One launch for a whole parameter set: table = int64[E][6] {p, g, momentum_buf, n, lr | wd<<32 (float bits), first},
  * blockmap = int32[nblocks][2] {entry, chunk}; every block updates zs3_sgd_chunk() consecutive elements. */
 int zs3_sgd_chunk(void);
-int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov, void* stream);
+int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov, const int* skip_flag,
+                  void* stream);
 /* step_dev (optional): device int64 holding the number of steps taken so far; overrides `step` (= step_dev[0] + 1) */
 int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   float wd, int step, const void* step_dev, void* stream);

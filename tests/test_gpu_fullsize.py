@@ -285,3 +285,23 @@ def test_every_conv_shape_at_batch_16_against_fp64_samples(dev, shape):
     assert e_y < 5e-5 and e_dx < 5e-5 and e_dw < 5e-5
     if bias is not None:
         assert relerr(bg.grad, dy.double().sum((0, 1, 2))) < 5e-5
+        return      # the classifier has no BatchNorm: its forward stays bf16x3 (functional.forward_is_f16x3)
+    # VERDICT r4 #2a: the same shape through the launch a batch-statistics layer of the benched step makes -- fp16 hi/lo planes
+    # (prec 4, f16x3), store-only epilogue with the BatchNorm partial sums, the tile rule of this M -- against the same fp64
+    # samples, in the maximum norm at the bound of test_conv_forward_f16x3 (5e-6 of the output scale)
+    from zs3_amd import ops
+    wp16 = ops.prep_weight(w, f16_forward=True)
+    assert wp16.f_fmt == 1
+    ops.PROFILE = prof = []
+    try:
+        y4, st4 = ops.conv2d_fwd(x, wp16, s, pad, d, want_stats=True)
+    finally:
+        ops.PROFILE = None
+    torch.cuda.synchronize()
+    assert len(prof) == 1 and any(m in prof[0][0] for m in ("<4", ",4,", ",4>")), prof[0][0]      # a prec-4 instantiation ran
+    e4 = relerr(y4.reshape(-1, co)[mo], y_ref)
+    y4d = y4.double().reshape(-1, co)
+    e_s = ((st4[:, 0].double().sum(0) - y4d.sum(0)).abs().max() / y4d.abs().sum(0).max()).item()
+    e_q = ((st4[:, 1].double().sum(0) - y4d.square().sum(0)).abs().max() / y4d.square().sum(0).max()).item()
+    print(f"[B=16 {shape}] f16x3 forward {e4:.1e} on {prof[0][0]} (bf16x3 {e_y:.1e}); BN sums {e_s:.1e} / {e_q:.1e}")
+    assert e4 < 5e-6 and e_s < 2e-6 and e_q < 2e-6

@@ -19,6 +19,8 @@ class LossLog:
     def __init__(self, device=None, depth=2):
         self.depth = depth
         self.buf = torch.zeros(depth, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(depth)
+        # the range flag of the f16x3 forward travels with the loss: same moment, same asynchronous copy, one iteration late
+        self.flags = torch.zeros(depth, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else None
         self.pending = []      # (index, slot, event)
         self.count = 0
 
@@ -29,6 +31,9 @@ class LossLog:
         slot = self.count % self.depth
         if loss.is_cuda:
             self.buf[slot:slot + 1].copy_(loss.detach().reshape(1), non_blocking=True)
+            from . import ops
+            if self.flags is not None and ops._range_flags:
+                self.flags[slot:slot + 1].copy_(ops.range_flag(loss.device), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         else:
@@ -44,6 +49,10 @@ class LossLog:
             idx, slot, ev = self.pending.pop(0)
             if ev is not None:
                 ev.synchronize()
+                if self.flags is not None and int(self.flags[slot]):
+                    from . import functional as Fz
+                    self.flags[slot] = 0
+                    Fz.check_forward_range(flag_value=1)     # fall back to bf16x3 forward products (the flagged steps were skipped)
             got.append((idx, float(self.buf[slot])))
         return got
 

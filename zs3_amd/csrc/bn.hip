@@ -127,13 +127,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
 // one partial row per 64 output rows (4161 / 16513 rows x 64-256 channels: with 32 x 8 that was 2-8 workgroups walking 520-2064
 // rows per thread -- 35-240 us per call, 1.6 ms of the step's dependent chain for 11 of the 113 BN layers).
 // (The first, one-wave-per-channel form read one 4-byte value per lane with stride C: ~10 us per call, 226 calls per step.)
-static int fin_tall_rows() {   // ZS3_BN_FIN_TALL=<rows> moves the switch (A/B runs); default 2048
-  static const int v = [] {
-    const char* e = getenv("ZS3_BN_FIN_TALL");
-    return e && atoi(e) > 0 ? atoi(e) : 2048;
-  }();
-  return v;
-}
+static int fin_tall_rows() { return 2048; }   // partial rows from which the tall form takes over (swept in round 2)
 template <int FIN_CH, int FIN_GROUPS>
 __device__ __forceinline__ bool combine_partials(const float* partial, int chunks, int C, int& c, double& s, double& q) {
   __shared__ double red[2][FIN_GROUPS][FIN_CH];
@@ -173,7 +167,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_fwd_finalize_kernel(co
                                                              const double* count_dev, const float* gamma, const float* beta, float eps,
                                                              float momentum, float* running_mean, float* running_var,
                                                              float* mean_out, float* invstd_out, float* scale_out,
-                                                             float* shift_out, long* num_batches_tracked) {
+                                                             float* shift_out, long* num_batches_tracked, int* range_flag) {
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   int c;
   double s, q;
@@ -190,7 +184,12 @@ __global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_fwd_finalize_kernel(co
     float sc = g * (float)invstd;
     scale_out[c] = sc;
     shift_out[c] = b - (float)mean * sc;
-    if (running_mean) {
+    // range guard of the f16x3 forward: an operand beyond fp16's range makes the conv output -- and with it
+    // these sums -- non-finite.  The layer raises the sticky flag (the fused SGD skips the step while it is up, the trainer falls
+    // back to bf16x3 forward products) and leaves the persistent running statistics alone.
+    const bool bad = range_flag && !(isfinite(s) && isfinite(q));
+    if (bad) *range_flag = 1;
+    if (running_mean && !bad) {
       double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
@@ -535,15 +534,15 @@ extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, doub
                                    const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, float* mean_out, float* invstd_out, float* scale_out,
-                                   float* shift_out, long* num_batches_tracked, void* stream) {
+                                   float* shift_out, long* num_batches_tracked, int* range_flag, void* stream) {
   if (chunks >= fin_tall_rows())
     hipLaunchKernelGGL((bn_fwd_finalize_kernel<8, 128>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, chunks, C,
                        count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
-                       shift_out, num_batches_tracked);
+                       shift_out, num_batches_tracked, range_flag);
   else
     hipLaunchKernelGGL((bn_fwd_finalize_kernel<32, 8>), dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
                        count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
-                       shift_out, num_batches_tracked);
+                       shift_out, num_batches_tracked, range_flag);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -76,8 +76,12 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = 0u;
   } else if (PREC == 4) {
     hi = cvt_pk_f16(a, b);
-    const f16x2_t h = __builtin_bit_cast(f16x2_t, hi);
-    lo = cvt_pk_f16(a - (float)h[0], b - (float)h[1]);   // the remainder is exact in fp32
+    // lo = fp16(x - fp32(hi)) in ONE instruction per value: the mixed-precision FMA reads hi's halves as fp16 operands, computes
+    // hi * -1.0 + x exactly (the remainder is representable in fp32) and rounds once to fp16 into the low / high half of `lo` --
+    // 3 VALU per pair instead of 6 (v_cvt_f32_f16 x2, v_sub_f32 x2, v_cvt_pk_f16_f32).  Bit-identical to the long form on 4.2 M
+    // pairs incl. subnormals, infinities, NaNs and arbitrary bit patterns (tools/probe/split/split_probe.hip, on the GPU).
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
   } else {
     hi = cvt_pk_bf16(a, b);  // round-to-nearest hi: |x - hi| <= 2^-9 |x|, remainder exact in fp32
     lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));

@@ -273,56 +273,6 @@ __global__ __launch_bounds__(256, igemm_wpe(BM, BN, PREC, PIPE, A16)) void conv_
       if (more) store_tile(s0, cur ^ 1);
       __syncthreads();
     }
-  } else if (PIPE == 3) {
-    // three register stages (round 4, bf16-stored input): a tile's global loads are issued FOUR K steps before its MFMAs, and the
-    // steady state contains NO branch around a load or an LDS write: hipcc waits vmcnt(0) at the join of a branch that holds a
-    // load, which turns the two-deep prefetch of the PIPE 2 form into none at all once a K step is only
-    // 256-512 matrix-pipe cycles (plain bf16: measured 2.3 us per K step whatever the prefetch depth).  Requests past the last
-    // step re-read the last step (the step counter stops advancing; the data is never multiplied).  Step j lives in LDS stage
-    // j & 1 and travels through register set j % 3.
-    Stage s0, s1, s2;
-    int requested = 0;                       // K step of the most recent request
-    auto next_step = [&]() {                 // scalar state only: no load lives under this branch
-      if (requested + 1 < KT) {
-        advance();
-        ++requested;
-      }
-    };
-    load_tile(s0);
-    next_step();
-    load_tile(s1);
-    next_step();
-    load_tile(s2);
-    store_tile(s0, 0);
-    next_step();
-    load_tile(s0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 3 <= KT; kt += 3) {
-      compute(kt & 1);                       // step kt;     next: step kt + 1 from s1, reload s1 with step kt + 4
-      store_tile(s1, (kt + 1) & 1);
-      next_step();
-      load_tile(s1);
-      __syncthreads();
-      compute((kt + 1) & 1);                 // step kt + 1; next: step kt + 2 from s2, reload s2 with step kt + 5
-      store_tile(s2, kt & 1);
-      next_step();
-      load_tile(s2);
-      __syncthreads();
-      compute(kt & 1);                       // step kt + 2; next: step kt + 3 from s0, reload s0 with step kt + 6
-      store_tile(s0, (kt + 1) & 1);
-      next_step();
-      load_tile(s0);
-      __syncthreads();
-    }
-    if (kt < KT) {                           // one or two steps left: step kt is in LDS, step kt + 1 (if any) in s1
-      compute(kt & 1);
-      if (kt + 1 < KT) {
-        store_tile(s1, (kt + 1) & 1);
-        __syncthreads();
-        compute((kt + 1) & 1);
-      }
-    }
   } else {
     // two register stages: a tile's global loads are issued two K steps before they are written to LDS
     Stage s0, s1;
@@ -469,7 +419,6 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
   const int ntn = (p.ncols + BN - 1) / BN;
-  const int KT_TILE = p.KH * p.KW * (p.cin_pad / 32);   // K steps of a whole output tile
   const int wm = wave & 3;
 #ifdef ZS3_CONV_TIMING
   const long t_kernel0 = __builtin_readcyclecounter();
@@ -481,9 +430,50 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
   // leaves idle are taken by the weight-gradient streams.  The layers it applied to (3x3 of layer 3, ASPP) moved to the
   // strip-resident kernel in round 3 and the path was removed.)
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int kb = 0, KT = KT_TILE;
   const int mt = tile / ntn, nt = tile - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
+  // ---- filter taps that read nothing but padding for EVERY row of this tile are skipped (round 5).  The K loop runs tap-major,
+  // so a dead tap is a contiguous run of cin_pad / 32 K steps whose A rows all come from the zero page: 3x3 at dilation 18 on a
+  // 33 x 33 map -- ASPP's last branch -- has its taps above (below) the centre row dead for every output row >= 15 (<= 17), and a
+  // tile is 256 consecutive pixels = 7.8 image rows: 5.7 of 9 taps live on average (6.8 at dilation 12, 8.5 at dilation 6).
+  // Adding exact zeros to an accumulator changes nothing, so the result is bit-identical.  Every wave derives the same mask
+  // (lane l looks at rows l, l + 64, l + 128, l + 192; an OR across the wave), hence the same K-step count -- no LDS, no barrier.
+  const int T = p.KH * p.KW;
+  unsigned tapmask = T <= 32 ? (T == 32 ? 0xFFFFFFFFu : (1u << T) - 1u) : 0u;
+  if (T > 1 && T <= 32) {
+    unsigned mk = 0u;
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int q = 0; q < BM / 64; ++q) {
+      const int m = m0 + q * 64 + lane;
+      if (m < p.M) {
+        const int n = m / hw, rem = m - n * hw;
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        for (int t = 0; t < T; ++t) {
+          const int th_ = t / p.KW, tw_ = t - th_ * p.KW;
+          int hi, wi;
+          bool ok;
+          if (p.dgrad) {
+            const int th = oh + p.pad_h - th_ * p.dil, tw = ow + p.pad_w - tw_ * p.dil;
+            const int smask = (1 << p.stride_log2) - 1;
+            hi = th >> p.stride_log2;
+            wi = tw >> p.stride_log2;
+            ok = ((th | tw) >= 0) && (((th | tw) & smask) == 0);
+          } else {
+            hi = oh * p.stride - p.pad_h + th_ * p.dil;
+            wi = ow * p.stride - p.pad_w + tw_ * p.dil;
+            ok = (hi | wi) >= 0;
+          }
+          if (ok && hi < p.H && wi < p.W) mk |= 1u << t;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mk |= (unsigned)__shfl_xor((int)mk, o, 64);
+    tapmask = (unsigned)__builtin_amdgcn_readfirstlane((int)mk);
+    if (tapmask == 0u) tapmask = 1u;     // (cannot happen for a tile with a row inside M; keeps the loop well-formed)
+  }
+  const int KT = (T <= 32 ? __builtin_popcount(tapmask) : T) * (p.cin_pad / 32);   // K steps of this tile
   // ---- the tile's fused epilogue.  Runs in both wave roles with the same barrier sequence; only the consumers hold
   // accumulators (`acc` is a dummy for the producers).
   auto finish_segment = [&](auto role, auto& acc) {
@@ -611,7 +601,9 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
                      : reinterpret_cast<const unsigned short*>(p.zero);
         wstep[j] = ok ? 1 : 0;
       }
-      int kh = 0, kw = 0, c0 = 0, kofs = 0;
+      // current filter tap (live taps only, ascending) / channel offset inside it / offset in the K = taps x cin_pad axis of the weights
+      int tcur = T <= 32 ? __builtin_ctz(tapmask) : 0;
+      int kh = tcur / p.KW, kw = tcur - kh * p.KW, c0 = 0, kofs = tcur * p.cin_pad;
       const float* abase[RA];
       int astep[RA];
       auto tap_addresses = [&]() {   // per-row gather base of the current filter tap (called when a tap starts)
@@ -640,12 +632,16 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
       auto advance = [&]() {
         kofs += 32;
         c0 += 32;
-        if (c0 == p.cin_pad) {
+        if (c0 == p.cin_pad) {   // next LIVE tap (scalar code; past the last one the values are never used)
           c0 = 0;
-          if (++kw == p.KW) {
-            kw = 0;
-            ++kh;
+          ++tcur;
+          if (T <= 32) {
+            const unsigned rest = tcur < 32 ? tapmask >> tcur : 0u;
+            tcur += rest ? __builtin_ctz(rest) : 0;
           }
+          kh = tcur / p.KW;
+          kw = tcur - kh * p.KW;
+          kofs = tcur * p.cin_pad;
         }
       };
       // (A register-staged producer -- global_load_dwordx4 + ds_write_b128 of the same bytes -- was measured against this
@@ -890,30 +886,18 @@ int launch_dma(const ConvArgs& a, int prec, hipStream_t st) {
   return prec == 1 ? launch_dma_prec<1>(a, grid, st) : prec == 4 ? launch_dma_prec<4>(a, grid, st) : launch_dma_prec<3>(a, grid, st);
 }
 
-// ZS3_IGEMM_PIPE=3: tile_cfg 11 / 14 on the three-stage branch-free prefetch loop (round 4).  The two-stage loop keeps its loads
-// under `if (more steps)` branches and hipcc waits vmcnt(0) where such a branch joins -- its ISA waits for the loads it has just
-// issued before every LDS write, i.e. no prefetch inside one workgroup; PIPE 3 fixes that (counted waits, 24 loads in flight).
-// Inside the training step it buys nothing: 45.5-45.7 ms against 44.9-45.1 for PIPE 2, same box (tools/probe/r4v.sh) -- two to four
-// resident workgroups per CU already cover each other's latency.  (The first A/B of this switch showed 43.5 against 46.0 ms: that
-// build's stem raced -- see the barrier in front of epilogue 1 -- its output was zero, and a network of zeros runs every kernel 10-45 %
-// faster on this chip.  bench.py prints the last loss since.)  Default: PIPE 2.
-static bool pipe3() {
-  static const bool v = getenv("ZS3_IGEMM_PIPE") && atoi(getenv("ZS3_IGEMM_PIPE")) == 3;
-  return v;
-}
-
+// (A three-stage branch-free prefetch loop for tile_cfg 11 / 14 -- round 4 -- measured 0.5 ms per step slower than the two-stage loop
+// on a live network and is kept as tools/probe/igemm_pipe3/igemm_pipe3.patch with its numbers.)
 template <int BM, int BN, int PIPE>
 int launch_cfg(const ConvArgs& a, int prec, hipStream_t st) {
   int mt = (a.M + BM - 1) / BM, nt = (a.ncols + BN - 1) / BN;
   dim3 grid(mt * nt), block(256);
   if (a.x_bf16) {   // bf16-stored input: plain-bf16 products on the two-deep-prefetch form of the tile
     if (prec != 1) return -7;
-    static const bool k64 = getenv("ZS3_IGEMM16_K64") ? atoi(getenv("ZS3_IGEMM16_K64")) != 0 : true;
-    static const int pipe16 = getenv("ZS3_IGEMM16_PIPE") ? atoi(getenv("ZS3_IGEMM16_PIPE")) : 2;   // (3: isolated 46.5 us against 43.9 on 256 -> 1024 @33^2, in-step level: tools/probe/r4k.sh, r4m.sh)
-    if (k64 && (a.cin_pad & 63) == 0 && (a.cin_valid & 7) == 0 && (a.ldx & 7) == 0) {
-      if (pipe16 == 3) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 3, true, 64>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true, 64>), grid, block, 0, st, a);
-    } else
+    constexpr bool k64 = true;   // 64-channel K steps on bf16-stored input (32.3 against 34.2 ms per 2-byte step with 32-channel steps)
+    if (k64 && (a.cin_pad & 63) == 0 && (a.cin_valid & 7) == 0 && (a.ldx & 7) == 0)
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true, 64>), grid, block, 0, st, a);
+    else
       hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, 2, true>), grid, block, 0, st, a);
   } else if (prec == 1)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 1, PIPE>), grid, block, 0, st, a);
@@ -992,10 +976,10 @@ static int conv_igemm_impl(const float* x, const void* w_pk, float* y, const flo
     case 2: return launch_cfg<128, 64, 1>(a, prec, st);
     case 3: return launch_cfg<64, 128, 1>(a, prec, st);
     case 4: return launch_cfg<64, 64, 1>(a, prec, st);
-    case 11: return pipe3() && prec != 0 ? launch_cfg<128, 128, 3>(a, prec, st) : launch_cfg<128, 128, 2>(a, prec, st);
+    case 11: return launch_cfg<128, 128, 2>(a, prec, st);
     case 12: return launch_cfg<128, 64, 2>(a, prec, st);
     case 13: return launch_cfg<64, 128, 2>(a, prec, st);
-    case 14: return pipe3() && prec != 0 ? launch_cfg<64, 64, 3>(a, prec, st) : launch_cfg<64, 64, 2>(a, prec, st);
+    case 14: return launch_cfg<64, 64, 2>(a, prec, st);
     case 31: return launch_dma(a, prec, st);
     case 41: return zs3conv::launch_halo(a, 256, prec, st);   // -7: not a stride-1 same-size multi-tap layer (zs3_conv_halo_ok)
     case 42: return zs3conv::launch_halo(a, 192, prec, st);

@@ -19,15 +19,9 @@
 //     writes two full 128-byte row segments (fp32) and the per-column scale / shift are per-lane scalars; bf16 outputs pair
 //     neighbouring columns through one DPP exchange per two values and store 4 bytes per lane.  Nothing is waited for -- the
 //     stores drain under the next tile's MFMAs.
-//   * LOADING epilogues (round 4, `LEPI`: residual / lazily masked skip gradient, accumulate, the fused BatchNorm-backward
-//     sums -- every data-gradient launch of the residual network) would stall the CU's only MFMA waves on memory latency.
-//     They are the PRODUCERS' job: the consumers drop their accumulators into an LDS tile (64 ds_write_b32 per lane, no
-//     wait) and go on multiplying the next tile; the producer waves -- which issue the kernel's global loads anyway and
-//     have the issue slots -- fetch the epilogue operands of the finished tile as 16-byte row pieces in the same
-//     three-steps-ahead stream as the operand loads, combine them with the LDS tile, store the rows coalesced and keep
-//     the BatchNorm-backward column sums in registers (a producer wave owns 32 columns of all the tile's rows, so the
-//     column sums reduce inside the wave by shuffles: deterministic, no barrier).  The epilogue of tile j thus overlaps the
-//     multiply loop of tile j+1.
+//   * Epilogues that LOAD per element (residual, accumulate, the fused BatchNorm-backward sums: every data-gradient launch of the
+//     residual network) would stall the CU's only MFMA waves on memory latency and stay on conv_igemm.hip's kernels.  (Round 4 ran
+//     them in the producer waves: correct and slower -- tools/probe/pw_lepi/ has the patch and its numbers.)
 // Replaces F.conv2d of the 1x1 nn.Conv2d at resnet.py:33-53 (conv1, conv3), aspp.py:86-88 and their input gradients.
 #include <stdlib.h>
 
@@ -41,13 +35,26 @@ namespace {
 constexpr int PW_BN = 128;
 constexpr int PW_BSTAGE = 2 * 8192;                 // weights of a K step: two 16-channel sub-chunks x 128 columns x 64 B
 constexpr int PW_CTILE = 4 * PW_BN * 4;             // the epilogue's cross-wave column sums (BatchNorm partials)
-constexpr int PW_LDC = PW_BN + 4;                   // floats per row of the LEPI output tile
 // -DZS3_PW_ABLATE=n builds (tools/probe/build_variant.sh; timing probes, wrong results): 1 = no epilogue work (barriers kept),
 // 2 = no MFMAs, 4 = no global loads, 8 = no split / LDS writes, 32 = no BatchNorm sums
 #ifndef ZS3_PW_ABLATE
 #define ZS3_PW_ABLATE 0
 #endif
 int g_pw_wgs = 256;                                 // persistent workgroups per launch (zs3_conv_pw_set_wgs)
+// -DZS3_CONV_TIMING (tools/probe/build_variant.sh + tools/probe/pw_timing.py): per-wave s_memtime split of one workgroup's life,
+// written to the buffer registered with zs3_conv_pw_timing (block `buf[0]` reports)
+#ifdef ZS3_CONV_TIMING
+long* g_pw_timing = nullptr;
+#define HT_DECL long ht_a = 0, ht_b = 0, ht_c = 0, ht_d = 0, ht_last = __builtin_readcyclecounter(); const long ht_start = ht_last;
+#define HT(v) { const long t_ = __builtin_readcyclecounter(); v += t_ - ht_last; ht_last = t_; }
+#define HT_STORE(w) if (tbuf && blockIdx.x == (int)tbuf[0] && lane == 0) { long* o_ = tbuf + 8 + (w) * 5; o_[0] = ht_a; o_[1] = ht_b; o_[2] = ht_c; o_[3] = ht_d; o_[4] = __builtin_readcyclecounter() - ht_start; }
+#define HT_ARG , long* tbuf
+#else
+#define HT_DECL
+#define HT(v)
+#define HT_STORE(w)
+#define HT_ARG
+#endif
 
 // bf16 outputs from the accumulator registers.  Lane (lr, hh) holds column lr of rows R(r) = 32 i + (r & 3) + 8 (r >> 2) + 4 hh.
 // Lanes lr and lr ^ 1 swap one value per row pair (r, r + 1) through a DPP quad permutation, after which the even lane owns
@@ -98,16 +105,16 @@ __device__ __forceinline__ void store_acc_direct16(const ConvArgs& p, const f32x
 
 // INAFF: the producers apply x' = max(x * in_scale[c] + in_shift[c], 0) before the split (conv_common.h: ConvArgs::in_scale).
 // A16  : x is stored as bf16 (plain-bf16 products): 16 bytes = 8 channels per lane and row, copied into the LDS rows.
-// LEPI : loading epilogue run by the producer waves (header comment); Y16: its tensors (y, res, bn_y) are bf16.
-template <int PREC, int BM, bool INAFF = false, bool A16 = false, bool LEPI = false, bool Y16 = false>
-__global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const int ntiles, const int ntn) {
+// RAGGED: cin_valid is not a multiple of the 32-channel K step (48, 24 channels: two data-gradient launches of the decoder): lanes whose
+// channels lie past cin_valid in a tile's last step read the zero page there -- two selects per load that every other launch is spared.
+template <int PREC, int BM, bool INAFF = false, bool A16 = false, bool RAGGED = false>
+__global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const int ntiles, const int ntn HT_ARG) {
+  static_assert(!(RAGGED && INAFF), "the producer-side input transform is instantiated for whole K steps only");
   static_assert(!A16 || (PREC == 1 && !INAFF), "bf16-stored input: plain bf16 products, no producer-side transform");
-  static_assert(!LEPI || BM == 128, "the producers' epilogue tile is 128 rows");
   constexpr int BN = PW_BN, TM = BM / 64, TN = 2;
   constexpr int ASUB = BM * 64;                     // one 16-channel sub-chunk of the activation rows
   constexpr int STAGE = 2 * ASUB + PW_BSTAGE;
   constexpr int OFF_CT = 2 * STAGE;
-  constexpr int OFF_EP = OFF_CT + PW_CTILE;         // (LEPI) BM x PW_LDC floats: the finished tile on its way to the producers
   constexpr int NL = PREC >= 3 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
   const int NK = p.cin_pad >> 5;
   const int S = nmine * NK;                         // K steps of this workgroup
   const int S3 = (S + 2) / 3 * 3;                   // the producers' schedule is unrolled by three (register sets)
-  const int E = (!LEPI && p.stat_partial) ? 1 : 0;  // workgroup barriers of one (consumer-side) epilogue
+  const int E = p.stat_partial ? 1 : 0;  // workgroup barriers of one (consumer-side) epilogue
 
   if (wave >= 4) {
     // ------------------------------------------------------------------ producers (256 lanes)
@@ -138,28 +145,39 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     using XT = std::conditional_t<A16, bf16_t, float>;
     const XT* const xzero = reinterpret_cast<const XT*>(p.zero);
     const long rstep = RSTEP * (long)p.ldx;
-    // load stream state: tile / K step of the next request
+    // load stream state: tile / K step of the next request.  Every load address is a per-lane POINTER that advances by a per-lane
+    // increment each K step (a masked row points at the zero page and does not move): the round-3 form recomputed base + step *
+    // stride with two selects per load -- 70 of the 118 VALU instructions of a producer interval, and the timing build
+    // (tools/probe/pw_timing.py) showed the producers' issue time, not memory latency, bounding the K loop (1340 cycles per
+    // step against 990 for the MFMA waves).
     int lt = first, lk = 0;
-    const XT* abase = nullptr;
-    unsigned rowmask = 0u;
-    const unsigned char* wptr[2];
-    int wstep[2];
+    const XT* ap[NRA];
+    int ainc[NRA];
+    const unsigned char* wp_[2];
+    int winc[2];
+    const float* scp = nullptr;
+    // K steps for which this lane's channels lie inside cin_valid (all NK of them unless the last chunk is ragged: 48, 304 channels)
+    const int klim = p.cin_valid > chan0 ? (p.cin_valid - chan0 + 31) >> 5 : 0;
     auto setup_tile = [&](int tile) {
       tile = tile < ntiles ? tile : first + (nmine - 1) * G;   // past the end: re-request the last tile (never multiplied)
       const int mt = tile / ntn, nt = tile - mt * ntn;
       const int m0 = mt * BM, n0 = nt * BN;
-      abase = reinterpret_cast<const XT*>(p.x) + (long)(m0 + prow) * p.ldx + chan0;
-      rowmask = 0u;
+      const XT* abase = reinterpret_cast<const XT*>(p.x) + (long)(m0 + prow) * p.ldx + chan0;
 #pragma unroll
-      for (int r = 0; r < NRA; ++r) rowmask |= (m0 + prow + RSTEP * r < p.M ? 1u : 0u) << r;
+      for (int r = 0; r < NRA; ++r) {
+        const bool ok = m0 + prow + RSTEP * r < p.M;
+        ap[r] = ok ? abase + r * rstep : xzero;
+        ainc[r] = ok ? 32 : 0;
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int col = n0 + wrow + 64 * e;
         const bool ok = col < p.ncols;
-        wptr[e] = ok ? reinterpret_cast<const unsigned char*>(p.w_pk) + (size_t)col * (4 * (size_t)p.ldw) + qoff
-                     : reinterpret_cast<const unsigned char*>(p.zero);
-        wstep[e] = ok ? 1 : 0;
+        wp_[e] = ok ? reinterpret_cast<const unsigned char*>(p.w_pk) + (size_t)col * (4 * (size_t)p.ldw) + qoff
+                    : reinterpret_cast<const unsigned char*>(p.zero);
+        winc[e] = ok ? 128 : 0;
       }
+      if constexpr (INAFF) scp = p.in_scale + c8 * 4;
     };
     struct StepRegs {
       f32x4 a[NRA];      // four fp32 channels, or (A16) eight bf16 channels as raw bits
@@ -168,22 +186,23 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     };
     StepRegs buf[3];
     auto load_step = [&](StepRegs& d) {
-      const bool cok = lk * 32 + chan0 < p.cin_valid;
-      const XT* src = abase + lk * 32;
+      const bool cok = !RAGGED || lk < klim;
       if (!(ZS3_PW_ABLATE & 4)) {
 #pragma unroll
         for (int r = 0; r < NRA; ++r) {
-          const XT* s = (cok && ((rowmask >> r) & 1u)) ? src + r * rstep : xzero;
-          d.a[r] = *reinterpret_cast<const f32x4*>(s);
+          d.a[r] = *reinterpret_cast<const f32x4*>(cok ? ap[r] : xzero);
+          ap[r] += ainc[r];
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < 2; ++e) {
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            d.w[e][s] = *reinterpret_cast<const u32x4*>(wptr[e] + (size_t)(lk * 128 + s * 32) * wstep[e]);
+          for (int s = 0; s < 2; ++s) d.w[e][s] = *reinterpret_cast<const u32x4*>(wp_[e] + s * 32);
+          wp_[e] += winc[e];
+        }
         if constexpr (INAFF) {
-          d.sc = *reinterpret_cast<const f32x4*>(cok ? p.in_scale + lk * 32 + c8 * 4 : p.zero);
-          d.sh = *reinterpret_cast<const f32x4*>(cok ? p.in_shift + lk * 32 + c8 * 4 : p.zero);
+          d.sc = *reinterpret_cast<const f32x4*>(cok ? scp : p.zero);
+          d.sh = *reinterpret_cast<const f32x4*>(cok ? scp + (p.in_shift - p.in_scale) : p.zero);
+          scp += 32;
         }
       }
       if (++lk == NK) {
@@ -223,149 +242,6 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         for (int c = 0; c < 2; ++c) *reinterpret_cast<u32x4*>(sb + c * 8192 + e * 4096 + wdst) = s.w[e][c];
     };
 
-    // ---- (LEPI) the loading epilogue.  One `pass` = this wave's 32 columns x 16 rows of the finished tile; a lane owns eight
-    // values of it: bf16 tensors -- eight consecutive columns of one row (one 16-byte piece of y / res / bn_y); fp32 tensors --
-    // four consecutive columns of rows rip and rip + 8 (two 16-byte pieces).  The per-column BatchNorm operands of the tile sit in
-    // LDS (the 2 KB the consumer-side epilogue uses for its column sums: unused here), not in registers.
-    constexpr int EW = 8, CW = Y16 ? 8 : 4, NR = EW / CW, LPR = 32 / CW, NPASS = LEPI ? BM / 16 : 1;
-    using YT = std::conditional_t<Y16, bf16_t, float>;
-    using MT = std::conditional_t<Y16, unsigned short, unsigned char>;   // a row piece's mask bits: one byte per four columns
-    const int pw = wave - 4, rip = lane / LPR, ecol = 32 * pw + (lane % LPR) * CW;   // row in pass, first column in the tile
-    struct EpiRegs {
-      f32x4 ro[NR], by[NR];   // raw 16-byte pieces: res or (accumulate) the old y -- never both in one launch --, and bn_y
-      unsigned rm, bm;        // mask bytes of the NR pieces (piece n in bits 16 n ..)
-    };
-    EpiRegs ebuf[3][LEPI ? (Y16 ? 2 : 1) : 1];
-    float bs_s[CW], bs_q[CW];
-    float* const ccol = reinterpret_cast<float*>(dsm + OFF_CT);   // [4][128]: istd, -mean * istd, mask scale, mask shift
-    int e_m0 = 0, e_n0 = 0, e_mt = 0;          // tile whose epilogue is in progress
-    int e_issue = NPASS, e_cons = NPASS;       // next pass to request / to finish (NPASS: none)
-    int npend[3] = {0, 0, 0};                  // passes requested into register set 0 / 1 / 2 and not finished yet
-    auto epi_begin = [&](int tile) {
-      const int mt = tile / ntn, nt = tile - mt * ntn;
-      e_mt = mt; e_m0 = mt * BM; e_n0 = nt * BN;
-      e_issue = 0; e_cons = 0;
-#pragma unroll
-      for (int e = 0; e < CW; ++e) {
-        bs_s[e] = 0.f;
-        bs_q[e] = 0.f;
-      }
-      if (p.bs_partial && lane < 32) {           // this wave's 32 columns; read back by the same wave only
-        const int c = 32 * pw + lane, col = e_n0 + c;
-        const bool cok = col < p.ncols;
-        const float is = cok ? p.bs_istd[col] : 0.f;
-        ccol[c] = is;
-        ccol[128 + c] = cok ? -p.bs_mean[col] * is : 0.f;
-        ccol[256 + c] = (cok && p.bs_msc) ? p.bs_msc[col] : 0.f;
-        ccol[384 + c] = (cok && p.bs_msc) ? p.bs_msh[col] : 0.f;
-      }
-    };
-    auto epi_issue = [&](EpiRegs& d) -> int { // request pass e_issue (if any); 1 when a request was made
-      if (e_issue >= NPASS) return 0;
-      const int col = e_n0 + ecol;
-      const YT* zero = reinterpret_cast<const YT*>(p.zero);
-      const unsigned char* zb = reinterpret_cast<const unsigned char*>(p.zero);
-      const YT* rsrc = reinterpret_cast<const YT*>(p.accumulate ? p.y : p.res);
-      const int ldro = p.accumulate ? p.ldy : p.ldr;
-      d.rm = 0u;
-      d.bm = 0u;
-#pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const int row = e_m0 + e_issue * 16 + rip + 8 * n;
-        const bool ok = row < p.M && col < p.ncols;
-        if (rsrc) d.ro[n] = *reinterpret_cast<const f32x4*>(ok ? rsrc + (size_t)row * ldro + col : zero);
-        if (p.bs_partial) d.by[n] = *reinterpret_cast<const f32x4*>(ok ? reinterpret_cast<const YT*>(p.bs_y) + (size_t)row * p.bs_ldy + col : zero);
-        const size_t mi = (size_t)row * (p.ncols >> 2) + (col >> 2);
-        if (p.res_mbits) d.rm |= (unsigned)*reinterpret_cast<const MT*>(ok ? p.res_mbits + mi : zb) << (16 * n);
-        if (p.bs_mbits) d.bm |= (unsigned)*reinterpret_cast<const MT*>(ok ? p.bs_mbits + mi : zb) << (16 * n);
-      }
-      ++e_issue;
-      return 1;
-    };
-    auto unpack = [&](const f32x4 raw, float (&o)[CW]) {
-      if constexpr (Y16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned u = __float_as_uint(raw[e]);
-          o[2 * e] = __uint_as_float(u << 16);
-          o[2 * e + 1] = __uint_as_float(u & 0xFFFF0000u);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = raw[e];
-      }
-    };
-    auto epi_consume = [&](const EpiRegs& s) {   // finish pass e_cons with the operands requested into `s`
-
-      const int col = e_n0 + ecol;
-      const bool have_ro = p.res != nullptr || p.accumulate;
-#pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const int rloc = e_cons * 16 + rip + 8 * n;
-        const int row = e_m0 + rloc;
-        const bool ok = row < p.M && col < p.ncols;
-        const float* ct = reinterpret_cast<const float*>(dsm + OFF_EP) + rloc * PW_LDC + ecol;
-        float v[CW], t[CW];
-#pragma unroll
-        for (int e = 0; e < CW; e += 4) {
-          const f32x4 c = *reinterpret_cast<const f32x4*>(ct + e);
-          v[e] = c[0]; v[e + 1] = c[1]; v[e + 2] = c[2]; v[e + 3] = c[3];
-        }
-        if (have_ro) {
-          unpack(s.ro[n], t);
-          const unsigned rm = p.res_mbits ? (s.rm >> (16 * n)) : 0xFFFFFFFFu;
-#pragma unroll
-          for (int e = 0; e < CW; ++e) v[e] += ((rm >> (8 * (e >> 2) + (e & 3))) & 1u) ? t[e] : 0.f;   // one mask byte per four columns
-        }
-        if constexpr (Y16) {
-          u32x4 pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            pk[e] = cvt_pk_bf16(v[2 * e], v[2 * e + 1]);
-            v[2 * e] = __uint_as_float(pk[e] << 16);              // the sums below see what the next kernel will read
-            v[2 * e + 1] = __uint_as_float(pk[e] & 0xFFFF0000u);
-          }
-          if (ok) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.y) + (size_t)row * p.ldy + col) = pk;
-        } else {
-          if (ok) *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = f32x4{v[0], v[1], v[2], v[3]};
-        }
-        if (p.bs_partial) {
-          unpack(s.by[n], t);
-          const unsigned bm = s.bm >> (16 * n);
-#pragma unroll
-          for (int e = 0; e < CW; ++e) {
-            bool on = ok;
-            if (p.bs_mbits) on = on && ((bm >> (8 * (e >> 2) + (e & 3))) & 1u);
-            else if (p.bs_msc) on = on && (fmaf(t[e], ccol[256 + ecol + e], ccol[384 + ecol + e]) > 0.f);
-            const float dz = on ? v[e] : 0.f;
-            bs_s[e] += dz;
-            bs_q[e] = fmaf(dz, fmaf(t[e], ccol[ecol + e], ccol[128 + ecol + e]), bs_q[e]);
-          }
-        }
-      }
-      if (++e_cons == NPASS && p.bs_partial) {   // the tile's column sums: rows live in lane bits log2(LPR) .. 5
-#pragma unroll
-        for (int e = 0; e < CW; ++e) {
-#pragma unroll
-          for (int o = LPR; o < 64; o <<= 1) {
-            bs_s[e] += __shfl_xor(bs_s[e], o, 64);
-            bs_q[e] += __shfl_xor(bs_q[e], o, 64);
-          }
-        }
-        if (rip == 0 && col < p.ncols) {
-#pragma unroll
-          for (int e = 0; e < CW; ++e) {
-            p.bs_partial[((size_t)e_mt * 2 + 0) * p.ncols + col + e] = bs_s[e];
-            p.bs_partial[((size_t)e_mt * 2 + 1) * p.ncols + col + e] = bs_q[e];
-          }
-        }
-      }
-    };
-    // passes per interval: the epilogue of a tile is requested in intervals 1 .. NK - 4 of the following tile (its LDS tile is
-    // complete after the first barrier of that tile and is overwritten after the last) and finished three intervals later
-    constexpr int PPI_MAX = Y16 ? 2 : 1;
-    const int ppi = LEPI ? (NPASS + (NK - 4) - 1) / (NK - 4) : 0;   // <= PPI_MAX (pw_lepi_ok: NK >= 8 with bf16 tensors, >= 12 with fp32)
-
     // prologue: step 0 in stage 0; steps 1, 2, 3 requested into register sets 1, 2, 0
     setup_tile(first);
     load_step(buf[0]);
@@ -375,58 +251,34 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     load_step(buf[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // B_0
+    HT_DECL   // producers: a = waiting for the loads of the step to be written, b = split + LDS writes + next requests, c = barriers, d = prologue
+    HT(ht_d)
     // interval i (the consumers multiply step i): write step i + 1 into the other stage, request step i + 4.  An interval
     // that starts a tile (i = NK, 2 NK, ...) also takes part in the E barriers of the previous tile's epilogue.
-    int nexttile = NK, kloc = 0, tdone = 0;   // kloc: K step of interval i inside its tile; tdone: tiles fully multiplied before it
+    int nexttile = NK;
     for (int i0 = 0; i0 < S3; i0 += 3) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int i = i0 + r;
+#ifdef ZS3_CONV_TIMING
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NRA + 4 + (INAFF ? 2 : 0))) : "memory");
+        HT(ht_a)
+#endif
         write_step(buf[(r + 1) % 3], (i + 1) & 1);
         load_step(buf[(r + 1) % 3]);
-        if constexpr (LEPI) {
-          // (register set (r + 1) % 3: what was requested three intervals ago is finished now, then re-requested)
-#pragma unroll
-          for (int q = 0; q < PPI_MAX; ++q)
-            if (q < npend[(r + 1) % 3]) epi_consume(ebuf[(r + 1) % 3][q]);
-          npend[(r + 1) % 3] = 0;
-          if (kloc == 1 && tdone >= 1 && i < S) epi_begin(first + (tdone - 1) * G);
-#pragma unroll
-          for (int q = 0; q < PPI_MAX; ++q)
-            if (q < ppi) npend[(r + 1) % 3] += epi_issue(ebuf[(r + 1) % 3][q]);
-          if (++kloc == NK) {
-            kloc = 0;
-            ++tdone;
-          }
-        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HT(ht_b)
         if (i == nexttile) {
           nexttile += NK;
           if (i < S)
             for (int e = 0; e < E; ++e) __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_s_barrier();   // B_{i+1}: step i + 1 is in LDS
+        HT(ht_c)
       }
     }
     for (int e = 0; e < E; ++e) __builtin_amdgcn_s_barrier();   // the last tile's epilogue
-    if constexpr (LEPI) {
-      // passes still in flight belong to the second-to-last tile only if the padding intervals did not drain them: finish them,
-      // then the last tile (its LDS tile is complete after the barrier below), two passes at a time
-#pragma unroll
-      for (int r = 1; r < 4; ++r)     // (issue order of the register sets: 1, 2, 0)
-#pragma unroll
-        for (int q = 0; q < PPI_MAX; ++q)
-          if (q < npend[r % 3]) epi_consume(ebuf[r % 3][q]);
-      __builtin_amdgcn_s_barrier();   // X: the consumers have written the last tile
-      epi_begin(first + (nmine - 1) * G);
-      for (int t = 0; t < NPASS; t += 3) {   // three passes in flight (the register sets of the pipelined form)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) npend[r] = epi_issue(ebuf[r][0]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-          if (npend[r]) epi_consume(ebuf[r][0]);
-      }
-    }
+    HT_STORE(wave)
   } else {
     // ------------------------------------------------------------------ consumers: ds_read_b128 + MFMA, then the epilogue
     const int wm = (wave >> 1) & 1, wn = wave & 1;
@@ -496,6 +348,8 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
       asm volatile("" ::: "memory");
     };
     int gs = 0;   // global K-step counter (stage = gs & 1)
+    HT_DECL   // consumers: a = MFMA sub-steps, b = epilogues, c = K-step barriers, d = before the first step
+    HT(ht_d)
     for (int tj = 0; tj < nmine; ++tj) {
       const int tile = first + tj * G;
       const int mt = tile / ntn, nt = tile - mt * ntn;
@@ -511,9 +365,12 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         const unsigned char* nxt = dsm + ((gs + 1) & 1) * STAGE;
         substep(std::integral_constant<int, 0>{}, cur, 1);   // channels 0..15 of the step; fetch 16..31
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        HT(ht_a)
         __builtin_amdgcn_s_barrier();                        // B_{gs+1}: the other stage holds step gs + 1
         asm volatile("" ::: "memory");
+        HT(ht_c)
         substep(std::integral_constant<int, 1>{}, nxt, 0);   // channels 16..31; fetch the next step's 0..15
+        HT(ht_a)
       }
       // ---- epilogue of this tile (consumer waves only; the producers are already filling the next tile's stages)
 #pragma unroll
@@ -524,20 +381,6 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         for (int e = 0; e < E; ++e) __builtin_amdgcn_s_barrier();
         if (m0 < 0) p.y[tid] = acc[0][0][0] + acc[TM - 1][1][5];
         continue;
-      }
-      if constexpr (LEPI) {
-        // hand the tile to the producer waves: the previous tile's LDS copy was consumed before the last barrier above
-        float* ep = reinterpret_cast<float*>(dsm + OFF_EP);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-              ep[row * PW_LDC + wn * 64 + j * 32 + lr] = acc[i][j][r];
-            }
-        continue;   // (the next K-step barrier, or barrier X after the last tile, publishes it)
       }
       // straight from the accumulator registers; only the per-column BatchNorm sums cross waves (2 KB of LDS, one barrier)
       if ((ZS3_PW_ABLATE & 32) && p.stat_partial) {
@@ -574,12 +417,10 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
       }
       if (p.y_bf16) store_acc_direct16<TM, TN, BM, BN>(p, acc, m0, n0, wm, wn, lane);
       else store_acc_direct<TM, TN, BM, BN>(p, acc, m0, n0, wm, wn, lane);
+      HT(ht_b)
     }
     for (int e = S; e < S3; ++e) __builtin_amdgcn_s_barrier();   // the producers' schedule is padded to a multiple of three
-    if constexpr (LEPI) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // X: the last tile is in LDS for the producers
-    }
+    HT_STORE(wave)
   }
 }
 
@@ -589,23 +430,13 @@ bool pw_geom_ok(const ConvArgs& a, int bm) {
   if ((a.ldx & 3) || (a.cin_valid & 3) || (a.cin_pad & 31) || a.cin_pad < 32 || a.M <= 0) return false;
   return bm == 256 || bm == 128;
 }
-// loading epilogues: the producers' form (LEPI) -- 128-row tiles, >= 8 K steps per tile, vector-aligned tensors
-bool pw_lepi_ok(const ConvArgs& a, int bm) {
-  const int ew = a.y_bf16 ? 8 : 4;
-  if (bm != 128 || (a.cin_pad >> 5) < (a.y_bf16 ? 8 : 12) || (a.res && a.accumulate) || a.stat_partial || a.scale || a.shift || a.act || a.in_scale) return false;
-  if ((a.ncols % ew) || (a.ldy % ew) || (a.res && (a.ldr % ew)) || (a.bs_partial && (a.bs_ldy % ew))) return false;
-  if (a.bs_partial && (!a.bs_y || !a.bs_mean || !a.bs_istd)) return false;
-  if (a.res_mbits && !a.res) return false;
-  return true;
-}
-
-template <int PREC, int BM, bool INAFF = false, bool A16 = false, bool LEPI = false, bool Y16 = false>
-int launch_pw_t(const ConvArgs& a, hipStream_t st) {
+template <int PREC, int BM, bool INAFF = false, bool A16 = false, bool RAGGED = false>
+int launch_pw_r(const ConvArgs& a, hipStream_t st) {
   static bool configured = false;
-  constexpr int LDS = 2 * (2 * BM * 64 + PW_BSTAGE) + PW_CTILE + (LEPI ? BM * PW_LDC * 4 : 0);
+  constexpr int LDS = 2 * (2 * BM * 64 + PW_BSTAGE) + PW_CTILE;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<PREC, BM, INAFF, A16, LEPI, Y16>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<PREC, BM, INAFF, A16, RAGGED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return -4;
     configured = true;
@@ -613,29 +444,35 @@ int launch_pw_t(const ConvArgs& a, hipStream_t st) {
   const int ntn = (a.ncols + PW_BN - 1) / PW_BN;
   const int ntiles = ((a.M + BM - 1) / BM) * ntn;
   const int grid = ntiles < g_pw_wgs ? ntiles : g_pw_wgs;
-  hipLaunchKernelGGL((conv_pw_kernel<PREC, BM, INAFF, A16, LEPI, Y16>), dim3(grid), dim3(512), LDS, st, a, ntiles, ntn);
+#ifdef ZS3_CONV_TIMING
+  hipLaunchKernelGGL((conv_pw_kernel<PREC, BM, INAFF, A16, RAGGED>), dim3(grid), dim3(512), LDS, st, a, ntiles, ntn, g_pw_timing);
+#else
+  hipLaunchKernelGGL((conv_pw_kernel<PREC, BM, INAFF, A16, RAGGED>), dim3(grid), dim3(512), LDS, st, a, ntiles, ntn);
+#endif
   return ZS3_LAUNCH_CHECK();
+}
+
+template <int PREC, int BM, bool INAFF = false, bool A16 = false>
+int launch_pw_t(const ConvArgs& a, hipStream_t st) {
+  if (a.cin_valid & 31) {
+    if constexpr (INAFF) return -7;
+    else return launch_pw_r<PREC, BM, false, A16, true>(a, st);
+  }
+  return launch_pw_r<PREC, BM, INAFF, A16, false>(a, st);
 }
 
 }  // namespace
 
 int zs3conv::pw_eligible(const ConvArgs& a, int bm) {
   if (!pw_geom_ok(a, bm)) return 0;
-  return direct_epilogue(a) ? 1 : (pw_lepi_ok(a, bm) ? 1 : 0);
+  return direct_epilogue(a) ? 1 : 0;
 }
 
 int zs3conv::launch_pw(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   if (!pw_geom_ok(a, bm)) return -7;
   if (a.x_bf16 && (prec != 1 || (a.ldx & 7) || (a.cin_valid & 7) || a.in_scale)) return -7;
   if (a.y_bf16 && (a.ncols & 1)) return -7;
-  if (!direct_epilogue(a)) {   // residual / accumulate / fused BatchNorm-backward sums: the producers' epilogue
-    if (!pw_lepi_ok(a, bm)) return -7;
-    if (a.x_bf16 && a.y_bf16) return launch_pw_t<1, 128, false, true, true, true>(a, st);
-    if (prec == 4) return -7;   // f16x3 is the forward arithmetic; loading epilogues belong to data-gradient launches
-    if (!a.x_bf16 && !a.y_bf16) return prec == 1 ? launch_pw_t<1, 128, false, false, true, false>(a, st)
-                                                 : launch_pw_t<3, 128, false, false, true, false>(a, st);
-    return -7;                 // mixed element types (the classifier's data gradient): the register-staged kernels
-  }
+  if (!direct_epilogue(a)) return -7;   // residual / accumulate / fused BatchNorm-backward sums: conv_igemm.hip's kernels
   if (a.x_bf16) return bm == 256 ? launch_pw_t<1, 256, false, true>(a, st) : launch_pw_t<1, 128, false, true>(a, st);
   if (a.in_scale) {   // input transform (the producing layer's BatchNorm-apply + ReLU) in the producer waves
     if (!a.in_shift) return -1;
@@ -648,7 +485,7 @@ int zs3conv::launch_pw(const ConvArgs& a, int bm, int prec, hipStream_t st) {
 }
 
 // Whether tile_cfg 51 / 52 can run this convolution's GEOMETRY (1x1, stride 1, no padding; callers fall back to tile_cfg 31
-// otherwise).  Loading epilogues additionally need tile_cfg 52 and cin_pad >= 256 (zs3_conv_igemm returns -7 otherwise).
+// otherwise).  Store-only epilogues only (zs3_conv_igemm returns -7 otherwise).
 extern "C" int zs3_conv_pw_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
                               int pad_h, int pad_w, int tile_cfg) {
   ConvArgs a{};
@@ -658,6 +495,13 @@ extern "C" int zs3_conv_pw_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, 
   a.M = N * Ho * Wo;
   return pw_geom_ok(a, tile_cfg == 52 ? 128 : 256) ? 1 : 0;
 }
+
+#ifdef ZS3_CONV_TIMING
+extern "C" int zs3_conv_pw_timing(long* buf) {   // device int64 buffer: [0] = reporting block, [8 + 5 wave ..] = that block's per-wave cycle split
+  g_pw_timing = buf;
+  return 0;
+}
+#endif
 
 // Persistent workgroups per launch of tile_cfg 51 / 52 (default 256 = one per CU); returns the previous value.  Tests set a
 // small number so that small problems exercise the cross-tile pipeline.

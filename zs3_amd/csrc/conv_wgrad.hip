@@ -554,21 +554,13 @@ int pick_splitk(int M, int tiles) {
 
 // 128-wide tiles whenever there are more than 64 channels (measured: a half-empty 128 tile still beats 64-wide tiles)
 static int pick_tile_dim(int c) { return c > 64 ? 128 : 64; }
-static int env_int(const char* name) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : 0;
-}
-static int tile_override() {
-  static int v = -1;
-  if (v < 0) v = env_int("ZS3_WGRAD_TILE");
-  return v;
-}
+static int tile_override() { return 0; }   // (64: force 64 x 64 tiles; a debug knob of round 1)
 // kernel 2 (LDS-DMA, 256x256 tiles) takes the leading multiple-of-256 input channels when Cout fills 256-wide tiles;
 // a remainder of <= 128 input channels (the 304-channel decoder concat) goes to kernel 1 in a second launch over the
-// same split-K slabs.  Returns the number of input channels given to kernel 2.  ZS3_WGRAD_KERNEL=1|2 forces one (debug).
-static int g_wgrad_kernel = -1;   // zs3_conv_wgrad_set_kernel; -1: ZS3_WGRAD_KERNEL from the environment
+// same split-K slabs.  Returns the number of input channels given to kernel 2.  zs3_conv_wgrad_set_kernel(1 | 2) forces one.
+static int g_wgrad_kernel = -1;   // zs3_conv_wgrad_set_kernel (-1: not set yet = 0, the rules)
 static int dma_width(int co, int ci, int wo, int M) {
-  if (g_wgrad_kernel < 0) g_wgrad_kernel = env_int("ZS3_WGRAD_KERNEL");
+  if (g_wgrad_kernel < 0) g_wgrad_kernel = 0;
   const int v = g_wgrad_kernel;
   if (v == 1) return 0;
   if (v == 2) return ci;
@@ -585,9 +577,6 @@ static int pick_splitk_dma(int M, int tiles, long out_elems) {
   int maxs = M / 256;   // at least 16 K-steps (256 pixels) per split
   if (maxs < 1) maxs = 1;
   if (maxs > 128) maxs = 128;
-  static int forced = -1;
-  if (forced < 0) forced = env_int("ZS3_WGRAD_SPLIT");   // debug knob
-  if (forced > 0) return forced < maxs ? forced : maxs;
   const int cus = wgrad_cus();
   const double slab_units = (double)out_elems * 4.0 * 2.0 / 1e12 / 1.5e-6;
   const long ksteps = (M + 15) / 16;
@@ -606,7 +595,7 @@ static int pick_splitk_dma(int M, int tiles, long out_elems) {
 // 0: the rules above, 1: register-staged kernel for every layer (what the exact-fp32 test mode, prec = 0, needs), 2: LDS-DMA kernel
 // wherever Cin allows; returns the previous value.  Plans (zs3_conv_wgrad_plan) made under another setting are stale.
 extern "C" int zs3_conv_wgrad_set_kernel(int kernel) {
-  if (g_wgrad_kernel < 0) g_wgrad_kernel = env_int("ZS3_WGRAD_KERNEL");
+  if (g_wgrad_kernel < 0) g_wgrad_kernel = 0;
   const int old = g_wgrad_kernel;
   if (kernel >= 0 && kernel <= 2) g_wgrad_kernel = kernel;
   return old;

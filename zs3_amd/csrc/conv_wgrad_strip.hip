@@ -583,8 +583,7 @@ struct StripPlan {
 StripPlan strip_plan(int N, int H, int W, int Ho, int Wo, int KH, int KW, int stride, int pad_h, int pad_w, int dil, int co,
                      int ci) {
   StripPlan s{};
-  static const int enabled = getenv("ZS3_WGRAD_STRIP") ? atoi(getenv("ZS3_WGRAD_STRIP")) : 1;
-  if (!enabled || KH != 3 || KW != 3 || stride != 1 || H != Ho || W != Wo || pad_h != dil || pad_w != dil) return s;
+  if (KH != 3 || KW != 3 || stride != 1 || H != Ho || W != Wo || pad_h != dil || pad_w != dil) return s;
   if (co < 64 || ci < 64) return s;
   const int Wd = W + dil, Hd = H + dil;
   if (Wd <= 16) return s;
@@ -630,8 +629,7 @@ struct PwPlan {
 
 PwPlan pw_plan(long M, int co, int ci) {
   PwPlan s{};
-  static const int enabled = getenv("ZS3_WGRAD_PW") ? atoi(getenv("ZS3_WGRAD_PW")) : 1;
-  if (!enabled || co < 64 || ci < 64 || M < 32 * 12) return s;
+  if (co < 64 || ci < 64 || M < 32 * 12) return s;
   s.nco = co >= 128 ? 2 : 1;
   s.nci = ci >= 128 ? 2 : 1;
   s.lds_bytes = 2 * (s.nco + s.nci) * PW_ARRAY;

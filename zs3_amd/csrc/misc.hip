@@ -141,8 +141,11 @@ __global__ void sgd_kernel(float* p, const float* g, float* buf, long n, float l
 // multi-tensor SGD: one launch for the whole parameter set.  table[e] = {p, g, buf, n, lr|wd (two packed floats), first};
 // blockmap[b] = {entry, chunk}: block b updates elements [chunk*CHUNK, (chunk+1)*CHUNK) of entry e.
 #define ZS3_SGD_CHUNK 16384
+// skip_flag (optional): the sticky range flag of the f16x3 forward (zs3_bn_fwd_finalize).  While it is up the step that produced
+// these gradients multiplied operands beyond fp16's range: parameters and momentum stay as they are (a skipped step, like a loss
+// scaler's overflow step); a momentum buffer that this step would have created is zeroed so that the next step starts it.
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const long* __restrict__ table, const int* __restrict__ blockmap,
-                                                       float momentum, int nesterov) {
+                                                       float momentum, int nesterov, const int* __restrict__ skip_flag) {
   const int e = blockmap[2 * blockIdx.x], chunk = blockmap[2 * blockIdx.x + 1];
   const long* t = table + 6L * e;
   float* p = reinterpret_cast<float*>(t[0]);
@@ -152,6 +155,11 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const long* __restrict__
   const float lr = __uint_as_float((unsigned)(t[4] & 0xFFFFFFFFL)), wd = __uint_as_float((unsigned)(t[4] >> 32));
   const int first = (int)t[5];
   const long lo = (long)chunk * ZS3_SGD_CHUNK, hi = min(n, lo + ZS3_SGD_CHUNK);
+  if (skip_flag && *skip_flag) {
+    if (first && momentum != 0.f)
+      for (long i = lo + threadIdx.x; i < hi; i += 256) buf[i] = 0.f;
+    return;
+  }
   for (long i = lo + threadIdx.x; i < hi; i += 256) {
     float d = g[i] + wd * p[i];
     if (momentum != 0.f) {
@@ -472,10 +480,10 @@ extern "C" int zs3_sgd_step(float* p, const float* g, float* buf, long n, float 
 
 extern "C" int zs3_sgd_chunk(void) { return ZS3_SGD_CHUNK; }
 extern "C" int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov,
-                             void* stream) {
+                             const int* skip_flag, void* stream) {
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL(sgd_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)table,
-                     (const int*)blockmap, momentum, nesterov);
+                     (const int*)blockmap, momentum, nesterov, skip_flag);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -24,9 +24,9 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 WGRAD_SIDE_STREAM = True
 # Side streams inside a hipGraph capture (GraphedStep): the side stream joins the capture through its wait on the capturing stream
 # and is joined back by the end-of-backward callback, so the captured graph keeps the dgrad / wgrad overlap of the eager step.
-CAPTURE_SIDE_STREAMS = os.environ.get("ZS3_CAPTURE_SIDE", "0") == "1"   # (probe: tools/probe/graph_probe.py -- 36.2 ms with, 36.8 without for fwd + bwd in the 2-byte mode: hipGraph replay does not overlap the branches; off)
+CAPTURE_SIDE_STREAMS = False   # (probe: tools/probe/graph_probe.py -- 36.2 ms with, 36.8 without for fwd + bwd in the 2-byte mode: hipGraph replay does not overlap the branches; off)
 FUSE_BN_BWD_STATS = True   # BN-backward sums produced by the sole consumer's dgrad epilogue (BnLink)
-DROPOUT_FUSED = os.environ.get("ZS3_DROPOUT_FUSED", "1") != "0"   # nn.Dropout behind conv+BN+ReLU inside the BN-apply pass
+DROPOUT_FUSED = True   # nn.Dropout behind conv+BN+ReLU inside the BN-apply pass
 # BN-apply + ReLU in the sole consumer's operand path (conv_bn_act: next_conv).  Same-box A/B, ms per step: off 46.64 / 46.87, on
 # 46.51 / 46.47, on for 3x3 consumers only 46.68 / 46.67 (tools/probe/ab_env.sh; per layer: tools/probe/defer_bench.py)
 DEFER_BN_APPLY = os.environ.get("ZS3_DEFER_BN", "1") == "1"
@@ -115,6 +115,37 @@ def forward_is_f16x3(prec, bn):
     untrained network in eval() mode lets activations grow to 1e4 and beyond (running statistics 0 / 1 normalise nothing), which
     fp16 cannot hold, and eval mode is well-conditioned anyway (logits 3e-5 from the reference)."""
     return bool(ops.fwd_f16() and prec in (None, 3, 4) and bn is not None and bn["training"])
+
+
+def check_forward_range(device=None, flag_value=None):
+    """Range guard of the f16x3 forward.  fp16 hi/lo operands hold |x| <= 65504 (weights: |w| < 1023); the
+    rule that selects them (batch-statistics layers: inputs are batch-normalised activations or the image) keeps real networks far
+    inside that, but nothing in the data enforces it.  A layer whose operands overflowed produces non-finite batch sums, its
+    BatchNorm finalize raises the device's sticky flag (ops.range_flag) and skips its running-statistics update, and the fused
+    SGD skips its update while the flag is up -- the step is lost like a loss scaler's overflow step, nothing persistent is damaged.
+    This function is the host's half: called by LossLog / the trainers where they read the loss anyway (one iteration late,
+    `flag_value` = the copied flag) or directly (device given: a synchronising read), it lowers the flag and switches the
+    forward arithmetic to bf16x3 (fp32's exponent range) for every launch from then on.  Returns True when it fell back."""
+    import warnings
+    if flag_value is None:
+        if device is None or (device.type, device.index) not in ops._range_flags:
+            return False
+        flag_value = int(ops.range_flag(device).item())
+    if not flag_value:
+        return False
+    for flag in ops._range_flags.values():
+        flag.zero_()          # (stream order: the steps queued before this line still see it raised and skip their update)
+    if ops.FWD_F16:
+        ops.FWD_F16 = False
+        _planes.clear()
+        _refresh_tables.clear()
+        _defer_choice.clear()
+        _in_affine_choice.clear()
+        ops._TILE_CHOICE.clear()
+    warnings.warn("zs3_amd: a forward convolution multiplied operands beyond fp16's range (non-finite batch statistics); the "
+                  "affected steps were skipped and forward products fall back to the bf16 split (ZS3_FWD_F16=0) from here on",
+                  RuntimeWarning, stacklevel=2)
+    return True
 
 
 def weight_planes(w, need_t=True, f16=False):
@@ -353,7 +384,8 @@ class _ConvBnAct(torch.autograd.Function):
                 from .parallel import combine_bn_partials
                 part, count = combine_bn_partials(part, count, None if bn["sync"] is True else bn["sync"])
             st = ops.bn_fwd_finalize(part, count, gamma, beta, bn["eps"], bn["momentum"], bn["running_mean"],
-                                     bn["running_var"], bn.get("nbt"))
+                                     bn["running_var"], bn.get("nbt"),
+                                     range_flag=ops.range_flag(x.device) if wp.f_fmt == 1 else None)   # f16x3 launch: range guard
             if defer:
                 # the one consumer of this layer applies scale / shift / ReLU in its own operand path (forward and weight
                 # gradient): no BN-apply pass, no activation tensor -- the raw conv output is what travels on
@@ -574,7 +606,7 @@ def _applies_in_affine(x, wp, stride, pad, dil, prec, bn, residual, need_grad):
         ho, wo = ops.conv_out_size(h, wp.kh, stride, pad, dil), ops.conv_out_size(w_, wp.kw, stride, pad, dil)
         tile = ops._choose_tile(0, x.shape, n * ho * wo, ho, wo, wp.cin_pad, min(ops._round_up(wp.cin, 4), ldx), ldx, wp.kh, wp.kw,
                                 stride, pad, pad, dil, wp.cout, False, prec, 1 if store_only else 0)
-        hit = tile in (41, 42, 51, 52) and (not need_grad or ops._wgrad_plan(
+        hit = tile in (41, 42, 51, 52) and not (tile in (51, 52) and wp.cin % 32) and (not need_grad or ops._wgrad_plan(
             n, h, w_, ho, wo, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout, wp.cin)[0] in ("strip", "pw"))
         _in_affine_choice[key] = hit
     return hit
@@ -896,7 +928,7 @@ class _Fork(torch.autograd.Function):
         return out, None
 
 
-FORK_SUM = os.environ.get("ZS3_FORK_SUM", "1") != "0"   # 0: leave the fan-out gradients to autograd's pairwise accumulation
+FORK_SUM = True   # False: leave the fan-out gradients to autograd's pairwise accumulation
 
 
 def fork(x, n):

@@ -45,7 +45,7 @@ def _rows_gemm(x, wp, b, act=Fz.ACT_NONE, leak=0.2):
     return y.view(n, wp.cout)
 
 
-PREP_IN_FWD1 = os.environ.get("ZS3_GMMN_PREP_FUSED", "1") == "1"   # zs3_gmmn_mlp_fwd1_table: six launches per update instead of seven
+PREP_IN_FWD1 = True   # zs3_gmmn_mlp_fwd1_table: six launches per update instead of seven
 # Captured chains of generator updates (table mode): powers of two up to ZS3_GMMN_CHAIN.  A chain boundary costs a graph launch
 # (~100-200 us of idle queue when the host is not far enough ahead), so longer chains = fewer boundaries per step.
 CHAIN_MAX = max(1, int(os.environ.get("ZS3_GMMN_CHAIN", "32")))
@@ -106,7 +106,7 @@ class GMMNStep:
         self.use_graph = use_graph and self.fused_adam
         # the update's MLP forward / backward on the latency-shaped kernels of csrc/gmmn.hip (6 launches per update in table mode
         # with fused Adam, 16 on the general kernels); False keeps the general conv kernels (the A/B reference in tests)
-        self.fused_mlp = bool(fused_mlp) and os.environ.get("ZS3_GMMN_FUSED", "1") != "0"   # env: same-box A/B runs
+        self.fused_mlp = bool(fused_mlp)
         self._st = None       # static buffers (allocated at first call)
         self._graph = None
         self._update_graphs = {}     # captured update chains by (mode, chain length)

@@ -21,13 +21,7 @@ PROFILE_GEOM = None    # optional list: one (m, ncols, k, taps, stride, dil, dgr
 
 WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"   # strip-resident weight gradient of the 3x3 stride-1 layers
 PW = os.environ.get("ZS3_PW", "1") == "1"                      # persistent pointwise kernel for the 1x1 stride-1 layers
-PW_FORCE = int(os.environ.get("ZS3_PW_FORCE", "0"))           # 51 / 52: every eligible 1x1 layer on that tile (A/B runs)
-# fp32 storage: 1x1 data gradients with loading epilogues on the persistent kernel, its producer waves running the epilogue (round 4).
-# Correct (tests/test_gpu_ops.py) and OFF: same-box A/B, ms per step, 46.97 / 47.07 without, 48.31 / 48.57 with; isolated 256 -> 1024
-# dgrad 88 us against 62 (tools/probe/r4g.sh, r4h.sh): 274 tiles of 128 x 128 on 256 persistent workgroups leave most workgroups ONE tile,
-# whose epilogue nothing overlaps.
-PW_LEPI = os.environ.get("ZS3_PW_LEPI", "0") == "1"
-PW_LEPI_MINK = int(os.environ.get("ZS3_PW_LEPI_MINK", "384")) # ... from this reduction length on (>= 384: 12 K steps per tile)
+PW_FORCE = 0        # 51 / 52: every eligible 1x1 layer on that tile (set by A/B probes; the rule is pick_pw_tile)
 WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"         # producer-split weight gradient of the 1x1 stride-1 layers
 HALO = os.environ.get("ZS3_HALO", "1") == "1"     # strip-resident kernel (tile_cfg 41 / 42) for the multi-tap stride-1 layers
 
@@ -145,7 +139,7 @@ def pick_halo_tile(m, ncols, dgrad=False):
     return 42 if cost(192) < cost(256) else 41
 
 
-DMA_RULE = os.environ.get("ZS3_DMA", "1") == "1"   # the LDS-DMA kernel (tile_cfg 31) for the long-K wide layers (0: the 128x128 register-staged kernel)
+DMA_RULE = True     # the LDS-DMA kernel (tile_cfg 31) for the long-K wide layers (False: the 128x128 register-staged kernel; slower on every such layer)
 
 
 def pick_tile(m, ncols, k=0):
@@ -302,17 +296,12 @@ def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, s
                               prec, pw_epilogue, io)
     if prec == 0:   # exact fp32 (test mode): register-staged kernel only
         return tile_cfg if 0 < tile_cfg <= 14 else (14 if ncols <= 64 or ((m + 127) // 128) * ((ncols + 127) // 128) < 1000 else 11)
-    lepi_ok = pw_epilogue == 2 and tile_cfg == 52 and cin_pad >= 384 and ncols % 4 == 0 and prec != 4   # (f16x3 = forward launches: store-only on that kernel)
-    if tile_cfg in (51, 52) and not ((pw_epilogue == 1 or lepi_ok) and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h,
-                                                                        pad_w, tile_cfg)):
-        tile_cfg = 0               # not a 1x1 stride-1 layer, or an epilogue the persistent kernel leaves to the others
-    if tile_cfg == 0 and PW and kh * kw == 1 and pw_epilogue == 1:
+    if tile_cfg in (51, 52) and not (pw_epilogue and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, tile_cfg)):
+        tile_cfg = 0               # not a 1x1 stride-1 layer, or a loading epilogue: the persistent kernel leaves those to the others
+    if tile_cfg == 0 and PW and kh * kw == 1 and pw_epilogue:
         cand = pick_pw_tile(m, ncols, min(cin_pad, cin_valid))
         if cand and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, cand):
             tile_cfg = cand
-    if tile_cfg == 0 and PW and PW_LEPI and prec != 4 and kh * kw == 1 and pw_epilogue == 2 and m >= 8192 and ncols >= 128 and ncols % 4 == 0 and \
-            cin_pad >= PW_LEPI_MINK and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, 52):
-        tile_cfg = 52      # data-gradient launches with a loading epilogue: the producers run it (conv_pw.hip, LEPI)
     if tile_cfg == 0:
         tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
         if HALO and tile_cfg == 31 and kh * kw > 1:
@@ -331,10 +320,8 @@ def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, s
 # persistent pointwise kernel on bf16-stored tensors (A16 producers, DPP-packed bf16 stores): correct and OFF -- with 64-channel K
 # steps the register-staged kernel is the faster one for plain-bf16 1x1 layers (same-box A/B: 32.80 / 32.81 ms per step with the
 # persistent kernel, 32.25 / 32.23 without; tools/probe/r4i.sh): eight MFMAs per wave and barrier leave its K loop latency-bound
-PW16 = os.environ.get("ZS3_PW16", "0") == "1"
-HALO16 = os.environ.get("ZS3_HALO16", "1") == "1"    # strip-resident kernel on bf16-stored tensors
-PW16_LOAD_EPI = os.environ.get("ZS3_PW16_EPI", "0") == "1"   # ... including the data-gradient launches whose epilogue loads per element (OFF: 35.3-35.6 ms per step with, 34.0-34.4 without)
-PW16_EPI_MINK = int(os.environ.get("ZS3_PW16_EPI_MINK", "256"))   # ... from this reduction length on (>= 256: 8 K steps per tile)
+PW16 = False
+HALO16 = True     # strip-resident kernel on bf16-stored tensors
 
 
 def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec,
@@ -344,10 +331,8 @@ def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw,
     and the register-staged kernel takes everything else."""
     x16 = bool(io & 1)
     vec8 = ldx % 8 == 0 and cin_valid % 8 == 0
-    # 1x1 launches on the persistent kernel: store-only epilogues, or -- both sides bf16, >= 8 K steps per tile -- a loading one
-    pw_able = PW16_CAPABLE and (not x16 or vec8) and ncols % 2 == 0 and (
-        pw_epilogue == 1 or (pw_epilogue == 2 and PW16_LOAD_EPI and io == 3 and cin_pad >= PW16_EPI_MINK and ncols % 8 == 0 and
-                             tile_cfg in (0, 52)))
+    # 1x1 launches on the persistent kernel: store-only epilogues
+    pw_able = (not x16 or vec8) and ncols % 2 == 0 and bool(pw_epilogue)
     if tile_cfg in (41, 42) and not (kh * kw == 9 and (not x16 or (vec8 and prec == 1)) and halo_ok(
             xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg)):
         tile_cfg = 0
@@ -368,9 +353,6 @@ def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw,
     if ncols <= 64:
         return 14
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 512 else 14
-
-
-PW16_CAPABLE = True    # conv_pw.hip serves bf16-stored tensors (A16 producers, bf16 direct stores, the producers' loading epilogue)
 
 
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
@@ -395,16 +377,14 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if io & 1 and prec != 1:
         raise ValueError("a bf16-stored input needs plain-bf16 products (prec = 1)")
     m = n * ho * wo
-    # 1: store-only epilogue (no per-element loads); 2: a loading epilogue the persistent pointwise kernel's producer waves can run
-    # (residual OR accumulate, the fused BatchNorm-backward sums; no affine / activation / forward statistics); 0: neither
-    pw_epilogue = 1 if (res is None and not accumulate and bn_bwd is None and res_mask_bits is None) else (
-        2 if (scale is None and shift is None and act == 0 and not want_stats and not (res is not None and accumulate)) else 0)
+    # store-only epilogue (no per-element loads): what the persistent pointwise kernel runs
+    pw_epilogue = 1 if (res is None and not accumulate and bn_bwd is None and res_mask_bits is None) else 0
     # the kernel / tile choice depends on the launch geometry only: decided once per distinct launch (a training step repeats
     # ~60 geometries 230 times; the eligibility questions below are C calls)
     if tile_cfg in (141, 142):      # round-3 spelling of "tile_cfg 41 / 42 on a bf16-stored input"
         tile_cfg -= 100
     key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
-           HALO, HALO_BM, PW, PW_FORCE, DMA_RULE, io, PW16, HALO16, PW16_LOAD_EPI, PW16_CAPABLE, PW_LEPI, PW_LEPI_MINK, PW16_EPI_MINK)
+           HALO, HALO_BM, PW, PW_FORCE, DMA_RULE, io, PW16, HALO16)
     cached = _TILE_CHOICE.get(key)
     if cached is not None:
         tile_cfg = cached
@@ -495,7 +475,7 @@ def conv2d_dgrad(dy, wp, in_hw, stride=1, pad=0, dil=1, **kw):
 _WGRAD_PLAN = {}
 
 
-WGRAD16_FAST = os.environ.get("ZS3_WGRAD16_FAST", "1") == "1"   # strip-resident / pointwise weight-gradient kernels on bf16-stored operands (both bf16)
+WGRAD16_FAST = True   # strip-resident / pointwise weight-gradient kernels on bf16-stored operands (both bf16)
 
 
 def _wgrad_plan(n, h, w_, ho, wo, kh, kw, stride, pad_h, pad_w, dil, cout, cin, io=0):
@@ -535,7 +515,7 @@ def consumer_applies_bn(xshape, ldx, wp, stride, pad, dil, prec=None):
         return False
     tile = _choose_tile(0, xshape, n * ho * wo, ho, wo, wp.cin_pad, cin_valid, ldx, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout,
                         False, prec, True)
-    if tile not in (41, 42, 51, 52):
+    if tile not in (41, 42, 51, 52) or (tile in (51, 52) and wp.cin % 32):   # (the pointwise kernel transforms whole 32-channel K steps only)
         return False
     return _wgrad_plan(n, h, w_, ho, wo, wp.kh, wp.kw, stride, pad, pad, dil, wp.cout, wp.cin)[0] in ("strip", "pw")
 
@@ -625,13 +605,29 @@ def bn_sync_pack(partial, count):
     return out
 
 
-def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+_range_flags = {}
+
+
+def range_flag(device):
+    """The sticky range flag of the f16x3 forward on `device` (device int32[1], 0 = fine): raised by zs3_bn_fwd_finalize when
+    the batch sums of a layer whose convolution multiplied fp16 hi/lo operands are not finite (an operand beyond +-65504 -- or a
+    weight beyond 1023 -- became inf: DESIGN.md section 2), honoured by zs3_sgd_multi (the step is skipped), read and lowered by
+    functional.check_forward_range (the forward falls back to bf16x3 products)."""
+    key = (device.type, device.index)
+    if key not in _range_flags:
+        _range_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _range_flags[key]
+
+
+def bn_fwd_finalize(partial, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked=None,
+                    range_flag=None):
     partial, chunks, c, chost, cdev = _partial_args(partial, count)
     out = torch.empty((4, c), dtype=torch.float32, device=partial.device)  # mean, invstd, scale, shift
     base, row = out.data_ptr(), 4 * c           # (row pointers by arithmetic: four tensor views cost 6 us of host time per layer)
     check(lib().zs3_bn_fwd_finalize(P(partial), I(chunks), I(c), chost, cdev, P(gamma), P(beta),
                                     F(eps), F(momentum), P(running_mean), P(running_var), base, base + row,
-                                    base + 2 * row, base + 3 * row, P(num_batches_tracked), stream()), "zs3_bn_fwd_finalize")
+                                    base + 2 * row, base + 3 * row, P(num_batches_tracked), P(range_flag), stream()),
+          "zs3_bn_fwd_finalize")
     return out
 
 

@@ -84,7 +84,10 @@ class SGD(torch.optim.SGD):
                 cache[(dev, mom, nest)] = hit
             table = torch.from_numpy(arr).pin_memory()
             table_d = table.to(dev, non_blocking=True)
-            check(lib().zs3_sgd_multi(P(table_d), P(hit[1]), I(hit[2]), F(mom), I(int(nest)), stream()), "zs3_sgd_multi")
+            # (skip flag: while the f16x3 forward's range flag is up the gradients are not finite and the step is skipped)
+            from . import ops
+            flag = ops.range_flag(dev) if dev.type == "cuda" else None
+            check(lib().zs3_sgd_multi(P(table_d), P(hit[1]), I(hit[2]), F(mom), I(int(nest)), P(flag), stream()), "zs3_sgd_multi")
             keep.extend((table, table_d))
         self._keepalive = keep   # pinned staging buffers must outlive the asynchronous copies
         Fz.refresh_planes(*touched)   # one launch re-splits every updated conv weight into its bf16 hi/lo planes
