@@ -47,7 +47,8 @@ int g_pw_wgs = 256;                                 // persistent workgroups per
 long* g_pw_timing = nullptr;
 #define HT_DECL long ht_a = 0, ht_b = 0, ht_c = 0, ht_d = 0, ht_last = __builtin_readcyclecounter(); const long ht_start = ht_last;
 #define HT(v) { const long t_ = __builtin_readcyclecounter(); v += t_ - ht_last; ht_last = t_; }
-#define HT_STORE(w) if (tbuf && blockIdx.x == (int)tbuf[0] && lane == 0) { long* o_ = tbuf + 8 + (w) * 5; o_[0] = ht_a; o_[1] = ht_b; o_[2] = ht_c; o_[3] = ht_d; o_[4] = __builtin_readcyclecounter() - ht_start; }
+#define HT_STORE(w) if (tbuf && blockIdx.x == (int)tbuf[0] && lane == 0) { long* o_ = tbuf + 8 + (w) * 5; o_[0] = ht_a; o_[1] = ht_b; o_[2] = ht_c; o_[3] = ht_d; o_[4] = __builtin_readcyclecounter() - ht_start; } \
+  if (tbuf && (w) == 0 && lane == 0) { long* o_ = tbuf + 64 + 4 * (long)blockIdx.x; o_[0] = ht_start; o_[1] = __builtin_readcyclecounter(); o_[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); o_[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); }
 #define HT_ARG , long* tbuf
 #else
 #define HT_DECL
@@ -108,7 +109,7 @@ __device__ __forceinline__ void store_acc_direct16(const ConvArgs& p, const f32x
 // RAGGED: cin_valid is not a multiple of the 32-channel K step (48, 24 channels: two data-gradient launches of the decoder): lanes whose
 // channels lie past cin_valid in a tile's last step read the zero page there -- two selects per load that every other launch is spared.
 template <int PREC, int BM, bool INAFF = false, bool A16 = false, bool RAGGED = false>
-__global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const int ntiles, const int ntn HT_ARG) {
+__global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void conv_pw_kernel(const ConvArgs p, const int ntiles, const int ntn HT_ARG) {
   static_assert(!(RAGGED && INAFF), "the producer-side input transform is instantiated for whole K steps only");
   static_assert(!A16 || (PREC == 1 && !INAFF), "bf16-stored input: plain bf16 products, no producer-side transform");
   constexpr int BN = PW_BN, TM = BM / 64, TN = 2;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
   const int nmine = (ntiles - first + G - 1) / G;
   const int NK = p.cin_pad >> 5;
   const int S = nmine * NK;                         // K steps of this workgroup
-  const int S3 = (S + 2) / 3 * 3;                   // the producers' schedule is unrolled by three (register sets)
+  const int S2 = (S + 1) & ~1;                      // the producers' schedule is unrolled by two (register sets = LDS stages)
   const int E = p.stat_partial ? 1 : 0;  // workgroup barriers of one (consumer-side) epilogue
 
   if (wave >= 4) {
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
       u32x4 w[2][2];
       f32x4 sc, sh;      // (INAFF) scale / shift of this lane's four channels in this K step
     };
-    StepRegs buf[3];
+    StepRegs buf[2];
     auto load_step = [&](StepRegs& d) {
       const bool cok = !RAGGED || lk < klim;
       if (!(ZS3_PW_ABLATE & 4)) {
@@ -242,30 +243,31 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         for (int c = 0; c < 2; ++c) *reinterpret_cast<u32x4*>(sb + c * 8192 + e * 4096 + wdst) = s.w[e][c];
     };
 
-    // prologue: step 0 in stage 0; steps 1, 2, 3 requested into register sets 1, 2, 0
+    // prologue: step 0 in stage 0; steps 1, 2 requested into register sets 1, 0
     setup_tile(first);
     load_step(buf[0]);
     write_step(buf[0], 0);
     load_step(buf[1]);
-    load_step(buf[2]);
     load_step(buf[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // B_0
     HT_DECL   // producers: a = waiting for the loads of the step to be written, b = split + LDS writes + next requests, c = barriers, d = prologue
     HT(ht_d)
-    // interval i (the consumers multiply step i): write step i + 1 into the other stage, request step i + 4.  An interval
-    // that starts a tile (i = NK, 2 NK, ...) also takes part in the E barriers of the previous tile's epilogue.
+    // interval i (the consumers multiply step i): write step i + 1 -- register set and LDS stage (i + 1) & 1 -- then request step
+    // i + 3 into the set that just emptied.  An interval that starts a tile (i = NK, 2 NK, ...) also takes part in the E barriers of
+    // the previous tile's epilogue.  Two sets instead of round 3's three: the kernel now fits 128 registers and TWO workgroups
+    // share a CU -- twice the requests in flight per CU, and one workgroup's epilogue / barrier waits run under the other's MFMAs.
     int nexttile = NK;
-    for (int i0 = 0; i0 < S3; i0 += 3) {
+    for (int i0 = 0; i0 < S2; i0 += 2) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < 2; ++r) {
         const int i = i0 + r;
 #ifdef ZS3_CONV_TIMING
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NRA + 4 + (INAFF ? 2 : 0))) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRA + 4 + (INAFF ? 2 : 0)) : "memory");
         HT(ht_a)
 #endif
-        write_step(buf[(r + 1) % 3], (i + 1) & 1);
-        load_step(buf[(r + 1) % 3]);
+        write_step(buf[(r + 1) & 1], (r + 1) & 1);
+        load_step(buf[(r + 1) & 1]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         HT(ht_b)
         if (i == nexttile) {
@@ -286,61 +288,73 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
     const unsigned swz = (unsigned)((kh ^ ((lr >> 2) & 3)) << 4);
     const unsigned aoff = (unsigned)((wm * (BM / 2) + lr) * 64) + swz;            // row block i: + 2048 i; sub-chunk: + ASUB
     const unsigned boff = (unsigned)(2 * ASUB + (wn * 64 + lr) * 64) + swz;       // column block j: + 2048 j; sub-chunk: + 8192
+    HT_DECL   // consumers: a = MFMA sub-steps, b = epilogues, c = K-step barriers, d = before the first step
     f32x16 acc[TM][TN];
-    bf16x8 fa[2][TM][2], fb[2][TN][2];   // [register set][block][hi, lo]
-    constexpr int NREAD = (TM + TN) * NL;
-    constexpr int NMF = TM * TN * (PREC >= 3 ? 3 : 1);
-    constexpr int RS = NMF / NREAD >= 1 ? NMF / NREAD : 1;      // one fragment read every RS MFMAs
-    constexpr int RPER = (NREAD + NMF - 1) / NMF;               // (plain bf16: more reads than MFMAs)
-    auto read_k = [&](auto setc, auto kc, const unsigned char* st, int sc) {
-      constexpr int SET = decltype(setc)::value, K = decltype(kc)::value;
-      if constexpr (K < NREAD) {
-        constexpr int blk = K / NL, pl = K % NL;
-        if constexpr (blk < TM)
-          fa[SET][blk][pl] = *reinterpret_cast<const bf16x8*>(st + ((aoff + blk * 2048 + sc * ASUB) ^ (32u * pl)));
-        else
-          fb[SET][blk - TM][pl] = *reinterpret_cast<const bf16x8*>(st + ((boff + (blk - TM) * 2048 + sc * 8192) ^ (32u * pl)));
-      }
+    // ONE set of fragments: hi / lo of TM row blocks and TN column blocks.  A 16-channel sub-step u multiplies, for the split
+    // arithmetics, in three groups of TM x TN MFMAs -- G1: a_lo . b_hi, G2: a_hi . b_hi, G3: a_hi . b_lo -- so a_lo is dead after G1,
+    // b_hi after G2, a_hi and b_lo after G3, and sub-step u + 1 needs them in exactly that order: each fragment of u + 1 is fetched
+    // as soon as its register is free and has at least one group (TM x TN x 32 matrix-pipe cycles) to arrive.  The double-buffered
+    // fragment sets of round 3 cost 64 registers; this costs none and keeps the LDS latency under the MFMAs all the same.  (Plain
+    // bf16 has one group per sub-step: its fragments are re-fetched behind it and the other workgroup on the CU covers the wait.)
+    bf16x8 fa[TM][2], fb[TN][2];         // [block][hi, lo]
+    auto rd_a = [&](int pl, const unsigned char* st, int sc) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i][pl] = *reinterpret_cast<const bf16x8*>(st + ((aoff + i * 2048 + sc * ASUB) ^ (32u * pl)));
     };
-    // one 16-channel sub-step from register set SET; the other set is filled from sub-chunk `sc` of stage `st` meanwhile
-    auto substep = [&](auto setc, const unsigned char* st, int sc) {
-      constexpr int SET = decltype(setc)::value;
-      auto mf = [&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        constexpr int pr = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
-        constexpr int ia = PREC >= 3 ? (pr == 0 ? 1 : 0) : 0, ib = PREC >= 3 ? (pr == 1 ? 1 : 0) : 0;
-        if (!(ZS3_PW_ABLATE & 2))
-          acc[i][j] = mfma16<PREC>(fa[SET][i][ia], fb[SET][j][ib], acc[i][j]);
-        if constexpr (RPER == 1) {
-          if constexpr (m % RS == 0) read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, m / RS>{}, st, sc);
-        } else {
-          read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, m * RPER>{}, st, sc);
-          read_k(std::integral_constant<int, SET ^ 1>{}, std::integral_constant<int, m * RPER + 1>{}, st, sc);
+    auto rd_b = [&](int pl, const unsigned char* st, int sc) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j][pl] = *reinterpret_cast<const bf16x8*>(st + ((boff + j * 2048 + sc * 8192) ^ (32u * pl)));
+    };
+    auto group = [&](int pa, int pb) {    // TM x TN MFMAs: a[.][pa] . b[.][pb]
+      if (!(ZS3_PW_ABLATE & 2)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<PREC>(fa[i][pa], fb[j][pb], acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // sub-step on the fragments in registers; `nst` / `nsc`: LDS stage and sub-chunk of the NEXT sub-step's fragments.  `sync`: the
+    // next sub-step lives in the other stage -- wait for this wave's outstanding reads of the current one, then the step barrier
+    // (the producers refill the current stage behind it), before the first fetch
+    // `fetch` = false: the tile's last sub-step -- nothing is fetched across the epilogue (32 registers the 128-register build
+    // needs there); the next tile's first fragments are read when it starts, one exposed LDS round trip per tile
+    auto substep = [&](const unsigned char* nst, int nsc, bool sync, bool fetch) {
+      auto step_barrier = [&]() {
+        if (sync) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          HT(ht_a)
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          HT(ht_c)
+        }
+      };
+      if constexpr (PREC >= 3) {
+        group(1, 0);
+        step_barrier();
+        if (fetch) rd_a(1, nst, nsc);
+        __builtin_amdgcn_sched_barrier(0);
+        group(0, 0);
+        if (fetch) rd_b(0, nst, nsc);
+        __builtin_amdgcn_sched_barrier(0);
+        group(0, 1);
+        if (fetch) {
+          rd_a(0, nst, nsc);
+          rd_b(1, nst, nsc);
         }
         __builtin_amdgcn_sched_barrier(0);
-      };
-      auto run = [&](auto self, auto mc) {
-        constexpr int m = decltype(mc)::value;
-        if constexpr (m < NMF) {
-          mf(mc);
-          self(self, std::integral_constant<int, m + 1>{});
+      } else {
+        group(0, 0);
+        step_barrier();
+        if (fetch) {
+          rd_a(0, nst, nsc);
+          rd_b(0, nst, nsc);
         }
-      };
-      run(run, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
     __builtin_amdgcn_s_barrier();   // B_0
     asm volatile("" ::: "memory");
-    {
-      auto fill = [&](auto self, auto kc) {
-        constexpr int K = decltype(kc)::value;
-        if constexpr (K < NREAD) {
-          read_k(std::integral_constant<int, 0>{}, kc, dsm, 0);
-          self(self, std::integral_constant<int, K + 1>{});
-        }
-      };
-      fill(fill, std::integral_constant<int, 0>{});
-    }
-    __builtin_amdgcn_sched_barrier(0);
     float* const ctile = reinterpret_cast<float*>(dsm + OFF_CT);
     auto lds_barrier = [&]() {   // the epilogue's hazards are on the staging area only: do not drain the global stores
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -348,7 +362,6 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
       asm volatile("" ::: "memory");
     };
     int gs = 0;   // global K-step counter (stage = gs & 1)
-    HT_DECL   // consumers: a = MFMA sub-steps, b = epilogues, c = K-step barriers, d = before the first step
     HT(ht_d)
     for (int tj = 0; tj < nmine; ++tj) {
       const int tile = first + tj * G;
@@ -360,16 +373,20 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      {   // this tile's first fragments (its first step is in LDS since the barrier that ended the previous tile's K loop)
+        const unsigned char* cur = dsm + (gs & 1) * STAGE;
+#pragma unroll
+        for (int pl = 0; pl < NL; ++pl) {
+          rd_a(pl, cur, 0);
+          rd_b(pl, cur, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       for (int k = 0; k < NK; ++k, ++gs) {
         const unsigned char* cur = dsm + (gs & 1) * STAGE;
         const unsigned char* nxt = dsm + ((gs + 1) & 1) * STAGE;
-        substep(std::integral_constant<int, 0>{}, cur, 1);   // channels 0..15 of the step; fetch 16..31
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        HT(ht_a)
-        __builtin_amdgcn_s_barrier();                        // B_{gs+1}: the other stage holds step gs + 1
-        asm volatile("" ::: "memory");
-        HT(ht_c)
-        substep(std::integral_constant<int, 1>{}, nxt, 0);   // channels 16..31; fetch the next step's 0..15
+        substep(cur, 1, false, true);          // channels 0..15 of the step; fetches 16..31 of the same stage
+        substep(nxt, 0, true, k + 1 < NK);     // channels 16..31; B_{gs+1} (the other stage holds step gs + 1), then fetches its 0..15
         HT(ht_a)
       }
       // ---- epilogue of this tile (consumer waves only; the producers are already filling the next tile's stages)
@@ -407,19 +424,23 @@ __global__ __launch_bounds__(512) void conv_pw_kernel(const ConvArgs p, const in
           }
         }
         lds_barrier();
-        if (tid < BN) {
-          const int col = n0 + tid;
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));   // (keeps red + tid out of the registers that live across the K loop: it was the build's one spill)
+        if (t2 < BN) {
+          const int col = n0 + t2;
           if (col < p.ncols) {
-            p.stat_partial[((size_t)mt * 2 + 0) * p.ncols + col] = red[tid] + red[2 * BN + tid];
-            p.stat_partial[((size_t)mt * 2 + 1) * p.ncols + col] = red[BN + tid] + red[3 * BN + tid];
+            p.stat_partial[((size_t)mt * 2 + 0) * p.ncols + col] = red[t2] + red[2 * BN + t2];
+            p.stat_partial[((size_t)mt * 2 + 1) * p.ncols + col] = red[BN + t2] + red[3 * BN + t2];
           }
         }
       }
-      if (p.y_bf16) store_acc_direct16<TM, TN, BM, BN>(p, acc, m0, n0, wm, wn, lane);
+      // (the element type of y is the input's: one epilogue per instantiation -- with both compiled in, the unused one's register
+      // pressure pushed the 128-register build into scratch; launch_pw routes mixed-type launches to the other kernels)
+      if constexpr (A16) store_acc_direct16<TM, TN, BM, BN>(p, acc, m0, n0, wm, wn, lane);
       else store_acc_direct<TM, TN, BM, BN>(p, acc, m0, n0, wm, wn, lane);
       HT(ht_b)
     }
-    for (int e = S; e < S3; ++e) __builtin_amdgcn_s_barrier();   // the producers' schedule is padded to a multiple of three
+    for (int e = S; e < S2; ++e) __builtin_amdgcn_s_barrier();   // the producers' schedule is padded to a multiple of two
     HT_STORE(wave)
   }
 }
@@ -443,7 +464,8 @@ int launch_pw_r(const ConvArgs& a, hipStream_t st) {
   }
   const int ntn = (a.ncols + PW_BN - 1) / PW_BN;
   const int ntiles = ((a.M + BM - 1) / BM) * ntn;
-  const int grid = ntiles < g_pw_wgs ? ntiles : g_pw_wgs;
+  const int wgs = BM == 128 ? 2 * g_pw_wgs : g_pw_wgs;   // 128-row tiles: 128 registers, 66 KB of LDS -> two workgroups per CU
+  const int grid = ntiles < wgs ? ntiles : wgs;
 #ifdef ZS3_CONV_TIMING
   hipLaunchKernelGGL((conv_pw_kernel<PREC, BM, INAFF, A16, RAGGED>), dim3(grid), dim3(512), LDS, st, a, ntiles, ntn, g_pw_timing);
 #else
@@ -472,6 +494,7 @@ int zs3conv::launch_pw(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   if (!pw_geom_ok(a, bm)) return -7;
   if (a.x_bf16 && (prec != 1 || (a.ldx & 7) || (a.cin_valid & 7) || a.in_scale)) return -7;
   if (a.y_bf16 && (a.ncols & 1)) return -7;
+  if (a.y_bf16 != a.x_bf16) return -7;   // mixed element types (the seams of the 2-byte mode): the register-staged kernels
   if (!direct_epilogue(a)) return -7;   // residual / accumulate / fused BatchNorm-backward sums: conv_igemm.hip's kernels
   if (a.x_bf16) return bm == 256 ? launch_pw_t<1, 256, false, true>(a, st) : launch_pw_t<1, 128, false, true>(a, st);
   if (a.in_scale) {   // input transform (the producing layer's BatchNorm-apply + ReLU) in the producer waves

@@ -332,7 +332,7 @@ def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw,
     x16 = bool(io & 1)
     vec8 = ldx % 8 == 0 and cin_valid % 8 == 0
     # 1x1 launches on the persistent kernel: store-only epilogues
-    pw_able = (not x16 or vec8) and ncols % 2 == 0 and bool(pw_epilogue)
+    pw_able = io == 3 and vec8 and ncols % 2 == 0 and bool(pw_epilogue)   # (both sides bf16: the kernel has one element type per instantiation)
     if tile_cfg in (41, 42) and not (kh * kw == 9 and (not x16 or (vec8 and prec == 1)) and halo_ok(
             xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, tile_cfg)):
         tile_cfg = 0
