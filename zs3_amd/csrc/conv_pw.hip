@@ -122,7 +122,10 @@ __global__ __launch_bounds__(512, BM == 128 ? 4 : 2) void conv_pw_kernel(const C
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x;
-  const int first = xcd_remap(blockIdx.x, G);       // G <= ntiles: every workgroup owns at least one tile
+  // G <= ntiles: every workgroup owns at least one tile.  (Giving the two co-resident workgroups of a CU -- b and b + G / 2, observed with
+  // tools/probe/pw_place.py -- neighbouring column tiles of the same activation rows, hoping for vector-L1 hits on the second request,
+  // changed nothing: 45.28 against 45.26 ms per step, tools/probe/r5i.sh.)
+  const int first = xcd_remap(blockIdx.x, G);
   const int nmine = (ntiles - first + G - 1) / G;
   const int NK = p.cin_pad >> 5;
   const int S = nmine * NK;                         // K steps of this workgroup

@@ -164,6 +164,9 @@ def pick_tile(m, ncols, k=0):
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
 
 
+PW_MAXK = 512      # longest reduction the persistent pointwise kernel takes (longer: the LDS-DMA kernel)
+
+
 def pick_pw_tile(m, ncols, k):
     """Layers that go to the persistent pointwise kernel (tile_cfg 51: 256-row tiles, 52: 128-row tiles; csrc/conv_pw.hip),
     0 = none (pick_tile's kernels)."""
@@ -172,7 +175,7 @@ def pick_pw_tile(m, ncols, k):
     # forward table at B=16 (tools/probe/r3m.sh; rules' kernel / 51 / 52, us): 64->256 @129^2 125 / 86 / 80, 128->512 @65^2 75 / 68 / 62,
     # 256->1024 @33^2 62 / 63 / 52, 512->2048 @33^2 159 / 142 / 144 -- the write-heavy short reductions, where the stores
     # draining under the next tile pay; with K >= 1024 (1024->256: 52 / 60 / 64) the LDS-DMA kernel stays ahead
-    if ncols >= 256 and k <= 512 and m >= 8192:
+    if ncols >= 256 and k <= PW_MAXK and m >= 8192:
         return 52
     return 0
 
@@ -384,7 +387,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if tile_cfg in (141, 142):      # round-3 spelling of "tile_cfg 41 / 42 on a bf16-stored input"
         tile_cfg -= 100
     key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
-           HALO, HALO_BM, PW, PW_FORCE, DMA_RULE, io, PW16, HALO16)
+           HALO, HALO_BM, PW, PW_FORCE, DMA_RULE, io, PW16, HALO16, PW_MAXK)
     cached = _TILE_CHOICE.get(key)
     if cached is not None:
         tile_cfg = cached
