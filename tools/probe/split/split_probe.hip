@@ -59,7 +59,7 @@ int main() {
   hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dx, dout, n);
   std::vector<unsigned> o(6 * (size_t)n);
   if (hipMemcpy(o.data(), dout, 6 * (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { printf("copy failed\n"); return 1; }
-  long bad16 = 0, badbf = 0, nan_only16 = 0, nan_onlybf = 0;
+  long bad16 = 0, badbf = 0, nan_only16 = 0, nan_onlybf = 0, badbf_finite = 0;
   auto is_nan16 = [](unsigned short h) { return (h & 0x7C00) == 0x7C00 && (h & 0x3FF); };
   auto is_nanbf = [](unsigned short h) { return (h & 0x7F80) == 0x7F80 && (h & 0x7F); };
   for (int i = 0; i < n; ++i) {
@@ -73,9 +73,12 @@ int main() {
       const unsigned a = o[6 * i + 4], b = o[6 * i + 5];
       bool only_nan = true;
       for (int hfl = 0; hfl < 2; ++hfl) { unsigned short p = a >> (16 * hfl), q = b >> (16 * hfl); if (p != q && !(is_nanbf(p) && is_nanbf(q))) only_nan = false; }
-      if (only_nan) ++nan_onlybf; else if (++badbf <= 8) printf("bf16 mismatch: x = (%g, %g) hi %08x lo ref %08x dot2 %08x\n", x[2 * i], x[2 * i + 1], o[6 * i + 3], a, b);
+      const bool fin = isfinite(x[2 * i]) && isfinite(x[2 * i + 1]) && fabsf(x[2 * i]) < 3e38f && fabsf(x[2 * i + 1]) < 3e38f;
+      if (fin && ++badbf_finite <= 16) printf("bf16 FINITE mismatch: x = (%.9g, %.9g) hi %08x lo ref %08x dot2 %08x\n", x[2 * i], x[2 * i + 1], o[6 * i + 3], a, b);
+      if (only_nan) ++nan_onlybf; else if (++badbf <= 2) printf("bf16 mismatch: x = (%g, %g) hi %08x lo ref %08x dot2 %08x\n", x[2 * i], x[2 * i + 1], o[6 * i + 3], a, b);
     }
   }
+  printf("bf16 dot2 mismatches with both inputs finite (< 3e38): %ld\n", badbf_finite);
   printf("%d pairs: f16 mix form: %ld mismatches (+%ld NaN-payload-only); bf16 dot2 form: %ld mismatches (+%ld NaN-payload-only)\n", n, bad16, nan_only16, badbf, nan_onlybf);
   return 0;
 }

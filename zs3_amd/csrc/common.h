@@ -69,6 +69,24 @@ __device__ __forceinline__ void unscale_acc(f32x16& acc) {
   }
 }
 
+// lo halves from a packed hi and the two values (the second phase of a split; the LDS-DMA kernel runs the phases in different MFMA slots)
+__device__ __forceinline__ unsigned f16_lo_pair(unsigned hi, float a, float b) {
+  // lo = fp16(x - fp32(hi)) in ONE instruction per value: the mixed-precision FMA reads hi's halves as fp16 operands, computes
+  // hi * -1.0 + x exactly (the remainder is representable in fp32) and rounds once to fp16 into the low / high half of `lo` --
+  // 3 VALU per pair instead of 6 (v_cvt_f32_f16 x2, v_sub_f32 x2, v_cvt_pk_f16_f32).  Bit-identical to the long form on 4.2 M
+  // pairs incl. subnormals, infinities, NaNs and arbitrary bit patterns (tools/probe/split/split_probe.hip, on the GPU).
+  unsigned lo;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+  return lo;
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// (The bf16 split has no such short form.  v_dot2_f32_bf16 with k = {-1, 0} / {0, -1} computes x - fp32(hi) in one instruction and
+// is bit-identical to the long form in a flat probe kernel (tools/probe/split/split_probe.hip) -- but a DOT result needs three wait
+// states before another VALU instruction reads it, which inline assembly hides from hipcc (garbage in every conv kernel), and
+// the builtin form, which hipcc schedules correctly, selects the destructive v_dot2c encoding plus two copies (6 VALU again) and
+// still failed the convolution tests.  Round 5; not pursued.)
+
 template <int PREC>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   if (PREC == 1) {
@@ -76,12 +94,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = 0u;
   } else if (PREC == 4) {
     hi = cvt_pk_f16(a, b);
-    // lo = fp16(x - fp32(hi)) in ONE instruction per value: the mixed-precision FMA reads hi's halves as fp16 operands, computes
-    // hi * -1.0 + x exactly (the remainder is representable in fp32) and rounds once to fp16 into the low / high half of `lo` --
-    // 3 VALU per pair instead of 6 (v_cvt_f32_f16 x2, v_sub_f32 x2, v_cvt_pk_f16_f32).  Bit-identical to the long form on 4.2 M
-    // pairs incl. subnormals, infinities, NaNs and arbitrary bit patterns (tools/probe/split/split_probe.hip, on the GPU).
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+    lo = f16_lo_pair(hi, a, b);
   } else {
     hi = cvt_pk_bf16(a, b);  // round-to-nearest hi: |x - hi| <= 2^-9 |x|, remainder exact in fp32
     lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
@@ -90,7 +103,6 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 
 // max(v * sc + sh, 0) on four values: two packed fp32 FMAs (v_pk_fma_f32) + four v_max -- the BatchNorm-apply + ReLU that the conv
 // producers perform on their operand (ConvArgs::in_scale)
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ f32x4 affine_relu4(f32x4 v, f32x4 sc, f32x4 sh) {
   const f32x2 lo = __builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
   const f32x2 hi = __builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});

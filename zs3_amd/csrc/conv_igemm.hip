@@ -771,13 +771,11 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
         const int q = hp >> 1;
         const float a = q == 0 ? r0[0] : q == 1 ? r0[2] : q == 2 ? r1[0] : r1[2];
         const float b = q == 0 ? r0[1] : q == 1 ? r0[3] : q == 2 ? r1[1] : r1[3];
+        // two phases per pair, spread over the MFMA slots: hi = the packed conversion (+ for bf16 the two fp32 images of its
+        // halves); lo = fp16: the two mixed-precision FMAs of common.h (1 + 2 VALU), bf16: two subtractions + the conversion (3 + 3)
         if ((hp & 1) == 0) {
           if constexpr (PREC == 4) {
-            const unsigned h = cvt_pk_f16(a, b);
-            const f16x2_t hv = __builtin_bit_cast(f16x2_t, h);
-            uh[buf][q] = h;
-            ha = (float)hv[0];
-            hb = (float)hv[1];
+            uh[buf][q] = cvt_pk_f16(a, b);
           } else {
             const unsigned h = cvt_pk_bf16(a, b);
             uh[buf][q] = h;
@@ -785,7 +783,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs p) {
             hb = __uint_as_float(h & 0xFFFF0000u);
           }
         } else {
-          ul[buf][q] = PREC == 4 ? cvt_pk_f16(a - ha, b - hb) : PREC == 3 ? cvt_pk_bf16(a - ha, b - hb) : 0u;
+          ul[buf][q] = PREC == 4 ? f16_lo_pair(uh[buf][q], a, b) : PREC == 3 ? cvt_pk_bf16(a - ha, b - hb) : 0u;
         }
       };
       // sub-step s4 of the tile in the current ring slot; fillers prepare sub-step s4+1 (s4 == 3: sub-step 0 of the
