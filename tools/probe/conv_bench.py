@@ -18,7 +18,7 @@ if os.environ.get("ZS3_SHAPES"):   # e.g. ZS3_SHAPES=2,16,26: only these rows of
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]
 mode = sys.argv[2] if len(sys.argv) > 2 else "fwd"
 ops.PREC_DEFAULT = int(os.environ.get("ZS3_PREC", "3"))   # 1 = plain bf16 products
-B = 16
+B = int(os.environ.get("ZS3_B", "16"))
 def timeit(fn, iters=5):
     for _ in range(2): fn()
     torch.cuda.synchronize(); t = time.perf_counter()

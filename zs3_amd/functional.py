@@ -527,6 +527,10 @@ class _ConvBnAct(torch.autograd.Function):
                                                    bn_bwd=(in_link.y, in_link.mean, in_link.istd, in_link.msc,
                                                            in_link.msh, in_link.mbits), out_dtype=x.dtype, **skip_kw)
                     in_link.partial, in_link.for_ptr = part_in, dx.data_ptr()
+                # (the decoder's 304-channel concat: its data gradient's third 128-column tile multiplies 48 valid columns -- 21 % of
+                # the launch on padding.  Two launches into channel slices, 256 columns on the big tiles + 48 on 64-wide tiles, were
+                # measured in round 5: 45.12 against 45.11 ms per step -- nothing; the wasted matrix work is not what the backward
+                # pass waits for.)
                 else:
                     dx = ops.conv2d_dgrad(dy, wp, (ctx.x_shape[1], ctx.x_shape[2]), stride, pad, dil, prec=prec, out_dtype=x.dtype,
                                           **skip_kw)

@@ -124,13 +124,19 @@ def halo_ok(x_shape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad
 HALO_BM = os.environ.get("ZS3_HALO_BM", "bwd256")   # auto | 256 | 192 | bwd256 (dgrad launches on 256-row tiles)
 
 
+# Launches with fewer 256 x 128 tiles than this leave the 256-row rules (round 5, the B = 8 shard of BASELINE configs[3]: M = 8 712 at
+# 33 x 33 is 35 x 2 = 70 such tiles on 256 CUs -- there 64 x 64 tiles beat the LDS-DMA kernel on the long-K 1x1 layers, 35 against 44 us,
+# and 192-row strips the 256-row ones in the data gradients, 66 against 78 us; at B = 16 the same launches are 138 tiles and stay)
+SMALL_LAUNCH_TILES = 100
+
+
 def pick_halo_tile(m, ncols, dgrad=False):
     """256- or 192-row tiles for the strip-resident kernel: the tile height that needs fewer rounds x rows on 256 CUs
     (16 x 33 x 33 output pixels x 256 channels: 138 tiles of 256 rows -> one round at 54 % of the chip; 182 tiles of
     192 rows -> one round at 71 %, each 0.75x as long)."""
     if HALO_BM in ("256", "192"):
         return 41 if HALO_BM == "256" else 42
-    if HALO_BM == "bwd256" and dgrad:
+    if HALO_BM == "bwd256" and dgrad and ((m + 255) // 256) * ((ncols + 127) // 128) >= SMALL_LAUNCH_TILES:
         return 41
     nt = (ncols + 127) // 128
     def cost(bm):
@@ -157,7 +163,7 @@ def pick_tile(m, ncols, k=0):
     # tiles 47.3 / 47.1 -- nothing left in the rules.
     if ncols <= 64:
         return 14
-    if m >= 8192 and k >= 512 and ncols >= 256:
+    if m >= 8192 and k >= 512 and ncols >= 256 and ((m + 255) // 256) * ((ncols + 127) // 128) >= SMALL_LAUNCH_TILES:
         return 31 if DMA_RULE else 11
     if ncols >= 256 and 128 <= k <= 256:
         return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
@@ -387,7 +393,7 @@ def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pa
     if tile_cfg in (141, 142):      # round-3 spelling of "tile_cfg 41 / 42 on a bf16-stored input"
         tile_cfg -= 100
     key = (tile_cfg, n, h, w_, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec, pw_epilogue,
-           HALO, HALO_BM, PW, PW_FORCE, DMA_RULE, io, PW16, HALO16, PW_MAXK)
+           HALO, HALO_BM, PW, PW_FORCE, DMA_RULE, io, PW16, HALO16, PW_MAXK, SMALL_LAUNCH_TILES)
     cached = _TILE_CHOICE.get(key)
     if cached is not None:
         tile_cfg = cached
