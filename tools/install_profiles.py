@@ -4,7 +4,7 @@ import json, os, sys
 rnd = int(sys.argv[1])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles")
-base = "python bench.py --no-cpu-baseline --bf16-steps 0"
+base = "python bench.py --no-cpu-baseline --bf16-steps 0 --shard-steps 0 --ddp-steps 0 --script-steps 0"
 runs = {"sup": ("supervised", base + " --steps 5 --warmup 2 --gmmn-steps 0", "7 steps in the trace: 2 warm-up + 5 timed"),
         "bf16": ("supervised_bf16", base + " --steps 5 --warmup 2 --gmmn-steps 0 --dtype bf16", "7 steps in the trace: 2 warm-up + 5 timed"),
         "gmmn": ("gmmn", base + " --workload gmmn --steps 4 --warmup 2 --no-roofline", "6 steps in the trace: 2 warm-up + 4 timed")}
@@ -27,8 +27,8 @@ if os.path.exists(os.path.join(src, "pmc_traffic_bf16.json")):     # the 2-byte 
         db["conv_halo_family"] = {"launches": n16,
                                   "read_bytes_per_launch": sum(v["read_bytes_per_launch"] * v["launches"] for v in fam16) / n16,
                                   "write_bytes_per_launch": sum(v["write_bytes_per_launch"] * v["launches"] for v in fam16) / n16}
-    db["command"] = ("rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, a separate pass) --kernel-trace -- python bench.py --no-cpu-baseline "
-                     f"--bf16-steps 0 --steps 2 --warmup 1 --gmmn-steps 0 --no-roofline --dtype bf16 (tools/refresh_profiles.sh, round {rnd})")
+    db["command"] = ("rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, a separate pass) --kernel-trace -- " + base +
+                     f" --steps 2 --warmup 1 --gmmn-steps 0 --no-roofline --dtype bf16 (tools/refresh_profiles.sh, round {rnd})")
     json.dump(db, open(os.path.join(dst, f"r{rnd}_pmc_traffic_bf16.json"), "w"), indent=1)
 old = open(os.path.join(dst, f"r{rnd}_pmc_mfma.md")).read() if os.path.exists(os.path.join(dst, f"r{rnd}_pmc_mfma.md")) else ""
 head = old.split("\ncounters:")[0] if "\ncounters:" in old else f"# r{rnd}_pmc_mfma\n"
@@ -42,6 +42,6 @@ fam = [v for k, v in d["kernels"].items() if k.startswith("conv_halo_kernel<3,")
 n = sum(v["launches"] for v in fam)
 d["conv_halo_family"] = {"launches": n, "read_bytes_per_launch": sum(v["read_bytes_per_launch"] * v["launches"] for v in fam) / n,
                          "write_bytes_per_launch": sum(v["write_bytes_per_launch"] * v["launches"] for v in fam) / n}
-d["command"] = ("rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, a separate pass) --kernel-trace -- python bench.py --no-cpu-baseline "
-                f"--steps 2 --warmup 1 --gmmn-steps 0 --no-roofline (tools/refresh_profiles.sh, round {rnd})")
+d["command"] = ("rocprofv3 --pmc FETCH_SIZE (then WRITE_SIZE, a separate pass) --kernel-trace -- " + base +
+                f" --steps 2 --warmup 1 --gmmn-steps 0 --no-roofline (tools/refresh_profiles.sh, round {rnd})")
 json.dump(d, open(p, "w"), indent=1)

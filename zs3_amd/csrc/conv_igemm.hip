@@ -109,7 +109,47 @@ __global__ __launch_bounds__(256, igemm_wpe(BM, BN, PREC, PIPE, A16)) void conv_
     XV areg[RA];
     u32x4 breg[RB];
   };
-  int kh = 0, kw = 0, c0 = 0, kofs = 0;
+  // ---- filter taps that read nothing but padding for every row of this tile are skipped (as in conv_igemm_dma_kernel below: the K
+  // loop is tap-major, a dead tap is a run of cin_pad / KS steps multiplying zeros -- bit-identical without them).  Only asked for
+  // dilations >= 4: ASPP's d = 18 branch on a 33 x 33 map lands here in the 2-byte mode (the LDS-DMA kernel moves fp32 rows, the
+  // strip of d = 18 does not fit the LDS), and a 64-row tile is two image rows: 5.7 of its 9 taps are live on average.
+  const int T = p.KH * p.KW;
+  unsigned tapmask = T <= 32 ? (T == 32 ? 0xFFFFFFFFu : (1u << T) - 1u) : 0u;
+  if (T > 1 && T <= 32 && p.dil >= 4) {
+    __shared__ unsigned s_tapmask;
+    if (tid == 0) s_tapmask = 0u;
+    unsigned mk = 0u;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      if (!rvalid[i]) continue;
+      for (int t = 0; t < T; ++t) {
+        const int th_ = t / p.KW, tw_ = t - th_ * p.KW;
+        int hi, wi;
+        bool ok;
+        if (p.dgrad) {
+          const int th = bh[i] - th_ * p.dil, tw = bw[i] - tw_ * p.dil;
+          const int smask = (1 << p.stride_log2) - 1;
+          hi = th >> p.stride_log2;
+          wi = tw >> p.stride_log2;
+          ok = ((th | tw) >= 0) && (((th | tw) & smask) == 0);
+        } else {
+          hi = bh[i] + th_ * p.dil;
+          wi = bw[i] + tw_ * p.dil;
+          ok = (hi | wi) >= 0;
+        }
+        if (ok && hi < p.H && wi < p.W) mk |= 1u << t;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mk |= (unsigned)__shfl_xor((int)mk, o, 64);
+    __syncthreads();
+    if (lane == 0) atomicOr(&s_tapmask, mk);
+    __syncthreads();
+    tapmask = s_tapmask;
+    if (tapmask == 0u) tapmask = 1u;
+  }
+  int tcur = T <= 32 ? __builtin_ctz(tapmask) : 0;
+  int kh = tcur / p.KW, kw = tcur - kh * p.KW, c0 = 0, kofs = tcur * p.cin_pad;
 
   // Branch-free tile loads: masked lanes read the zero page, so the loop body is straight-line code.  The
   // per-row gather address (bounds checks, 64-bit pointer) is recomputed only when a new filter tap
@@ -150,12 +190,16 @@ __global__ __launch_bounds__(256, igemm_wpe(BM, BN, PREC, PIPE, A16)) void conv_
   auto advance = [&]() {
     kofs += KS;
     c0 += KS;
-    if (c0 == p.cin_pad) {
+    if (c0 == p.cin_pad) {   // next live tap
       c0 = 0;
-      if (++kw == p.KW) {
-        kw = 0;
-        ++kh;
+      ++tcur;
+      if (T <= 32) {
+        const unsigned rest = tcur < 32 ? tapmask >> tcur : 0u;
+        tcur += rest ? __builtin_ctz(rest) : 0;
       }
+      kh = tcur / p.KW;
+      kw = tcur - kh * p.KW;
+      kofs = tcur * p.cin_pad;
     }
   };
   auto store_tile = [&](Stage& S, int stage) {
@@ -255,7 +299,7 @@ __global__ __launch_bounds__(256, igemm_wpe(BM, BN, PREC, PIPE, A16)) void conv_
     }
   };
 
-  const int KT = p.KH * p.KW * (p.cin_pad / KS);
+  const int KT = (T <= 32 ? __builtin_popcount(tapmask) : T) * (p.cin_pad / KS);
   if (PIPE == 1) {
     // one register stage: loads of step k+1 fly during the MFMAs of step k
     Stage s0;

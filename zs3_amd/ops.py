@@ -148,7 +148,7 @@ def pick_halo_tile(m, ncols, dgrad=False):
 DMA_RULE = True     # the LDS-DMA kernel (tile_cfg 31) for the long-K wide layers (False: the 128x128 register-staged kernel; slower on every such layer)
 
 
-def pick_tile(m, ncols, k=0):
+def pick_tile(m, ncols, k=0, taps=1):
     """Tile / kernel choice for the implicit-GEMM conv (zs3_conv_igemm tile_cfg): 1x = register-staged 4-wave kernel
     (11: 128x128, 14: 64x64 block tile), 31 = wave-specialised 256x128 kernel fed by LDS-DMA."""
     # measured on MI355X over the 28 layer shapes of the network, forward and dgrad (tools/probe/conv_bench.py).
@@ -163,8 +163,8 @@ def pick_tile(m, ncols, k=0):
     # tiles 47.3 / 47.1 -- nothing left in the rules.
     if ncols <= 64:
         return 14
-    if m >= 8192 and k >= 512 and ncols >= 256 and ((m + 255) // 256) * ((ncols + 127) // 128) >= SMALL_LAUNCH_TILES:
-        return 31 if DMA_RULE else 11
+    if m >= 8192 and k >= 512 and ncols >= 256 and (taps > 1 or ((m + 255) // 256) * ((ncols + 127) // 128) >= SMALL_LAUNCH_TILES):
+        return 31 if DMA_RULE else 11    # (multi-tap layers: the strip-resident kernel is asked next, _choose_tile)
     if ncols >= 256 and 128 <= k <= 256:
         return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
     return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
@@ -312,7 +312,7 @@ def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, s
         if cand and pw_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, cand):
             tile_cfg = cand
     if tile_cfg == 0:
-        tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid))
+        tile_cfg = pick_tile(m, ncols, kh * kw * min(cin_pad, cin_valid), kh * kw)
         if HALO and tile_cfg == 31 and kh * kw > 1:
             cand = pick_halo_tile(m, ncols, dgrad)
             if halo_ok(xshape, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, dgrad, prec, cand):
