@@ -12,6 +12,13 @@ gradients are SUM all-reduced over RCCL while backward runs (zs3_amd.parallel.Gr
 One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel (the LDS-DMA 256x128 implicit-GEMM convolution)
 with HIP events recorded around its launches inside the timed region (every 5th timed step); `cpu_baseline` times the CPU oracle
 (oracle/zs3_oracle, the checked restatement of the reference) on the host cores for a bounded sample.
+
+Further objects of the line, none of them part of `value` (each has a --*-steps flag, 0 = skip): `bf16` (the 2-byte mode of
+configs[4], same process, after the timed loop), `gmmn` (configs[2]; `gmmn.script_loop` = the reference's own per-image x
+per-class loop body driven through the drop-in classes), and, at N = 1 only and in child processes so that they cannot
+disturb the timed loop, `shard` (what ONE rank of the 8-GPU configs[3] run executes: 8 images, 60 classes, no collectives)
+and `ddp_one_rank` (the N > 1 code path -- gradient buckets, SyncBN and CE all-reduces over a one-rank RCCL group -- against the
+plain step).
 """
 import argparse
 import json

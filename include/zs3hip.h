@@ -365,7 +365,10 @@ int zs3_index_add_rows(const float* src, int lds, const long* idx, float* out, i
 int zs3_sgd_step(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, int nesterov,
                  int first, void* stream);
 /* One launch for a whole parameter set: table = int64[E][6] {p, g, momentum_buf, n, lr | wd<<32 (float bits), first},
- * blockmap = int32[nblocks][2] {entry, chunk}; every block updates zs3_sgd_chunk() consecutive elements. */
+ * blockmap = int32[nblocks][2] {entry, chunk}; every block updates zs3_sgd_chunk() consecutive elements.
+ * skip_flag (optional, device int32): when it reads non-zero the launch leaves parameters and existing momentum buffers alone
+ * (first-step buffers are zeroed) -- the forward range guard's flag (zs3_bn_fwd_finalize), so that a step whose forward left
+ * fp16's range never reaches the weights. */
 int zs3_sgd_chunk(void);
 int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov, const int* skip_flag,
                   void* stream);
