@@ -121,13 +121,23 @@ __global__ __launch_bounds__(256) void colstats_kernel(const ColArgs p) {
 }
 
 // FIN_CH channels x FIN_GROUPS row groups per block: thread (ty, tx) sums the partial rows ty, ty + FIN_GROUPS, ... of channel
-// c0 + tx in fp64, the row groups are combined through LDS in a fixed order (deterministic); the result is valid in the threads
-// with ty == 0.  Two shapes: 32 x 8 (256 threads; a half-wave reads 128 contiguous bytes of a partial row) for the usual short
-// partial buffers (69-1057 rows), and 8 x 128 (1024 threads) for the tall ones of the stem and layer1, whose conv kernels write
-// one partial row per 64 output rows (4161 / 16513 rows x 64-256 channels: with 32 x 8 that was 2-8 workgroups walking 520-2064
-// rows per thread -- 35-240 us per call, 1.6 ms of the step's dependent chain for 11 of the 113 BN layers).
-// (The first, one-wave-per-channel form read one 4-byte value per lane with stride C: ~10 us per call, 226 calls per step.)
-static int fin_tall_rows() { return 2048; }   // partial rows from which the tall form takes over (swept in round 2)
+// c0 + tx in fp64, the row groups are combined through LDS in a fixed order (deterministic; two levels when there are more
+// than eight groups); the result is valid in the threads with ty == 0.  These launches sit on the step's dependent chain 226
+// times (113 BN layers x forward / backward), each a handful of workgroups whose duration is the number of dependent load
+// rounds a thread makes: the shape is chosen for FEW ROWS PER THREAD.  16 x 64 (1024 threads, a quarter-wave reads 64
+// contiguous bytes of a partial row) for the usual partial buffers (69-1057 rows: <= 17 rows per thread, two rounds of eight
+// loads) and 8 x 128 for the tall ones of the stem and layer1, whose conv kernels write one partial row per 64 output rows
+// (4161 / 16513 rows x 64-256 channels).  History, us per call / ms per step: one wave per channel ~10 us; 32 x 8 (round 2;
+// 63-132 rows per thread) 6.6 forward / 8.7 backward; 16 x 64 (round 5): -0.22 to -0.33 ms per step on three boxes, same-box
+// A/B against 32 x 8 (32 x 32: -0.17, 8 x 128 everywhere: -0.15, 64 x 16: -0.08, 16 x 32: -0.15; tools/probe/r5o.sh).
+#ifndef ZS3_FIN_CH   // (tools/probe/build_variant.sh builds the A/B libraries with other shapes)
+#define ZS3_FIN_CH 16
+#define ZS3_FIN_GROUPS 64
+#endif
+#ifndef ZS3_FIN_TALL
+#define ZS3_FIN_TALL 2048   // partial rows from which the tall form takes over (swept in round 2, re-checked in round 5)
+#endif
+static int fin_tall_rows() { return ZS3_FIN_TALL; }
 template <int FIN_CH, int FIN_GROUPS>
 __device__ __forceinline__ bool combine_partials(const float* partial, int chunks, int C, int& c, double& s, double& q) {
   __shared__ double red[2][FIN_GROUPS][FIN_CH];
@@ -151,11 +161,27 @@ __device__ __forceinline__ bool combine_partials(const float* partial, int chunk
   red[0][ty][tx] = ls;
   red[1][ty][tx] = lq;
   __syncthreads();
+  if constexpr (FIN_GROUPS > 8) {   // two levels: eight threads per channel fold FIN_GROUPS / 8 rows each, the owner those eight
+    double fs = 0.0, fq = 0.0;
+    if (ty < 8) {
+#pragma unroll
+      for (int g = ty; g < FIN_GROUPS; g += 8) {
+        fs += red[0][g][tx];
+        fq += red[1][g][tx];
+      }
+    }
+    __syncthreads();
+    if (ty < 8) {
+      red[0][ty][tx] = fs;
+      red[1][ty][tx] = fq;
+    }
+    __syncthreads();
+  }
   if (ty != 0 || c >= C) return false;
   s = 0.0;
   q = 0.0;
 #pragma unroll
-  for (int g = 0; g < FIN_GROUPS; ++g) {
+  for (int g = 0; g < (FIN_GROUPS > 8 ? 8 : FIN_GROUPS); ++g) {
     s += red[0][g][tx];
     q += red[1][g][tx];
   }
@@ -525,7 +551,7 @@ extern "C" int zs3_bn_sync_pack(const float* partial, int chunks, int C, double 
     hipLaunchKernelGGL((bn_sync_pack_kernel<8, 128>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, chunks, C,
                        count, totals);
   else
-    hipLaunchKernelGGL((bn_sync_pack_kernel<32, 8>), dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+    hipLaunchKernelGGL((bn_sync_pack_kernel<ZS3_FIN_CH, ZS3_FIN_GROUPS>), dim3((C + ZS3_FIN_CH - 1) / ZS3_FIN_CH), dim3(ZS3_FIN_CH * ZS3_FIN_GROUPS), 0, (hipStream_t)stream, partial, chunks, C,
                        count, totals);
   return ZS3_LAUNCH_CHECK();
 }
@@ -540,7 +566,7 @@ extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, doub
                        count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
                        shift_out, num_batches_tracked, range_flag);
   else
-    hipLaunchKernelGGL((bn_fwd_finalize_kernel<32, 8>), dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+    hipLaunchKernelGGL((bn_fwd_finalize_kernel<ZS3_FIN_CH, ZS3_FIN_GROUPS>), dim3((C + ZS3_FIN_CH - 1) / ZS3_FIN_CH), dim3(ZS3_FIN_CH * ZS3_FIN_GROUPS), 0, (hipStream_t)stream, partial, chunks, C,
                        count, count_dev, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
                        shift_out, num_batches_tracked, range_flag);
   return ZS3_LAUNCH_CHECK();
@@ -561,7 +587,7 @@ extern "C" int zs3_bn_bwd_finalize(const float* partial, int chunks, int C, doub
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<8, 128>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, chunks, C,
                        count, count_dev, dgamma, dbeta, c1, c2, use_batch_stats);
   else
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<32, 8>), dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, C,
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<ZS3_FIN_CH, ZS3_FIN_GROUPS>), dim3((C + ZS3_FIN_CH - 1) / ZS3_FIN_CH), dim3(ZS3_FIN_CH * ZS3_FIN_GROUPS), 0, (hipStream_t)stream, partial, chunks, C,
                        count, count_dev, dgamma, dbeta, c1, c2, use_batch_stats);
   return ZS3_LAUNCH_CHECK();
 }
