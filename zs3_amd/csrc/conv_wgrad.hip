@@ -508,6 +508,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const f32x4* __restr
   }
 }
 
+// many slabs (the stem: hundreds of splits of a 57 KB gradient): 64 columns x 16 slab groups per block, thread (tx, ty) sums the
+// slabs ty, ty + 16, ... of its column, the groups are combined through LDS in a fixed order (deterministic) -- a thread of the
+// plain form above would walk every slab in one dependent chain
+constexpr int RED_GROUPS = 16;
+__global__ __launch_bounds__(64 * RED_GROUPS) void wgrad_reduce4_tall_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ dw,
+                                                                           long n4, int splitk, long slab4) {
+  __shared__ f32x4 red[RED_GROUPS][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + tx;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+#pragma unroll 4
+    for (int k = ty; k < splitk; k += RED_GROUPS) s += part[(size_t)k * slab4 + i];
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n4) {
+#pragma unroll
+    for (int g = 1; g < RED_GROUPS; ++g) s += red[g][tx];
+    dw[i] = s;
+  }
+}
+
 template <int BC, int BD>
 int launch_wgrad(const WgradArgs& a, int taps, int splitk, int prec, int io, hipStream_t st) {
   int tiles = ((a.co_write + BC - 1) / BC) * ((a.ci_write + BD - 1) / BD) * taps;
@@ -600,6 +623,11 @@ extern "C" int zs3_conv_wgrad_set_kernel(int kernel) {
   if (kernel >= 0 && kernel <= 2) g_wgrad_kernel = kernel;
   return old;
 }
+#ifndef ZS3_STEM_WGS
+// same-box A/B of the supervised step (tools/probe/r5t.sh; the side streams' sizing gave 288 workgroups = 144 splits): 288 -> 45.05 /
+// 45.13 ms, 512 -> 44.75 / 44.74, 768 -> 44.64 / 44.62, 1536 -> 44.73 / 44.69, 3072 -> 44.70 / 44.72; the launch itself 361 -> 190 us
+#define ZS3_STEM_WGS 768
+#endif
 constexpr int STEM_FOLD = 32;   // channel count of the stem's NHWC4 windows (8 pixels x 4 channels)
 extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int* splitk_out, long* workspace_floats) {
   int s;
@@ -613,8 +641,14 @@ extern "C" int zs3_conv_wgrad_plan(int M, int Wo, int co, int ci, int taps, int*
     if (ci == STEM_FOLD && taps == 7) {   // the folded stem launch of zs3_conv_wgrad: 224 channels, one tap
       bd = pick_tile_dim(ci * taps);
       tiles = ((co + bc - 1) / bc) * ((ci * taps + bd - 1) / bd);
-    }
-    s = pick_splitk(M, tiles);
+      // the last launch of backward, on the main stream with nothing left to share the chip with: sized for all of it
+      // (ZS3_STEM_WGS workgroups), not for the side streams' share
+      s = (ZS3_STEM_WGS + tiles - 1) / tiles;
+      const int maxs = (M + 31) / 32 / 16;
+      if (s > maxs) s = maxs;
+      if (s < 1) s = 1;
+    } else
+      s = pick_splitk(M, tiles);
   }
   *splitk_out = s;
   *workspace_floats = s > 1 ? (long)s * co * taps * ci : 0;
@@ -687,8 +721,12 @@ extern "C" int zs3_conv_wgrad(const float* dy, const float* x, float* dw, float*
     if ((n & 3) == 0 && (((uintptr_t)workspace | (uintptr_t)dw) & 15) == 0) {
       blocks = (int)((n / 4 + 255) / 256);
       if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)workspace, (f32x4*)dw, n / 4,
-                         splitk, a.slab / 4);
+      if (splitk >= 4 * RED_GROUPS)
+        hipLaunchKernelGGL(wgrad_reduce4_tall_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(64 * RED_GROUPS), 0, st,
+                           (const f32x4*)workspace, (f32x4*)dw, n / 4, splitk, a.slab / 4);
+      else
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks), dim3(256), 0, st, (const f32x4*)workspace, (f32x4*)dw, n / 4,
+                           splitk, a.slab / 4);
     } else {
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n, splitk, a.slab);
     }
