@@ -14,7 +14,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 torch.manual_seed(1)
 m = DeepLab(num_classes=21, pretrained=False, sync_bn=False).to(dev).train()
 params = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
-opt = torch.optim.SGD(params, momentum=0.9, weight_decay=5e-4)
+from zs3_amd.optim import SGD
+opt = SGD(params, momentum=0.9, weight_decay=5e-4)     # the fused update of the bench step (torch.optim.SGD: +1.5 ms GPU, 42 ms of host time)
 crit = SegmentationLosses(cuda=True).build_loss("ce")
 x = torch.randn(16, 3, 513, 513, device=dev); y = torch.randint(0, 21, (16, 513, 513), device=dev).float()
 def step():
@@ -23,7 +24,7 @@ def run(tag):
     for _ in range(3): step()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(steps): step()
-    torch.cuda.synchronize(); print(f"{tag}: {(time.perf_counter() - t) / steps * 1e3:.2f} ms/step", flush=True)
+    torch.cuda.synchronize(); print(f"{tag}: {(time.perf_counter() - t) / steps * 1e3:.2f} ms/step, loss {float(step()):.6f}", flush=True)
 run("full step")
 real = ops.conv2d_wgrad
 cache = {}
