@@ -13,6 +13,14 @@
 // invstd = 1/sqrt(var_biased + eps), running_var uses the unbiased variance).
 #include <cstdint>
 #include <cstdlib>
+// the elementwise kernels of this file read every input element once: non-temporal loads keep them from evicting the operand tiles
+// of the convolution / weight-gradient workgroups that run next to them (same-box A/B of the supervised step: 44.81 -> 44.40,
+// 44.94 -> 44.41 ms, on a second box 45.79 -> 45.24, 45.64 -> 45.18; non-temporal STORES level or worse -- the next kernel reads
+// what these write; the same hint on the conv epilogues' operand loads +0.2 ms, on pooling / resize +0.1, 2-byte mode level;
+// tools/probe/r5aa.sh, r5ab.sh)
+#ifndef ZS3_NO_LD_NT   // (A/B builds)
+#define ZS3_LD_NT 1
+#endif
 #include "common.h"
 #include "zs3hip.h"
 
@@ -165,9 +173,9 @@ __device__ __forceinline__ bool combine_partials(const float* partial, int chunk
     double fs = 0.0, fq = 0.0;
     if (ty < 8) {
 #pragma unroll
-      for (int g = ty; g < FIN_GROUPS; g += 8) {
-        fs += red[0][g][tx];
-        fq += red[1][g][tx];
+      for (int i = 0; i < FIN_GROUPS / 8; ++i) {   // groups ty, ty + 8, ...: same order as before, a trip count the compiler can unroll
+        fs += red[0][ty + 8 * i][tx];
+        fq += red[1][ty + 8 * i][tx];
       }
     }
     __syncthreads();
