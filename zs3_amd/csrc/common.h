@@ -122,22 +122,18 @@ __device__ __forceinline__ f32x4 bf16x4_to_f32(u32x2 v) {
 }
 __device__ __forceinline__ u32x2 f32x4_to_bf16(f32x4 v);
 template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
-#ifdef ZS3_LD_NT   // (A/B builds of one source: non-temporal loads / stores in that file's kernels)
-template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
-#else
-template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-#endif
+// ZS3_LD_NT, defined by a source file before it includes this header: its ld4 loads are non-temporal (`global_load ... nt`) -- for
+// kernels that read every element once (bn.hip's elementwise passes); files whose loads are re-read by neighbouring tiles or by the
+// next kernel leave it undefined (measured per file in round 5: DESIGN.md section 7)
 #ifdef ZS3_LD_NT
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
 template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) { return bf16x4_to_f32(__builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p))); }
 #else
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) { return bf16x4_to_f32(*reinterpret_cast<const u32x2*>(p)); }
 #endif
 template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
-#ifdef ZS3_ST_NT
-template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
-#else
 template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-#endif
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return __uint_as_float(((unsigned)*p) << 16); }
