@@ -135,16 +135,16 @@ def check_forward_range(device=None, flag_value=None):
         return False
     for flag in ops._range_flags.values():
         flag.zero_()          # (stream order: the steps queued before this line still see it raised and skip their update)
-    if ops.FWD_F16:
+    if ops.FWD_F16:     # (a later call that finds an older step's copy of the raised flag only lowers it again: one warning per fallback)
         ops.FWD_F16 = False
         _planes.clear()
         _refresh_tables.clear()
         _defer_choice.clear()
         _in_affine_choice.clear()
         ops._TILE_CHOICE.clear()
-    warnings.warn("zs3_amd: a forward convolution multiplied operands beyond fp16's range (non-finite batch statistics); the "
-                  "affected steps were skipped and forward products fall back to the bf16 split (ZS3_FWD_F16=0) from here on",
-                  RuntimeWarning, stacklevel=2)
+        warnings.warn("zs3_amd: a forward convolution multiplied operands beyond fp16's range (non-finite batch statistics); the "
+                      "affected steps were skipped and forward products fall back to the bf16 split (ZS3_FWD_F16=0) from here on",
+                      RuntimeWarning, stacklevel=2)
     return True
 
 
