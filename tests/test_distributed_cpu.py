@@ -107,7 +107,12 @@ def _worker(rank, world, port, q):
             xs = [torch.randn(2, 3, 6, 6) for _ in range(world)]
             net.zero_grad()
             loss = net(xs[rank]).square().sum()
+            from zs3_amd import ops
+            flag = ops.range_flag(torch.device("cpu"))
+            flag.fill_(1 if (it == 1 and rank == 1) else 0)    # rank 1's forward left fp16's range in the second iteration
             loss.backward()   # hooks launch the all-reduces; the queued callback joins them
+            assert int(flag) == (1 if it == 1 else 0)           # ... and every rank knows (the fused SGD skips the step everywhere)
+            flag.zero_()
             got = [p.grad.clone() for p in net.parameters()]
             # reference: sum of the per-rank gradients computed locally without hooks
             want = [torch.zeros_like(p) for p in net.parameters()]

@@ -187,6 +187,11 @@ class GradSync:
                 torch._foreach_copy_([_as_flat(p.grad, p) for p in back], self._views(bi, back))
             self._works[bi] = None
             self._ready[bi] = set()
+        # the f16x3 range flag (ops.range_flag) is per device, the gradients are not: one rank's overflow reaches
+        # every rank as NaNs inside the all-reduced buckets, and only the rank whose own flag is up would skip the update.  MAX over
+        # the group: every rank skips the step and falls back to bf16x3 forward products together.
+        from . import ops
+        dist.all_reduce(ops.range_flag(self.params[0].device), op=dist.ReduceOp.MAX, group=self.group)
         self._armed = False
 
     def remove(self):
