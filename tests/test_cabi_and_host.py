@@ -101,6 +101,15 @@ def test_module_surface_matches_reference_interface(golden):
                                else _FakeDP())
     with pytest.raises(AssertionError):
         patch_replication_callback(torch.nn.Linear(2, 2))
+    # the reference's own `--gpu-ids 0,1` (train_pascal.py:88-93): single-process replication over several devices is refused with
+    # the one-process-per-GPU recipe in the message, instead of sending ctypes-backed modules through DataParallel.replicate
+    two = _FakeDP()
+    two.device_ids = [0, 1]
+    with pytest.raises(RuntimeError, match="torchrun"):
+        patch_replication_callback(two)
+    one = _FakeDP()
+    one.device_ids = [0]
+    patch_replication_callback(one)
     # a "pretrained" ImageNet checkpoint with the 7-character `module.` prefix loads (resnet.py:211-226)
     import tempfile
     ck = {"state_dict": {"module." + k: torch.full_like(v, 0.5) for k, v in m.backbone.state_dict().items() if "layer1.0.conv1" in k}}
@@ -321,6 +330,16 @@ def test_forward_arithmetic_rule_and_loss_log():
     assert ops.PREC_DEFAULT == 0 and not ops.HALO
     ops.set_exact_fp32(False)
     assert ops.PREC_DEFAULT == 3 and lib().zs3_conv_wgrad_set_kernel(I(0)) == 2 and ops.fwd_f16()
+    # nested: the exact-fp32 mode toggled INSIDE the 2-byte mode hands back plain-bf16 products, not PREC_DEFAULT = 3
+    # next to bf16 storage (conv_igemm would refuse: "a bf16-stored input needs prec = 1")
+    ops.set_storage(torch.bfloat16)
+    ops.set_exact_fp32(True)
+    ops.set_exact_fp32(False)
+    assert ops.PREC_DEFAULT == 1 and ops.ACT_DTYPE == torch.bfloat16 and ops.HALO
+    ops.set_exact_fp32(False)                                  # idempotent
+    assert ops.PREC_DEFAULT == 1
+    ops.set_storage(torch.float32)
+    assert ops.PREC_DEFAULT == 3 and ops.fwd_f16()
     log, seen = LossLog(), []
     for i in range(7):
         seen.extend(log.push(torch.tensor(float(i))))

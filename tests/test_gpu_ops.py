@@ -182,6 +182,15 @@ def test_f16x3_forward_range_guard(dev, amax):
         # silently; the flag is what tells)
         assert rel(out.permute(0, 3, 1, 2), ref) > 0.5
         assert torch.equal(bng.running_mean.cpu(), bn.running_mean) and torch.equal(bng.running_var.cpu(), bn.running_var)
+        # while the flag is up every LATER finalize launch -- the layers downstream of the dead layer (whose zeros give
+        # finite, meaningless sums) and the steps queued before the host looks -- leaves its persistent buffers alone too
+        xs = (x / amax).to(dev).permute(0, 2, 3, 1).contiguous()      # an O(1) input: sums are finite
+        bnd = copy.deepcopy(bn).to(dev)
+        wd = nn.Parameter(wt.to(dev).contiguous(memory_format=torch.channels_last))
+        Fz.conv_bn_act(xs, wd, bn=bnd, pad=1, act=Fz.ACT_RELU)
+        torch.cuda.synchronize()
+        assert torch.equal(bnd.running_mean.cpu(), bn.running_mean) and torch.equal(bnd.running_var.cpu(), bn.running_var)
+        assert int(bnd.num_batches_tracked) == int(bn.num_batches_tracked)
         # the fused SGD skips the step while the flag is up: parameters untouched, the momentum buffer it would have created is zero
         p = nn.Parameter(torch.randn(1000, device=dev))
         before = p.detach().clone()

@@ -165,7 +165,9 @@ def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    # (a timeout: collectives that do not pair up -- the failure the lonely-rank case below guards against -- raise instead of hanging)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     try:
         image, label, seen_only, table = _batch()
         sl = slice(2 * rank, 2 * rank + 2)
@@ -173,6 +175,10 @@ def _worker(rank, world, port, outdir):
         res = {"sup": _supervised(dev, image[sl].to(dev), label[sl].to(dev), validate=val),
                "gmmn": _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev)),
                "gcn": _gcn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev))}
+        # a rank WITHOUT clusters (every label map one connected component: adj_mat is None, :323) still takes part in the
+        # criterion's all-reduce that the other rank issues from its cluster term -- with zeros, not through a no_grad dummy call
+        lonely = torch.full_like(seen_only[sl], 3) if rank == 1 else seen_only[sl]
+        res["gcn_lonely"] = _gcn(dev, image[sl].to(dev), lonely.to(dev), table.to(dev))
         torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
@@ -236,3 +242,9 @@ def test_two_ranks_on_one_device_equal_the_single_process_step():
         for p2, pa, pb in zip(r[0]["gcn"][key], solo_g[0][key], solo_g[1][key]):
             assert _rel(p2, (pa + pb) / 2) < 1e-5, key
     assert not torch.equal(r[0]["gcn"]["gcn"][0], solo_g[0]["gcn"][0])
+    # ---------------- one rank without clusters: no hang, no mis-paired collective -- both ranks end on the same weights
+    for key in ("gen", "gcn"):
+        for a, b in zip(r[0]["gcn_lonely"][key], r[1]["gcn_lonely"][key]):
+            assert torch.equal(a, b), key
+    assert torch.equal(r[0]["gcn_lonely"]["pred_w"], r[1]["gcn_lonely"]["pred_w"])
+    assert all(torch.isfinite(torch.tensor(r[k]["gcn_lonely"]["losses"])).all() for k in range(2))

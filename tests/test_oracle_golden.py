@@ -55,6 +55,63 @@ def test_constructor_init_matches_reference(golden, torch_threads):
     check_table(gen2.state_dict().items(), g["names_g2"], g["stats_g2"], rtol=0, atol=0, what="gmmn2")
 
 
+def test_oracle_at_513_at_the_default_crop_and_at_output_stride_8(golden, torch_threads):
+    """tests/golden/sizes.npz (tools/make_goldens.py `sizes`): the reference at 513 x 513, at its default crop 312 x 312
+    (train_pascal.py:203-204; eval and one train-mode forward + weighted CE + backward) and with output_stride = 8
+    (resnet.py:72-74, aspp.py:49-50).  tests/test_gpu_parity_sizes.py judges the HIP path with the oracle at exactly these
+    configurations: this is what pins it there."""
+    g = golden("sizes.npz")
+    for size in (513, 312):
+        torch.manual_seed(1)
+        m = zo.DeepLab(num_classes=21, pretrained=False).eval()
+        x = zo.make_synthetic_batch(2, size, seed=size, with_label_emb=False)["image"]
+        assert np.allclose(stats(x), g[f"eval{size}_in_stats"], rtol=0, atol=0)
+        with torch.no_grad():
+            logits = m(x)
+        ref = torch.from_numpy(g[f"eval{size}_logits_sub"])
+        assert (logits[:, :, ::8, ::8] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+        assert np.allclose(stats(logits), g[f"eval{size}_logits_stats"], rtol=1e-5)
+        assert np.array_equal(logits.argmax(1).numpy().astype(np.uint8), g[f"eval{size}_argmax"])
+    torch.manual_seed(1)
+    m = zo.DeepLab(num_classes=21, pretrained=False)
+    for name, mod in m.named_modules():
+        if name.endswith("bn3"):
+            mod.weight.data.fill_(0.1)
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+    m.train()
+    b = zo.make_synthetic_batch(2, 312, seed=1312, with_label_emb=False)
+    w = torch.ones(21)
+    w[[10, 14]] = 100.0
+    logits = m(b["image"])
+    loss = zo.SegmentationLosses(weight=w).build_loss("ce")(logits, b["label"])
+    loss.backward()
+    ref = torch.from_numpy(g["train312_logits_sub"])
+    assert (logits.detach()[:, :, ::8, ::8] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert abs(loss.item() - float(g["train312_loss"])) <= 1e-6 * abs(float(g["train312_loss"]))
+    check_table(((k, p.grad) for k, p in m.named_parameters()), g["train312_grad_names"], g["train312_grad_stats"], rtol=2e-3,
+                what="grad312")
+    check_table(((k, v) for k, v in m.state_dict().items() if "running" in k), g["train312_run_names"], g["train312_run_stats"],
+                rtol=1e-5, what="running312")
+    gp = torch.from_numpy(g["train312_grad_pred_w"])
+    assert (m.decoder.pred_conv.weight.grad - gp).abs().max().item() <= 1e-4 * gp.abs().max().item()
+    torch.manual_seed(1)
+    m = zo.DeepLab(output_stride=8, num_classes=21, pretrained=False)
+    for name, mod in m.named_modules():
+        if name.endswith("bn3"):
+            mod.weight.data.fill_(0.1)
+    m.eval()
+    x = zo.make_synthetic_batch(2, 65, seed=8, with_label_emb=False)["image"]
+    with torch.no_grad():
+        logits = m(x)
+        top, low = m.backbone(x)
+    ref = torch.from_numpy(g["os8_logits"])
+    assert tuple(top.shape) == tuple(int(v) for v in g["os8_top_shape"]) == (2, 2048, 9, 9)
+    assert (logits - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert np.array_equal(logits.argmax(1).numpy().astype(np.uint8), g["os8_argmax"])
+    assert np.allclose(stats(top), g["os8_top_stats"], rtol=1e-5) and np.allclose(stats(low), g["os8_low_stats"], rtol=1e-5)
+
+
 def test_deeplab_forward_backward_matches_reference(golden, torch_threads):
     g = golden("deeplab_forward.npz")
     torch.manual_seed(1)

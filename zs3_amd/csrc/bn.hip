@@ -202,7 +202,13 @@ __global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_fwd_finalize_kernel(co
                                                              float momentum, float* running_mean, float* running_var,
                                                              float* mean_out, float* invstd_out, float* scale_out,
                                                              float* shift_out, long* num_batches_tracked, int* range_flag) {
-  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  // range guard, part 1: a flag that is ALREADY up when this launch starts (raised by an earlier layer of this forward pass or by an
+  // earlier step the host has not looked at yet; launches are stream-ordered) means this layer's input is what a dead layer
+  // produced -- ReLU turns its NaNs into finite zeros, so the sums below look fine and are garbage.  Such a launch leaves every
+  // persistent buffer alone: running statistics and num_batches_tracked keep their last good values on every layer downstream
+  // of the overflow and in every step until check_forward_range lowers the flag.
+  const bool flag_up = range_flag && *reinterpret_cast<volatile int*>(range_flag) != 0;
+  if (num_batches_tracked && !flag_up && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   int c;
   double s, q;
   const bool owner = combine_partials<FIN_CH, FIN_GROUPS>(partial, chunks, C, c, s, q);
@@ -221,8 +227,12 @@ __global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_fwd_finalize_kernel(co
     // range guard of the f16x3 forward: an operand beyond fp16's range makes the conv output -- and with it
     // these sums -- non-finite.  The layer raises the sticky flag (the fused SGD skips the step while it is up, the trainer falls
     // back to bf16x3 forward products) and leaves the persistent running statistics alone.
-    const bool bad = range_flag && !(isfinite(s) && isfinite(q));
-    if (bad) *range_flag = 1;
+    // (the layer that raises the flag itself: its channel groups race on the flag, so its finite channels may or may not update
+    // their running statistics and its num_batches_tracked counts the lost step -- one layer, one step; everything behind it is
+    // covered by `flag_up`)
+    const bool overflow = range_flag && !(isfinite(s) && isfinite(q));
+    if (overflow) *range_flag = 1;
+    const bool bad = overflow || flag_up;
     if (running_mean && !bad) {
       double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;

@@ -121,8 +121,11 @@ def check_forward_range(device=None, flag_value=None):
     """Range guard of the f16x3 forward.  fp16 hi/lo operands hold |x| <= 65504 (weights: |w| < 1023); the
     rule that selects them (batch-statistics layers: inputs are batch-normalised activations or the image) keeps real networks far
     inside that, but nothing in the data enforces it.  A layer whose operands overflowed produces non-finite batch sums, its
-    BatchNorm finalize raises the device's sticky flag (ops.range_flag) and skips its running-statistics update, and the fused
-    SGD skips its update while the flag is up -- the step is lost like a loss scaler's overflow step, nothing persistent is damaged.
+    BatchNorm finalize raises the device's sticky flag (ops.range_flag) and skips its running-statistics update -- as does every
+    finalize launch that finds the flag already up (the layers downstream of the overflow see a dead layer's zeros, the steps queued
+    before the host looks see garbage) -- and the fused SGD skips its update while the flag is up: the affected steps are lost like a
+    loss scaler's overflow steps; parameters, momentum and (up to the raising layer's own racing channel groups) running
+    statistics keep their last good values.
     This function is the host's half: called by LossLog / the trainers where they read the loss anyway (one iteration late,
     `flag_value` = the copied flag) or directly (device given: a synchronising read), it lowers the flag and switches the
     forward arithmetic to bf16x3 (fp32's exponent range) for every launch from then on.  Returns True when it fell back."""

@@ -90,14 +90,13 @@ class GCNContextStep(GMMNStep):
     # ---- per batch: CE of the clusters' features through pred_conv, weighted (:436-454)
     def _extra_classifier_terms(self):
         if not self._cluster_feats:
-            if self.group is not None:
-                # the globally normalised CE all-reduces its weight sum: a rank without clusters still has to take part.
-                # One ignored (label 255) dummy cluster, no backward.
-                dev = self._st["emb"].device
-                with torch.no_grad():
-                    dummy = torch.zeros((1, 1, 1, self.feature_dim), device=dev)
-                    out = self.model.decoder.forward_class_prediction(ops.nchw(dummy))
-                    self.criterion(out, torch.full((1, 1, 1), 255.0, device=dev))
+            # the globally normalised CE all-reduces [sum(w), sum(w * nll)] on every rank that calls the criterion in its training
+            # step: a rank without clusters still has to take part, with zeros.  (Not through the criterion on a dummy logit under
+            # no_grad: "auto" is local there by design -- validation must not touch torch.distributed -- and this rank would skip
+            # the collective the others issue.  ADVICE r5; tests/test_gpu_world2.py runs a rank without clusters.)
+            from .utils.loss import ce_exchange_nothing
+            owner = getattr(self.criterion, "__self__", None)
+            ce_exchange_nothing(getattr(owner, "group", None), self._st["emb"].device)
             return
         feats = torch.cat(self._cluster_feats, 0)                               # [K, D] = NHWC [1, K, 1, D]
         k, d = feats.shape

@@ -709,13 +709,26 @@ class GMMNStep:
         if self.group is not None:
             grads = [p.grad for g_ in self.optimizer.param_groups for p in g_["params"] if p.grad is not None]
             self.bytes_reduced += all_reduce_tensors(grads, group=pg, average=self.grad_reduce == "mean")
+            # one rank's f16x3 overflow (the backbone's train-mode BatchNorm forward raises the flag) reaches
+            # every rank inside the summed gradients: all ranks skip this classifier step and fall back together
+            from .parallel import exchange_range_flag
+            exchange_range_flag(dev, pg)
         self.optimizer.step()
         if ring_slots:
             if n_ring > st["loss_ring"].numel():
                 raise RuntimeError("more generator updates in one step than the loss ring holds")
             dst = torch.tensor([a_ for a_, _ in ring_slots], dtype=torch.int64, device=dev)
             mmd_losses.index_copy_(0, dst, st["loss_ring"][:n_ring])
-        vals = torch.cat((mmd_losses, closs.detach().reshape(1))).cpu()   # the single read-back of the step
+        # the single read-back of the step; the f16x3 range flag travels with it (this step never goes through LossLog: without
+        # this look a raised flag would make the fused SGD skip every later classifier step in silence -- ADVICE r5)
+        tail = [closs.detach().reshape(1)]
+        if ops._range_flags:
+            tail.append(ops.range_flag(dev).float())
+        vals = torch.cat((mmd_losses, *tail)).cpu()
+        if len(tail) == 2:
+            if float(vals[-1]) != 0.0:
+                Fz.check_forward_range(flag_value=1)     # lowers the flag, warns, bf16x3 forward products from here on
+            vals = vals[:-1]
         g_batch = sum(float(vals[sl]) / nuniq for sl, nuniq in mmd_slots)
         self.last_updates = len(mmd_slots)
         return g_batch, float(vals[-1]), out

@@ -11,6 +11,17 @@ from torch.nn.parallel import DataParallel
 
 def patch_replication_callback(data_parallel):
     assert isinstance(data_parallel, DataParallel)
+    ids = list(getattr(data_parallel, "device_ids", None) or [])
+    if len(ids) > 1:
+        # the reference's own invocation `--gpu-ids 0,1` (train_pascal.py:88-93) builds DataParallel(model, device_ids=[0, 1]):
+        # single-process replication would push modules that hold per-device weight planes, side streams and raw device pointers
+        # through DataParallel.replicate / scatter -- undefined behaviour.  Say what to run instead.
+        raise RuntimeError(
+            f"zs3_amd drives one MI355X per process: DataParallel over device_ids={ids} is not supported.  Launch one process per "
+            "GPU instead -- `torchrun --nproc-per-node N --master-addr 127.0.0.1 train_*.py ...` with "
+            "torch.distributed.init_process_group('nccl') and torch.cuda.set_device(LOCAL_RANK) at the top of the script, and wrap "
+            "the model as DataParallel(model, device_ids=[LOCAL_RANK]) (or leave the wrapper out): gradients, SyncBN statistics "
+            "and the loss normalisation then go over RCCL by construction (INTEGRATION.md).")
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         from ... import parallel

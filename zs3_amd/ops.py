@@ -75,7 +75,7 @@ def set_storage(dtype):
     Fz._in_affine_choice.clear()
 
 
-_exact_state = None   # weight-gradient kernel selection in force when the exact-fp32 test mode was entered
+_exact_state = None   # (weight-gradient kernel selection, PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW) in force when the exact-fp32 test mode was entered
 
 
 def set_exact_fp32(on=True):
@@ -86,18 +86,17 @@ def set_exact_fp32(on=True):
     global PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW, _exact_state
     from . import functional as Fz
     if on:
-        if _exact_state is None:
-            _exact_state = int(lib().zs3_conv_wgrad_set_kernel(I(1)))
+        if _exact_state is None:   # (PREC_DEFAULT and the kernel-family switches in force when the mode was entered: a round trip
+            # is the identity also INSIDE the 2-byte mode, where PREC_DEFAULT is 1 -- like set_storage's own save / restore)
+            _exact_state = (int(lib().zs3_conv_wgrad_set_kernel(I(1))), PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW)
         PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW = 0, False, False, False, False
         lib().zs3_conv_wgrad_set_kernel(I(1))
-    else:
-        PREC_DEFAULT = 3
-        HALO = os.environ.get("ZS3_HALO", "1") == "1"
-        PW = os.environ.get("ZS3_PW", "1") == "1"
-        WGRAD_STRIP = os.environ.get("ZS3_WGRAD_STRIP", "1") == "1"
-        WGRAD_PW = os.environ.get("ZS3_WGRAD_PW", "1") == "1"
-        lib().zs3_conv_wgrad_set_kernel(I(_exact_state if _exact_state is not None else 0))
+    elif _exact_state is not None:
+        wk, PREC_DEFAULT, HALO, PW, WGRAD_STRIP, WGRAD_PW = _exact_state
+        lib().zs3_conv_wgrad_set_kernel(I(wk))
         _exact_state = None
+    else:
+        return
     _TILE_CHOICE.clear()
     _WGRAD_PLAN.clear()
     _MTILES.clear()

@@ -190,8 +190,9 @@ class GradSync:
         # the f16x3 range flag (ops.range_flag) is per device, the gradients are not: one rank's overflow reaches
         # every rank as NaNs inside the all-reduced buckets, and only the rank whose own flag is up would skip the update.  MAX over
         # the group: every rank skips the step and falls back to bf16x3 forward products together.
-        from . import ops
-        dist.all_reduce(ops.range_flag(self.params[0].device), op=dist.ReduceOp.MAX, group=self.group)
+        # (Only while the f16x3 forward can be active at all -- fp32 storage, x3 arithmetic, switch on: a condition every rank
+        # evaluates alike, and after a fallback, which the ranks make together, the exchange is gone.)
+        exchange_range_flag(self.params[0].device, self.group)
         self._armed = False
 
     def remove(self):
@@ -200,6 +201,16 @@ class GradSync:
             h.remove()
         for p in self.params:
             Fz.register_grad_buffer(p, None)
+
+
+def exchange_range_flag(device, group=None):
+    """MAX all-reduce of the device's f16x3 range flag over the data-parallel group, when that arithmetic can be active (see
+    GradSync.finish; GMMNStep makes the same exchange before its classifier step).  Returns whether it exchanged."""
+    from . import ops
+    if not ops.fwd_f16() or not dist.is_initialized():
+        return False
+    dist.all_reduce(ops.range_flag(device), op=dist.ReduceOp.MAX, group=group)
+    return True
 
 
 class _null:

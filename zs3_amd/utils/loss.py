@@ -60,6 +60,21 @@ def global_ce_normalise(loss_ws, batch, group):
     return loss_ws[2] / loss_ws[1] / (batch if batch > 0 else 1), batch
 
 
+def ce_exchange_nothing(group, device):
+    """A rank's share of the criterion's collective when it has NOTHING to put through the criterion at a point where the other
+    ranks call it on a logit that requires a gradient (GCNContextStep: a rank whose images have no clusters): exactly the exchange
+    global_ce_normalise makes -- one SUM all-reduce of [sum(w), sum(w * nll)] -- with zeros.  `group` is the criterion's own
+    (SegmentationLosses.group): "auto" resolves as it does for the ranks that do call the criterion in their training step, so
+    the collectives pair up; None / a single rank: nothing happens."""
+    from ..parallel import resolve_group
+    group = resolve_group(group)
+    if group is None:
+        return False
+    import torch.distributed as dist
+    dist.all_reduce(torch.zeros(2, dtype=torch.float32, device=device), group=None if group is True else group)
+    return True
+
+
 def ce_group(group, logit):
     """the `group` a criterion call really uses: "auto" is local (None) unless the call is part of a training step -- gradient mode
     on and a logit that requires a gradient (see cross_entropy_2d)"""
