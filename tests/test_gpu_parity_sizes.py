@@ -66,7 +66,7 @@ def _argmax_agrees(out, gold, tol):
 
 
 # (size, delivered logits error vs fp64, bound) -- eval mode, default-initialised weights (running statistics 0 / 1)
-EVAL_CASES = {513: 1.5e-4, 312: 1.5e-4}
+EVAL_CASES = {513: 6e-5, 312: 6e-5}     # delivered on MI355X: 1.93e-5 / 1.96e-5 (the oracle's own fp32: 1.2e-6 / 1.5e-6)
 
 
 @pytest.mark.parametrize("size", sorted(EVAL_CASES))
@@ -90,7 +90,7 @@ def test_eval_logits_and_argmax_at_the_real_sizes(dev, golden, size):
     print(f"\n[parity {size}x{size} eval] logits vs fp64: ours {e:.2e}, the oracle's own fp32 {e32:.2e}; argmax identical on the "
           f"{100 * frac:.2f} % of pixels outside the 2 x {EVAL_CASES[size]:.0e} margin")
     assert e < 1e-3                      # north-star tolerance
-    assert e < EVAL_CASES[size]          # 3x delivered (5.3e-5 at 513, 4.5e-5 at 312 when written)
+    assert e < EVAL_CASES[size]          # 3x delivered
     assert frac > 0.99
     gold = torch.from_numpy(g[f"eval{size}_logits_sub"])
     eg = rel(out[:, :, ::8, ::8], gold)
@@ -103,15 +103,30 @@ def test_eval_logits_and_argmax_at_the_real_sizes(dev, golden, size):
 
 # train mode, tamed residual gains.  Bounds = 3x delivered (comment: delivered when written)
 TRAIN_TOL = {
-    513: {"logits": 3e-4, "loss": 3e-5, "running": 3e-4,
-          "grads": {"decoder.pred_conv.weight": 3e-4, "decoder.pred_conv.bias": 3e-4, "decoder.last_conv.0.weight": 3e-3,
-                    "aspp.conv1.weight": 6e-3, "backbone.layer4.2.conv3.weight": 9e-3, "backbone.layer1.0.conv1.weight": 3e-2,
-                    "backbone.conv1.weight": 3e-2, "backbone.bn1.weight": 3e-2}},
-    312: {"logits": 3e-4, "loss": 3e-5, "running": 3e-4,
-          "grads": {"decoder.pred_conv.weight": 3e-4, "decoder.pred_conv.bias": 3e-4, "decoder.last_conv.0.weight": 3e-3,
-                    "aspp.conv1.weight": 6e-3, "backbone.layer4.2.conv3.weight": 9e-3, "backbone.layer1.0.conv1.weight": 3e-2,
-                    "backbone.conv1.weight": 3e-2, "backbone.bn1.weight": 3e-2}},
+    # delivered at 513: logits 1.98e-4 (the oracle's own fp32: 1.0e-5), loss 1.9e-6, worst running statistic 2.1e-4
+    513: {"logits": 6e-4, "loss": 1e-5, "running": 6.5e-4,
+          "grads": {"decoder.pred_conv.weight": 2.5e-4,          # 7.7e-5  (oracle fp32: 3.6e-6)
+                    "decoder.pred_conv.bias": 5e-5,              # 1.4e-5  (1.8e-6)
+                    "decoder.last_conv.0.weight": 1.2e-2,        # 3.8e-3  (9.4e-4)
+                    "aspp.conv1.weight": 2.7e-2,                 # 8.9e-3  (9.5e-4)
+                    "backbone.layer4.2.conv3.weight": 2.4e-2,    # 7.9e-3  (1.6e-3)
+                    "backbone.layer1.0.conv1.weight": 2.6e-2,    # 8.6e-3  (2.9e-3)
+                    "backbone.conv1.weight": 2.6e-2,             # 8.4e-3  (2.9e-3)
+                    "backbone.bn1.weight": 3e-2}},               # 9.9e-3  (3.5e-3)
+    # delivered at 312: logits 1.38e-4 (7.5e-6), loss 1.5e-6, worst running statistic 2.1e-4
+    312: {"logits": 4.2e-4, "loss": 1e-5, "running": 6.5e-4,
+          "grads": {"decoder.pred_conv.weight": 2.8e-4,          # 9.3e-5  (4.4e-6)
+                    "decoder.pred_conv.bias": 8e-5,              # 2.7e-5  (1.1e-6)
+                    "decoder.last_conv.0.weight": 1.2e-2,        # 3.9e-3  (7.4e-4)
+                    "aspp.conv1.weight": 2.8e-2,                 # 9.2e-3  (6.6e-4)
+                    "backbone.layer4.2.conv3.weight": 2.6e-2,    # 8.4e-3  (1.5e-3)
+                    "backbone.layer1.0.conv1.weight": 2.7e-2,    # 8.9e-3  (3.6e-3)
+                    "backbone.conv1.weight": 2.7e-2,             # 9.0e-3  (3.1e-3)
+                    "backbone.bn1.weight": 2.6e-2}},             # 8.5e-3  (2.7e-3)
 }
+# (The gradient errors below the decoder are ~3x the fp32 oracle's own distance from fp64: the backward pass multiplies bf16x3
+# products (2^-16-class) and every ReLU whose pre-activation sits within that of zero may take the other
+# branch; the classifier's gradient, which sees no ReLU below it in the backward chain, is at 8e-5.)
 
 
 @pytest.mark.parametrize("size", sorted(TRAIN_TOL))
@@ -193,14 +208,14 @@ def test_output_stride_8_eval_forward(dev, golden):
         r32 = ref.eval()(x)
     assert out.shape == r64.shape and top.shape == rtop.shape == (2, 2048, 9, 9) and low.shape == rlow.shape
     e, e32, et = rel(out, r64), rel(r32, r64), rel(top, rtop)
-    frac = _argmax_agrees(out, r64, 1.5e-4)
+    frac = _argmax_agrees(out, r64, 6e-5)
     print(f"\n[parity OS8 65x65 eval] logits vs fp64: ours {e:.2e} (oracle fp32 {e32:.2e}), backbone output {et:.2e}, argmax "
           f"identical on {100 * frac:.2f} % of pixels")
-    assert e < 1.5e-4 and et < 1.5e-4 and frac > 0.98
+    assert e < 6e-5 and et < 3e-5 and frac > 0.98          # delivered: 1.96e-5, 9.6e-6, 99.7 %
     g = golden("sizes.npz")
     eg = rel(out, torch.from_numpy(g["os8_logits"]))
     print(f"[parity OS8 65x65 eval] vs the reference's golden logits: {eg:.2e}")
-    assert eg < 1.5e-4
+    assert eg < 6e-5            # delivered: 1.91e-5
     m.train()
     ref64.train()
     out = m(x.to(dev))
@@ -212,5 +227,5 @@ def test_output_stride_8_eval_forward(dev, golden):
     et = rel(out, r64)
     g = rel2(m.decoder.pred_conv.weight.grad, ref64.decoder.pred_conv.weight.grad)
     print(f"[parity OS8 65x65 train] logits {et:.2e}, loss {loss.item():.6f} vs {l64.item():.6f}, d pred_conv {g:.2e}")
-    assert et < 1e-3 and abs(loss.item() - l64.item()) < 1e-4 * abs(l64.item()) and g < 1e-3
+    assert et < 2e-4 and abs(loss.item() - l64.item()) < 1e-5 * abs(l64.item()) and g < 1.1e-4     # delivered: 5.4e-5, <1e-6, 3.5e-5
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
