@@ -333,6 +333,17 @@ int zs3_dropout_act_bwd(const float* dy, int ldd, const float* h, int ldh, float
  * with several consumers (aspp.py:104-108: x feeds five branches; deeplab.py:41-42: layer1's output feeds layer2 and the
  * decoder) in one pass -- autograd would add pairwise.  srcs: HOST array of device pointers; out may alias srcs[0]. */
 int zs3_sum_n(const void* const* srcs, int n, float* out, long count, int io, void* stream);
+/* The two fills / copies the step used to leave to the tensor library, as entry points of this one so that a recorded plan
+ * (below) carries them: zs3_fill_zero = `bytes` zero bytes at dst (the zero-initialised channel pad of a gradient buffer);
+ * zs3_pad_rows = dst[m][0:C] = src[m][0:C], dst[m][C:ldd] = 0 for M rows (io 0: 4-byte elements, 3: 2-byte) -- the 21 -> 24
+ * channel pad of the class-score gradient in front of pred_conv's data / weight gradient (decoder.py:26). */
+int zs3_fill_zero(void* dst, long bytes, void* stream);
+/* rows x [g][c] floats <-> rows x [G][C] floats (g <= G, c <= C), zero padded: unpack = 0 pads (dst = the [G][C] rows), unpack = 1
+ * selects the [g][c] corner back (src = the [G][C] rows).  The 7x7x3 stem weight as the 7 x (8 pixels x 4 channels) operand of
+ * the stem's window convolution (resnet.py:79 -> zs3_nchw3_to_nhwc4) and its gradient on the way back -- F.pad and its backward
+ * until round 5, the last tensor-library kernels inside the supervised step. */
+int zs3_repack_pad(const float* src, long rows, int g, int c, float* dst, int G, int C, int unpack, void* stream);
+int zs3_pad_rows(const void* src, int lds, int C, void* dst, int ldd, long M, int io, void* stream);
 /* out[c] = sum_m x[m][c] (rows in order): bias gradients of the generator's Linear layers */
 int zs3_colsum(const float* x, int ldx, int M, int C, float* out, void* stream);
 /* torch.optim.Adam for several tensors in one launch, device-resident step count; table[e] = {p, g, exp_avg, exp_avg_sq,
@@ -372,6 +383,14 @@ int zs3_sgd_step(float* p, const float* g, float* buf, long n, float lr, float m
 int zs3_sgd_chunk(void);
 int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov, const int* skip_flag,
                   void* stream);
+/* zs3_sgd_multi with the groups' hyper-parameters as LAUNCH ARGUMENTS: table[e][4] = the entry's parameter-group index,
+ * group_lr_wd = HOST array [ngroups][2] {lr, wd}, 1 <= ngroups <= zs3_sgd_max_groups() (-3 otherwise: use zs3_sgd_multi).  The
+ * table then holds nothing that a learning-rate schedule changes (lr_scheduler.py:46-76 sets a new lr before every step,
+ * base_trainer.py:15): no per-step table upload for the schedule, and a recorded plan (below) follows the schedule by patching
+ * this one argument (zs3_plan_patch). */
+int zs3_sgd_max_groups(void);
+int zs3_sgd_multi_g(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov, const int* skip_flag,
+                    const float* group_lr_wd, int ngroups, void* stream);
 /* step_dev (optional): device int64 holding the number of steps taken so far; overrides `step` (= step_dev[0] + 1) */
 int zs3_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                   float wd, int step, const void* step_dev, void* stream);
@@ -390,6 +409,54 @@ int zs3_cluster_graph(const int* seg, int H, int W, int* cmap, int* seed, int* l
  * batch up front and reads the B cluster counts back once. */
 int zs3_cluster_graph_batch(const int* seg, int B, int H, int W, int* cmap, int* seed, int* labels, int* ncluster, float* adj,
                             int cap, void* stream);
+
+/* ---- recorded launch plans: the step loop under the C ABI (round 6) ------------------------------------------------------- */
+/* The loop body of base_trainer.py:16-20 (zero_grad / forward / loss / backward / step) is ~1000 calls of the entry points above
+ * per iteration, identical from iteration to iteration up to a few scalars.  A PLAN records them once and replays them from C:
+ *
+ *   plan = zs3_plan_create();  zs3_plan_record_begin(plan);  <one eager step>;  nops = zs3_plan_record_end(plan);
+ *   per iteration:  zs3_plan_patch / zs3_plan_replace_u64 (learning rate, dropout seeds);  zs3_plan_replay(plan, 0, -1);
+ *
+ * While a plan records, every entry point whose last parameter is `void* stream` appends {its arguments} to the plan and then
+ * executes as usual (the recording wrappers are generated from this header: zs3_amd/build.py, csrc/gen/plan_wrappers.hip); HOST
+ * arrays among the arguments (zs3_sum_n's srcs, zs3_mmd_fwd's sigma, zs3_sgd_multi_g's group_lr_wd) are copied into the plan.
+ * zs3_plan_replay(plan, first, count) issues ops [first, first + count) (count < 0: to the end) again: same entry points, same
+ * arguments, same streams -- plain launches on the real streams, not a hipGraph, so side-stream launches overlap exactly as
+ * in the eager step.  Returns 0, or the first failing op's return code (its index: zs3_plan_failed_op).  The CALLER keeps every
+ * device buffer the recorded step touched alive and at its address (zs3_amd/plan.py records under a private allocator pool).
+ * One plan records at a time, process-wide (launches come from the caller's thread and from autograd's device thread).
+ * Calls return 0 / a count on success, < 0 on misuse (-1 bad handle / index, -2 recording state, -3 size, -4 kind). */
+long zs3_plan_create(void);
+int zs3_plan_destroy(long plan);
+int zs3_plan_record_begin(long plan);
+int zs3_plan_record_end(long plan);                 /* -> number of recorded ops */
+int zs3_plan_size(long plan);
+int zs3_plan_truncate(long plan, int nops);         /* forget the ops behind the first nops */
+int zs3_plan_replay(long plan, int first, int count);
+int zs3_plan_failed_op(long plan);
+int zs3_plan_op_name(long plan, int op, char* buf, int cap);          /* entry-point name of op (debugging, tests) */
+int zs3_plan_find_op(long plan, const char* name, int nth);           /* index of the nth op of that entry point, -1 if none */
+/* every recorded `unsigned long long` argument equal to old_value (a dropout seed: the forward launch and its backward launches
+ * carry the same one) becomes new_value; -> number of arguments rewritten */
+int zs3_plan_replace_u64(long plan, unsigned long long old_value, unsigned long long new_value);
+/* Rebinding a buffer of the recorded step (the input batch; the optimizer's table): zs3_plan_find_ptr lists where a device pointer
+ * occurs -- up to cap (op, arg) pairs into where[2k], where[2k + 1], -> the total -- and zs3_plan_set_ptr rewrites ONE argument.
+ * Ask right after the recording, while the buffer is alive and its address means nothing else.  zs3_plan_replace_ptr rewrites every
+ * pointer argument equal to old_ptr: only safe for addresses outside the recording's allocator pool -- inside it one address serves
+ * several tensors in the course of a step. */
+int zs3_plan_find_ptr(long plan, const void* ptr, int* where, int cap);
+int zs3_plan_set_ptr(long plan, int op, int arg, const void* ptr);
+int zs3_plan_replace_ptr(long plan, const void* old_ptr, const void* new_ptr);
+/* overwrite scalar / host-array argument `arg` (0-based position in the entry point's parameter list) of op with `bytes` bytes */
+int zs3_plan_patch(long plan, int op, int arg, const void* data, int bytes);
+/* read argument `arg` of op back (-> its size in bytes; cap = room at out): tests and debugging */
+int zs3_plan_get_arg(long plan, int op, int arg, void* out, int cap);
+/* kind of argument `arg` of op as a character code: 'p' pointer, 's' stream, 'i' int, 'l' long, 'f' float, 'd' double, 'u' unsigned long
+ * long, 'h' host array copied into the plan; 0 behind the last argument */
+int zs3_plan_arg_kind(long plan, int op, int arg);
+/* waiter waits for everything queued on producer so far (event record + stream wait, one reusable event per waiting stream):
+ * the cross-stream dependencies of the step (weight-gradient side streams, functional.py) as a recordable call. */
+int zs3_stream_wait(void* waiter, void* producer);
 
 #ifdef __cplusplus
 }

@@ -478,12 +478,125 @@ extern "C" int zs3_sgd_step(float* p, const float* g, float* buf, long n, float 
   return ZS3_LAUNCH_CHECK();
 }
 
+// dst[m][0:C] = src[m][0:C], dst[m][C:ldd] = 0 (T = 4- or 2-byte elements, moved as raw bits)
+template <typename T>
+__global__ void pad_rows_kernel(const T* __restrict__ src, int lds, int C, T* __restrict__ dst, int ldd, long M) {
+  const long total = M * ldd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / ldd;
+    const int c = (int)(i - m * ldd);
+    dst[i] = c < C ? src[m * lds + c] : T(0);
+  }
+}
+
+// pack: dst[r][j][k] (G x C per row) = src[r][j][k] (g x c per row) for j < g, k < c, else 0;  unpack: the inverse selection
+__global__ void repack_pad_kernel(const float* __restrict__ src, long rows, int g, int c, float* __restrict__ dst, int G, int C,
+                                  int unpack) {
+  const int per = unpack ? g * c : G * C;
+  const long total = rows * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / per;
+    const int e = (int)(i - r * per);
+    if (unpack) {
+      const int j = e / c, k = e - j * c;
+      dst[i] = src[r * (G * C) + j * C + k];
+    } else {
+      const int j = e / C, k = e - j * C;
+      dst[i] = (j < g && k < c) ? src[r * (g * c) + j * c + k] : 0.f;
+    }
+  }
+}
+
+extern "C" int zs3_repack_pad(const float* src, long rows, int g, int c, float* dst, int G, int C, int unpack, void* stream) {
+  if (rows <= 0) return 0;
+  if (g > G || c > C || g < 1 || c < 1) return -1;
+  hipLaunchKernelGGL(repack_pad_kernel, dim3(ew_blocks(rows * (unpack ? g * c : G * C))), dim3(256), 0, (hipStream_t)stream, src,
+                     rows, g, c, dst, G, C, unpack);
+  return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_fill_zero(void* dst, long bytes, void* stream) {
+  if (bytes <= 0) return 0;
+  return (int)hipMemsetAsync(dst, 0, (size_t)bytes, (hipStream_t)stream);
+}
+
+extern "C" int zs3_pad_rows(const void* src, int lds, int C, void* dst, int ldd, long M, int io, void* stream) {
+  if (M <= 0) return 0;
+  if (C > ldd || (io != 0 && io != 3)) return -1;
+  if (io == 3)
+    hipLaunchKernelGGL(pad_rows_kernel<unsigned short>, dim3(ew_blocks(M * ldd)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, lds, C, (unsigned short*)dst, ldd, M);
+  else
+    hipLaunchKernelGGL(pad_rows_kernel<unsigned>, dim3(ew_blocks(M * ldd)), dim3(256), 0, (hipStream_t)stream, (const unsigned*)src,
+                       lds, C, (unsigned*)dst, ldd, M);
+  return ZS3_LAUNCH_CHECK();
+}
+
 extern "C" int zs3_sgd_chunk(void) { return ZS3_SGD_CHUNK; }
 extern "C" int zs3_sgd_multi(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov,
                              const int* skip_flag, void* stream) {
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL(sgd_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)table,
                      (const int*)blockmap, momentum, nesterov, skip_flag);
+  return ZS3_LAUNCH_CHECK();
+}
+
+// zs3_sgd_multi with the learning rate / weight decay of the parameter GROUPS as launch arguments: table[e][4] is the entry's
+// group index and {lr, wd} of up to ZS3_SGD_MAX_GROUPS groups travel by value with the launch.  The table then depends on nothing
+// that changes from step to step (a poly schedule changes lr every iteration): a recorded plan patches the launch argument, an
+// eager step needs no per-step host-to-device copy for the schedule.
+#define ZS3_SGD_MAX_GROUPS 8
+struct SgdGroups {
+  float lr[ZS3_SGD_MAX_GROUPS], wd[ZS3_SGD_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void sgd_multi_g_kernel(const long* __restrict__ table, const int* __restrict__ blockmap,
+                                                         float momentum, int nesterov, const int* __restrict__ skip_flag,
+                                                         const SgdGroups groups) {
+  const int e = blockmap[2 * blockIdx.x], chunk = blockmap[2 * blockIdx.x + 1];
+  const long* t = table + 6L * e;
+  float* p = reinterpret_cast<float*>(t[0]);
+  const float* g = reinterpret_cast<const float*>(t[1]);
+  float* buf = reinterpret_cast<float*>(t[2]);
+  const long n = t[3];
+  const int grp = (int)t[4] & (ZS3_SGD_MAX_GROUPS - 1);
+  // (selected with compares: a dynamic index into a by-value kernel argument would send the struct through scratch memory)
+  float lr = groups.lr[0], wd = groups.wd[0];
+#pragma unroll
+  for (int k = 1; k < ZS3_SGD_MAX_GROUPS; ++k)
+    if (grp == k) {
+      lr = groups.lr[k];
+      wd = groups.wd[k];
+    }
+  const int first = (int)t[5];
+  const long lo = (long)chunk * ZS3_SGD_CHUNK, hi = min(n, lo + ZS3_SGD_CHUNK);
+  if (skip_flag && *skip_flag) {
+    if (first && momentum != 0.f)
+      for (long i = lo + threadIdx.x; i < hi; i += 256) buf[i] = 0.f;
+    return;
+  }
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    float d = g[i] + wd * p[i];
+    if (momentum != 0.f) {
+      float b = first ? d : momentum * buf[i] + d;
+      buf[i] = b;
+      d = nesterov ? d + momentum * b : b;
+    }
+    p[i] -= lr * d;
+  }
+}
+
+extern "C" int zs3_sgd_max_groups(void) { return ZS3_SGD_MAX_GROUPS; }
+extern "C" int zs3_sgd_multi_g(const void* table, const void* blockmap, int nblocks, float momentum, int nesterov,
+                               const int* skip_flag, const float* group_lr_wd, int ngroups, void* stream) {
+  if (nblocks <= 0) return 0;
+  if (ngroups < 1 || ngroups > ZS3_SGD_MAX_GROUPS || !group_lr_wd) return -3;
+  SgdGroups groups;
+  for (int k = 0; k < ZS3_SGD_MAX_GROUPS; ++k) {
+    groups.lr[k] = k < ngroups ? group_lr_wd[2 * k] : 0.f;
+    groups.wd[k] = k < ngroups ? group_lr_wd[2 * k + 1] : 0.f;
+  }
+  hipLaunchKernelGGL(sgd_multi_g_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const long*)table,
+                     (const int*)blockmap, momentum, nesterov, skip_flag, groups);
   return ZS3_LAUNCH_CHECK();
 }
 

@@ -48,7 +48,6 @@ _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 _raw_current = getattr(torch._C, "_cuda_getCurrentStream", None)
 _raw_set = getattr(torch._C, "_cuda_setStream", None)
 _stream_objs = {}      # (stream_id, device_index, device_type) -> torch.cuda.Stream
-_fork_events = {}      # id(side stream) -> the Event that carries "main has produced dy / x" over to it
 
 
 def _current_stream():
@@ -69,12 +68,20 @@ def _set_stream(s):
 
 
 def _wait_for(waiter, producer):
-    """waiter.wait_stream(producer) with a reused Event (a wait refers to the record before it: re-recording later is safe)"""
-    ev = _fork_events.get(id(waiter))
-    if ev is None:
-        ev = _fork_events[id(waiter)] = torch.cuda.Event()
-    ev.record(producer)
-    waiter.wait_event(ev)
+    """waiter.wait_stream(producer) as ONE call of the library (zs3_stream_wait: event record + stream wait on one reusable event per
+    waiting stream).  Under the C ABI since round 6 so that a recorded plan (zs3_amd/plan.py) carries the step's cross-stream
+    dependencies; it is also the cheapest spelling (torch's Event.record + Stream.wait_event: two calls of 5-10 us)."""
+    ops.check(ops.lib().zs3_stream_wait(waiter.cuda_stream, producer.cuda_stream), "zs3_stream_wait")
+
+
+# A recorded plan replays the step's launches with the addresses of the recording step, without the caching allocator in between.
+# While a plan records (zs3_amd/plan.py sets this), tensors that a SIDE stream reads are therefore not handed to the allocator's
+# record_stream bookkeeping -- it makes a block reusable when the HOST has seen the side stream's event complete, a fact about the
+# recording run's timing that no replay repeats -- but kept alive here until the end-of-backward join, after which the main stream
+# (where they were allocated) is ordered behind every side-stream reader.
+PLAN_RECORDING = False
+_plan_keep = []
+PLAN_EPOCH = [0]     # bumped whenever buffers a plan may have recorded are dropped (weight planes, mode switches): plans re-record
 
 
 def wgrad_streams(device):
@@ -99,7 +106,7 @@ def join_wgrad_stream():
     _wgrad_side_of.clear()
     for pool in _side.values():
         for st in pool:
-            torch.cuda.current_stream(st.device).wait_stream(st)
+            _wait_for(torch.cuda.current_stream(st.device), st)
 
 
 
@@ -140,6 +147,7 @@ def check_forward_range(device=None, flag_value=None):
         flag.zero_()          # (stream order: the steps queued before this line still see it raised and skip their update)
     if ops.FWD_F16:     # (a later call that finds an older step's copy of the raised flag only lowers it again: one warning per fallback)
         ops.FWD_F16 = False
+        PLAN_EPOCH[0] += 1
         _planes.clear()
         _refresh_tables.clear()
         _defer_choice.clear()
@@ -171,7 +179,8 @@ def weight_planes(w, need_t=True, f16=False):
 def invalidate_planes(*params):
     """Drop cached planes of parameters that were updated through raw pointers (our fused optimizers)."""
     for w in params:
-        _planes.pop(id(w), None)
+        if _planes.pop(id(w), None) is not None:
+            PLAN_EPOCH[0] += 1       # a recorded plan may hold these buffers' addresses
 
 
 # ---------------------------------------------------------------------------------- gradient buckets (parallel.GradSync)
@@ -304,6 +313,11 @@ def _pad_channels(t, mult):
     if ld > 0 and ld % mult == 0 and (c % mult == 0):
         return t
     cp = (c + mult - 1) // mult * mult
+    if t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.stride(-1) == 1:
+        try:
+            return ops.pad_rows(t, cp)          # one launch of the library (a recorded plan carries it)
+        except AssertionError:
+            pass                                # rows without a uniform stride: the general copy below
     buf = torch.zeros(t.shape[:-1] + (cp,), dtype=t.dtype, device=t.device)
     buf[..., :c].copy_(t)
     return buf[..., :c]
@@ -495,11 +509,13 @@ class _ConvBnAct(torch.autograd.Function):
             want_bias = ctx.has_bias and ctx.needs_input_grad[4]
             dy = _pad_channels(dz, 8) if (need_x or need_w or (want_bias and not vec_ok)) else dz
             if want_bias:
+                # column sums in two launches of the library: per-chunk partial sums, then the chunks (rows of [chunks][2][C], every
+                # second one) added in order -- no tensor-library reduction on the path (a recorded plan replays both)
                 if vec_ok:
-                    dbias = ops.colstats(dz)[:, 0].sum(0)
+                    dbias = _sum_partials(ops.colstats(dz))
                 else:  # odd channel count (21 classes): reduce the zero-padded 8-aligned copy with the HIP kernel
                     full = dy.as_strided(dy.shape[:-1] + (ops._rows(dy)[2],), dy.stride(), dy.storage_offset())
-                    dbias = ops.colstats(full)[:, 0].sum(0)[:cout]
+                    dbias = _sum_partials(ops.colstats(full))[:cout]
         dx = dw = None
         lazy_bits = None
         if dskip is not None:
@@ -540,9 +556,8 @@ class _ConvBnAct(torch.autograd.Function):
                 if dskip is not None and not fuse:
                     dx = dx + dskip
                 if dx.shape[-1] != ctx.x_shape[-1]:  # x carried pad channels
-                    full = torch.zeros(ctx.x_shape, dtype=dx.dtype, device=dx.device)
-                    full[..., : dx.shape[-1]].copy_(dx)
-                    dx = full
+                    dx = _pad_channels(dx, ctx.x_shape[-1])
+                    dx = dx.as_strided(ctx.x_shape, dx.stride(), dx.storage_offset())
             else:
                 raise RuntimeError("the stem convolution has no data gradient (its input is the image)")
         elif dskip is not None and ctx.needs_input_grad[0]:
@@ -558,28 +573,31 @@ class _ConvBnAct(torch.autograd.Function):
             if side is not None:
                 main = _current_stream()
                 _wait_for(side, main)           # dy (and x) are ready on the main stream
-                dy.record_stream(side)          # keep their memory from being recycled while the side stream reads it
-                x.record_stream(side)
+                if PLAN_RECORDING:
+                    _plan_keep.append((dy, x))  # (see PLAN_RECORDING: alive until the join, no allocator bookkeeping)
+                else:
+                    dy.record_stream(side)      # keep their memory from being recycled while the side stream reads it
+                    x.record_stream(side)
                 _set_stream(side)
                 try:
                     dw = ops.conv2d_wgrad(dy, x, wp.cout, wp.cin, wp.kh, wp.kw, stride, pad, pad, dil, prec=prec,
                                           out=_bucket_out(weight, wp), x_affine=ctx.x_affine)
                 finally:
                     _set_stream(main)
-                dw.record_stream(main)
+                dw.record_stream(main)          # (allocated on the side stream, read on main by the optimizer)
                 first_side = _wgrad_side_of.get(id(weight))
                 if first_side is not None:
                     # a weight used by two layers: autograd ADDS this contribution to the first one on the main stream as soon as
                     # both exist -- before the end-of-backward join -- so the main stream has to see both launches finished
-                    main.wait_stream(first_side)
-                    main.wait_stream(side)
+                    _wait_for(main, first_side)
+                    _wait_for(main, side)
                 else:
                     _wgrad_side_of[id(weight)] = side
                 if not (weight.is_leaf and weight.grad is None):
                     # the gradient is READ inside this backward pass -- accumulated into an existing .grad (a second
                     # backward before the optimizer step) or propagated through a non-leaf weight (a transposed /
                     # computed operand) -- so the main stream cannot wait for the end-of-backward join
-                    main.wait_stream(side)
+                    _wait_for(main, side)
                 if not _join_armed[0]:
                     _join_armed[0] = True
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
@@ -593,6 +611,14 @@ class _ConvBnAct(torch.autograd.Function):
             else:
                 dw = cfg["wgrad"](dy, x)
         return dx, dw, dgamma, dbeta, dbias, dres, None
+
+
+def _sum_partials(part):
+    """[chunks][2][C] partial column sums -> [C] totals of the first plane (zs3_colsum over rows of stride 2C)"""
+    chunks, _, c = part.shape
+    out = torch.empty(c, dtype=torch.float32, device=part.device)
+    ops.check(ops.lib().zs3_colsum(ops.P(part), ops.I(2 * c), ops.I(chunks), ops.I(c), ops.P(out), ops.stream()), "zs3_colsum")
+    return out
 
 
 def _applies_in_affine(x, wp, stride, pad, dil, prec, bn, residual, need_grad):
@@ -852,7 +878,7 @@ class _Bilinear(torch.autograd.Function):
         out = None
         if ctx.grad_pad and c % ctx.grad_pad:
             cp = (c + ctx.grad_pad - 1) // ctx.grad_pad * ctx.grad_pad
-            out = torch.zeros((n, h, w, cp), dtype=dout.dtype, device=dout.device)[..., :c]
+            out = ops.zeros((n, h, w, cp), dout.dtype, dout.device)[..., :c]
         return ops.bilinear_bwd(dout, (h, w), out=out), None, None, None
 
 

@@ -86,7 +86,10 @@ class ASPP(nn.Module):
             p = self.global_avg_pool[1].forward_nhwc(Fz.global_avg_pool(xs[4]), bn, act=Fz.ACT_RELU)   # [N,1,1,256]
             return Fz.broadcast_to(p, (h, w), out=cat[..., 1024:1280])
 
-        concurrent = x.is_cuda and (Fz.CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())
+        # (not while a plan records: autograd runs a node's backward on the stream of its forward and orders the streams with events
+        # of its own, which no recorded plan would carry -- zs3_amd/plan.py; the recorded step keeps every node on one stream)
+        concurrent = x.is_cuda and not Fz.PLAN_RECORDING and (
+            Fz.CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())
         if not concurrent:
             parts = [branch(0), branch(1), branch(2), branch(3), pooled()]
         else:

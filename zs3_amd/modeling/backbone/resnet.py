@@ -4,7 +4,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as TF
 
 from ... import functional as Fz
 from ... import ops
@@ -88,7 +87,7 @@ class ResNet(nn.Module):
         wp = max(w + 7, 2 * (wo - 1) + 8)
         xp = torch.empty((n, h, wp, 4), dtype=torch.float32, device=image.device)
         check(lib().zs3_nchw3_to_nhwc4(P(image), P(xp), I(n), I(h), I(w), I(wp), I(3), stream()), "zs3_nchw3_to_nhwc4")
-        w_eff = TF.pad(self.conv1.weight.permute(0, 2, 3, 1), (0, 1, 0, 1)).reshape(64, 7, 1, 32).permute(0, 3, 1, 2)
+        w_eff = _StemWeight.apply(self.conv1.weight)     # [64, 32, 7, 1]: 7 taps x (8 pixels x 4 channels), zero padded
         geom = dict(ho=ho, wo=wo, cin_pad=32, cin_valid=32, kh=7, kw=1, stride=2, pad_h=3, pad_w=0, dil=1, ncols=64)
 
         def wgrad(dy, x):
@@ -125,6 +124,31 @@ class ResNet(nn.Module):
         state_dict = self.state_dict()
         state_dict.update({k[7:]: v for k, v in pretrain_dict.items() if k[7:] in state_dict})
         self.load_state_dict(state_dict)
+
+
+class _StemWeight(torch.autograd.Function):
+    """[64, 3, 7, 7] -> [64, 32, 7, 1]: row (o, kh) of the channels_last weight, 7 x 3 floats, becomes 8 x 4 floats (one zero pixel, one
+    zero channel per pixel) -- F.pad(w.permute(0, 2, 3, 1), (0, 1, 0, 1)).reshape(64, 7, 1, 32).permute(0, 3, 1, 2), and its backward,
+    as two launches of the library (zs3_repack_pad) so that a recorded plan carries them."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        from ..._lib import I, P, check, lib, stream
+        co, ci, kh, kw = weight.shape
+        wl = weight.detach().permute(0, 2, 3, 1).contiguous()          # a view for channels_last parameters
+        out = torch.empty((co, kh, 1, 32), dtype=torch.float32, device=weight.device)
+        check(lib().zs3_repack_pad(P(wl), co * kh, I(kw), I(ci), P(out), I(8), I(4), I(0), stream()), "zs3_repack_pad")
+        ctx.geom = (co, ci, kh, kw)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dw):
+        from ..._lib import I, P, check, lib, stream
+        co, ci, kh, kw = ctx.geom
+        d = dw.permute(0, 2, 3, 1).contiguous()                         # [64, 7, 1, 32]
+        out = torch.empty((co, kh, kw, ci), dtype=torch.float32, device=dw.device)
+        check(lib().zs3_repack_pad(P(d), co * kh, I(kw), I(ci), P(out), I(8), I(4), I(1), stream()), "zs3_repack_pad")
+        return out.permute(0, 3, 1, 2)                                  # logical OIHW, channels_last memory like the parameter
 
 
 def ResNet101(output_stride, BatchNorm, pretrained=True, imagenet_pretrained_path=""):

@@ -66,6 +66,7 @@ def set_storage(dtype):
         lib().zs3_conv_wgrad_set_kernel(I(wk))
         _fp32_state = None
     ACT_DTYPE = dtype
+    Fz.PLAN_EPOCH[0] += 1
     _TILE_CHOICE.clear()
     _WGRAD_PLAN.clear()
     _MTILES.clear()
@@ -97,6 +98,7 @@ def set_exact_fp32(on=True):
         _exact_state = None
     else:
         return
+    Fz.PLAN_EPOCH[0] += 1
     _TILE_CHOICE.clear()
     _WGRAD_PLAN.clear()
     _MTILES.clear()
@@ -811,6 +813,21 @@ def dropout_act_bwd(dy, h, p, seed, leak, row_idx=None, seed_dev=None):
                                     ctypes.c_ulonglong(seed), P(row_idx), P(seed_dev), F(leak), stream()),
           "zs3_dropout_act_bwd")
     return out
+
+
+def zeros(shape, dtype, device):
+    """torch.zeros through the library (zs3_fill_zero): a recorded plan replays the fill"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    check(lib().zs3_fill_zero(P(t), ctypes.c_long(t.numel() * t.element_size()), stream()), "zs3_fill_zero")
+    return t
+
+
+def pad_rows(t, cp):
+    """[..., C] rows (contiguous channels, uniform row stride) -> a dense [..., cp] tensor's [..., :C] view whose pad channels are zero"""
+    m, c, ld = _rows(t)
+    buf = torch.empty(t.shape[:-1] + (cp,), dtype=t.dtype, device=t.device)
+    check(lib().zs3_pad_rows(P(t), I(ld), I(c), P(buf), I(cp), ctypes.c_long(m), I(3 if t.dtype == BF16 else 0), stream()), "zs3_pad_rows")
+    return buf[..., :c]
 
 
 def colsum(x, out=None):

@@ -29,6 +29,13 @@ class SGD(torch.optim.SGD):
             for p in group["params"]:
                 p.grad = None
 
+    def group_hyper(self):
+        """{lr, weight_decay} of every parameter group as the host float array zs3_sgd_multi_g takes (and a plan patches)"""
+        vals = []
+        for group in self.param_groups:
+            vals.extend((float(group["lr"]), float(group["weight_decay"])))
+        return (ctypes.c_float * len(vals))(*vals)
+
     @torch.no_grad()
     def step(self, closure=None):
         """One multi-tensor launch per (device, momentum, nesterov).  The host side runs at every step boundary, where the
@@ -40,12 +47,16 @@ class SGD(torch.optim.SGD):
         loss = closure() if closure is not None else None
         chunk = lib().zs3_sgd_chunk()
         by_cfg = {}
-        touched, keep = [], []
-        for group in self.param_groups:
+        touched, keep, tables = [], [], []
+        # learning rate / weight decay of the groups as launch arguments (zs3_sgd_multi_g: the table holds the group INDEX, so a
+        # schedule changes no device memory and a recorded plan follows it by patching one argument); more groups than the launch
+        # carries: the packed-floats table of zs3_sgd_multi
+        by_group = len(self.param_groups) <= lib().zs3_sgd_max_groups()
+        for gi, group in enumerate(self.param_groups):
             if group.get("dampening", 0) != 0 or group.get("maximize", False):
                 raise NotImplementedError("zs3_amd.optim.SGD supports dampening=0, maximize=False")
             lr, mom, wd, nest = group["lr"], group["momentum"], group["weight_decay"], group["nesterov"]
-            packed = struct.unpack("<q", struct.pack("<ff", lr, wd))[0]
+            packed = gi if by_group else struct.unpack("<q", struct.pack("<ff", lr, wd))[0]
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -87,9 +98,15 @@ class SGD(torch.optim.SGD):
             # (skip flag: while the f16x3 forward's range flag is up the gradients are not finite and the step is skipped)
             from . import ops
             flag = ops.range_flag(dev) if dev.type == "cuda" else None
-            check(lib().zs3_sgd_multi(P(table_d), P(hit[1]), I(hit[2]), F(mom), I(int(nest)), P(flag), stream()), "zs3_sgd_multi")
-            keep.extend((table, table_d))
+            if by_group:
+                check(lib().zs3_sgd_multi_g(P(table_d), P(hit[1]), I(hit[2]), F(mom), I(int(nest)), P(flag), self.group_hyper(),
+                                            I(len(self.param_groups)), stream()), "zs3_sgd_multi_g")
+            else:
+                check(lib().zs3_sgd_multi(P(table_d), P(hit[1]), I(hit[2]), F(mom), I(int(nest)), P(flag), stream()), "zs3_sgd_multi")
+            keep.extend((table, table_d, hit[1]))
+            tables.append(table_d)
         self._keepalive = keep   # pinned staging buffers must outlive the asynchronous copies
+        self._zs3_tables = tables   # (zs3_amd/plan.py moves a recorded step's tables out of the step's allocator pool)
         Fz.refresh_planes(*touched)   # one launch re-splits every updated conv weight into its bf16 hi/lo planes
         return loss
 

@@ -27,7 +27,9 @@ class _CrossEntropy(torch.autograd.Function):
         loss_ws = torch.empty(3, dtype=torch.float32, device=logit.device)
         check(lib().zs3_ce_fwd(P(z), I(ld), P(target), I(int(target.dtype == torch.int64)), P(weight), ctypes.c_long(pix),
                                I(c), I(ignore_index), I(batch), P(part), P(loss_ws), stream()), "zs3_ce_fwd")
-        loss = loss_ws[0].clone()
+        # (a view, not a clone: the kernel's own output is what the caller reads -- no tensor-library copy on the path, so a recorded
+        # plan's replay refreshes the very tensor the trainer holds)
+        loss = loss_ws[0]
         from ..parallel import resolve_group
         group = resolve_group(group)
         if group is not None:
