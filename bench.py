@@ -82,6 +82,10 @@ def parse():
     ap.add_argument("--script-steps", type=int, default=3,
                     help="timed iterations of `gmmn.script_loop`: the reference's own per-image x per-class loop body "
                          "(train_pascal_GMMN.py:139-268) on the drop-in modules; 0 = skip")
+    ap.add_argument("--plan", type=int, default=1,
+                    help="1 (default): the supervised step runs as a recorded launch plan (zs3_amd/plan.py: recorded once after two eager "
+                         "steps, then replayed from C -- bit-identical to the eager step, tests/test_gpu_plan.py); 0: every step eager "
+                         "(one Python -> ctypes call per launch).  Instrumented steps (roofline events) are always eager.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -176,7 +180,10 @@ def main():
             host["ready"][slot] = ev
         stage(0)
 
-    def supervised_step(i):
+    from zs3_amd.plan import StepPlan
+    plan_step = StepPlan(model, crit, opt, enabled=bool(args.plan))
+
+    def supervised_step(i, eager=False):
         img, lab = image, label
         if host is not None:
             slot = i & 1
@@ -185,11 +192,9 @@ def main():
             host["stream"].wait_stream(torch.cuda.current_stream())   # the other buffer's last reader (step i-1) is queued
             stage(slot ^ 1)
         sched(opt, i, 0, 0.0)
-        opt.zero_grad()
-        out = model(img)
-        loss = crit(out, lab)
-        loss.backward()
-        opt.step()
+        # zero_grad -> forward -> loss -> backward -> optimizer step (base_trainer.py:16-20): eager for the first two calls of a
+        # configuration, recorded on the third, replayed from C afterwards (N > 1: always eager, the collectives are torch.distributed's)
+        out, loss = plan_step(img, lab, eager=eager)
         # the trainer reads the loss of every iteration (zs3_amd/base_trainer.py; the reference: base_trainer.py:21,24).  Read the way
         # the trainer reads it: copied to pinned host memory behind the step, looked at one iteration later -- every value is read,
         # no step waits for its own
@@ -304,6 +309,15 @@ def main():
     def measure_supervised(steps, warmup, roofline):
         """warm-up + timed supervised steps -> (seconds, last loss, event records of the timed steps, of the last warm-up step,
         instrumented step count)"""
+        if plan_step.enabled and plan_step._plannable(image, label):
+            # settle + record the launch plan of this configuration OUTSIDE the measured steps (two eager steps, one recorded: the
+            # recording allocates its private pool with fresh hipMallocs).  These are extra untimed steps in front of the W warm-up steps.
+            plan_step.close()
+            rec0, rep0 = plan_step.recordings, plan_step.replays
+            for i in range(5):
+                if plan_step.recordings > rec0 and plan_step.replays > rep0:
+                    break
+                supervised_step(i)
         if not roofline:
             dt, last = run(supervised_step, steps, warmup)
             return dt, last, [], [], 0
@@ -314,7 +328,7 @@ def main():
         for i in range(warmup):
             if i == warmup - 1:
                 ops.PROFILE = []
-            supervised_step(i)
+            supervised_step(i, eager=True)        # (timing events around every conv launch live in the Python wrappers)
         warm_prof = ops.PROFILE
         torch.cuda.synchronize()
         by_cfg = {}
@@ -343,7 +357,7 @@ def main():
                 nth[0] += 1
             else:
                 ops.PROFILE, ops.PROFILE_SAMPLE = None, None
-            return supervised_step(i)
+            return supervised_step(i, eager=instrument(i))
         dt, last = run(sampled_step, steps, 0)
         ops.PROFILE, ops.PROFILE_CFGS, ops.PROFILE_SAMPLE = None, None, None
         return dt, last, timed_prof, warm_prof, sum(1 for i in range(steps) if instrument(i))
@@ -356,6 +370,11 @@ def main():
         # are a finite pool that the side-stream waits of the weight-gradient launches share)
         roof_main = roofline_of(prof, warm_prof, instrumented, args.dtype) if (rank == 0 and prof) else None
         prof, warm_prof = [], []
+        executor = {"plan": bool(plan_step.recorded_ops), "recorded_launches": plan_step.recorded_ops,
+                    "timed_steps_replayed": args.steps - instrumented if plan_step.recorded_ops else 0,
+                    "timed_steps_eager": instrumented if plan_step.recorded_ops else args.steps,
+                    "note": "zs3_amd/plan.py: the step's entry-point calls recorded once (include/zs3hip.h, zs3_plan_*) and replayed from C, "
+                            "bit-identical to the eager step; the steps instrumented for `roofline` (HIP events around sampled launches) run eagerly"}
         if args.bf16_steps > 0 and world == 1 and args.dtype == "bf16x3":
             # the 2-byte mode (BASELINE configs[4] "bf16") on the same model, optimizer and batch: activations and
             # inter-layer gradients stored as bf16, plain bf16 products
@@ -413,6 +432,8 @@ def main():
         result["gmmn"] = gmmn_info
     if bf16_info:
         result["bf16"] = bf16_info
+    if args.workload == "supervised":
+        result["executor"] = executor
     if roof_main is not None:
         result["roofline"] = roof_main
     if cpu_info is not None:

@@ -280,9 +280,10 @@ def test_io_argument_sits_before_the_stream_on_every_activation_entry_point():
     with_io = {n for n, a in sigs.items() if len(a) >= 2 and a[-1] == "void* stream" and a[-2] == "int io"}
     for name in ("zs3_conv_igemm", "zs3_conv_igemm_in", "zs3_conv_igemm_bnstats", "zs3_conv_wgrad", "zs3_conv_wgrad_strip",
                  "zs3_conv_wgrad_pw", "zs3_affine_act", "zs3_bn_act_bwd", "zs3_bn_bwd_stats", "zs3_maxpool_fwd", "zs3_maxpool_bwd",
-                 "zs3_bilinear_fwd", "zs3_bilinear_bwd", "zs3_sum_n", "zs3_group_colsum", "zs3_colstats", "zs3_dropout"):
+                 "zs3_bilinear_fwd", "zs3_bilinear_bwd", "zs3_sum_n", "zs3_group_colsum", "zs3_colstats", "zs3_dropout",
+                 "zs3_pad_rows"):
         assert name in with_io, name
-    assert len(with_io) == 17
+    assert len(with_io) == 18
     for name in ("zs3_sgd_multi", "zs3_adam_step", "zs3_bn_fwd_finalize", "zs3_bn_bwd_finalize", "zs3_prep_weight",
                  "zs3_prep_weight_f16fwd", "zs3_prep_weight_f32", "zs3_mmd_fwd"):
         assert name in sigs and name not in with_io, name
@@ -403,3 +404,41 @@ def test_forward_inside_a_running_backward_keeps_the_backward_bookkeeping():
     assert seen["inside"] == (True, True)
     Fz._reset_backward_state()              # outside any autograd pass: the leftovers of a dead pass go
     assert 12345 not in Fz._handed and not Fz._handed_armed[0]
+
+
+def test_plan_entry_points_and_generated_wrappers():
+    """Recorded launch plans (include/zs3hip.h, csrc/plan.hip): the misuse codes of the plan API (no launch, so no GPU needed), and
+    the generated recording wrappers are the ones zs3_amd/build.py derives from the header as it is now -- one per entry point
+    whose last parameter is `void* stream`, nothing else renamed."""
+    from zs3_amd import build
+    from zs3_amd._lib import lib
+    L = lib()
+    a, b = L.zs3_plan_create(), L.zs3_plan_create()
+    assert a and b and a != b
+    assert L.zs3_plan_record_begin(a) == 0 and L.zs3_plan_record_begin(a) == 0       # idempotent for the recording plan
+    assert L.zs3_plan_record_begin(b) == -2 and L.zs3_plan_record_end(b) == -2       # one plan records at a time
+    assert L.zs3_plan_replay(a, 0, -1) == -2                                         # not into itself
+    assert L.zs3_plan_record_end(a) == 0 and L.zs3_plan_size(a) == 0 and L.zs3_plan_replay(a, 0, -1) == 0
+    assert L.zs3_plan_find_op(a, b"zs3_sgd_multi_g", 0) == -1 and L.zs3_plan_failed_op(a) == -1
+    assert L.zs3_plan_patch(a, 0, 0, (ctypes.c_float * 1)(1.0), 4) == -1 and L.zs3_plan_set_ptr(a, 0, 0, None) == -1
+    assert L.zs3_plan_replace_u64(a, 1, 2) == 0 and L.zs3_plan_find_ptr(a, None, None, 0) == 0
+    assert L.zs3_plan_destroy(a) == 0 and L.zs3_plan_destroy(b) == 0 and L.zs3_plan_destroy(0) == -1
+    assert L.zs3_sgd_max_groups() == 8
+    # generated sources are current
+    rename_h, wrappers = (os.path.join(build.GEN, f) for f in ("plan_rename.h", "plan_wrappers.hip"))
+    before = [open(p).read() for p in (rename_h, wrappers)]
+    build.generate_plan_sources()
+    assert [open(p).read() for p in (rename_h, wrappers)] == before, "csrc/gen is stale: run python -m zs3_amd.build and commit"
+    launchers = [name for _, name, params in build.parse_header() if params and params[-1] == ("void*", "stream")]
+    renamed = re.findall(r"#define (zs3_\w+) \1__impl", before[0])
+    assert renamed == launchers and len(launchers) >= 60
+    for name in launchers:
+        assert f'extern "C" int {name}(' in before[1] and f"{name}__impl(" in before[1]
+    for name, arrays in build.HOST_ARRAYS.items():       # host arrays are copied into the plan, by name
+        assert name in launchers
+        for arg in arrays:
+            assert re.search(rf"blk_\.{arg}\[i\] = {arg}\[i\]", before[1]), (name, arg)
+    # the __impl definitions stay inside the library
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L._name], capture_output=True, text=True).stdout
+    assert "__impl" not in out

@@ -69,12 +69,14 @@ class BaseTrainer:
         return image, target
 
     def _train_iteration(self, image, target):
-        self.optimizer.zero_grad()
-        prediction = self.model(image)
-        loss = self.criterion(prediction, target)
-        loss.backward()
-        self.optimizer.step()
-        return prediction, loss
+        """zero_grad -> forward -> loss -> backward -> step (base_trainer.py:16-20), through zs3_amd.plan.StepPlan: with the fused
+        optimizer (zs3_amd.optim.SGD) on one GPU the third iteration of a batch shape is recorded and the later ones are replayed from
+        C, bit-identical to the eager lines; any other setting (torch.optim, several ranks, ZS3_PLAN=0) runs exactly those lines."""
+        plan = self.__dict__.get("_zs3_step_plan")
+        if plan is None or plan.model is not self.model or plan.optimizer is not self.optimizer or plan.criterion is not self.criterion:
+            from .plan import StepPlan
+            plan = self.__dict__["_zs3_step_plan"] = StepPlan(self.model, self.criterion, self.optimizer)
+        return plan(image, target)
 
     def _epoch_end(self, epoch, running, seen_images):
         self.writer.add_scalar("train/total_loss_epoch", running, epoch)

@@ -125,6 +125,7 @@ class StepPlan:
         self._plan = self._pool = self._key = self._hyper = None
         self._held = None            # tensors of the recorded step that live past it: prediction, loss, optimizer tables, ...
         self._seeds, self._inputs, self._input_at, self._sgd_ops = [], None, None, []
+        self._grads, self._grads_moved = [], False
         self._settled = 0
 
     def _plannable(self, image, target):
@@ -216,6 +217,8 @@ class StepPlan:
             plan.close()
             return prediction, loss      # (the step did not read its batch where the caller's tensors live: a copy was made; stay eager)
         self._held = (prediction, loss, moved, image, target)
+        self._grads = [(p, p.grad) for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+        self._grads_moved = False
         self._sgd_ops = sgd_ops
         self._hyper = bytes(self.optimizer.group_hyper())
         self.recordings += 1
@@ -223,6 +226,10 @@ class StepPlan:
 
     def _replay(self, image, target):
         plan = self._plan
+        if self._grads_moved:          # an eager step ran since the last replay and left its own gradient tensors on the parameters:
+            for p, g in self._grads:   # hand the plan's back (the tensors the replayed launches write)
+                p.grad = g
+            self._grads_moved = False
         for slot, t in enumerate((image, target)):
             ptr = t.data_ptr()
             if ptr != self._inputs[slot]:
@@ -245,9 +252,13 @@ class StepPlan:
         return self._held[0], self._held[1]
 
     # ------------------------------------------------------------------------------------------------ the call
-    def __call__(self, image, target):
-        if not self._plannable(image, target):
+    def __call__(self, image, target, eager=False):
+        """-> (prediction, loss).  eager=True: this one call runs the ordinary eager step whatever the state of the plan (an
+        instrumented step: per-launch timing events live in the Python wrappers); the plan stays valid -- it owns its buffers, and
+        parameters / optimizer state / BatchNorm buffers are shared, so eager and replayed steps interleave freely."""
+        if eager or not self._plannable(image, target):
             self.eager_calls += 1
+            self._grads_moved = True
             return self._eager(image, target)
         key = self._fingerprint(image, target)
         if key != self._key:
@@ -322,6 +333,10 @@ class StepPlan:
             del hold
         finally:
             torch._C._cuda_endAllocateToPool(idx, self._pool.id)
+
+    @property
+    def recorded_ops(self):
+        return self._plan.nops if self._plan is not None else 0
 
     def close(self):
         self._drop()
