@@ -51,3 +51,26 @@ w = time.perf_counter() - w0
 f, l, bw, o = (sum(x[i] for x in t) / n * 1e3 for i in range(4))
 print(f"host enqueue per step: forward {f:.2f} ms, loss {l:.2f}, backward {bw:.2f}, optimizer {o:.2f}  -> {h / n * 1e3:.2f} ms; "
       f"wall per step {w / n * 1e3:.2f} ms; final sync waited {(w - h) * 1e3:.2f} ms for the queue to drain")
+
+# ---- round 6: the same step as a recorded launch plan (zs3_amd/plan.py): host time of one replay call
+from zs3_amd.plan import StepPlan
+plan_step = StepPlan(model, crit, opt)
+for _ in range(5):
+    plan_step(image, label)
+torch.cuda.synchronize()
+assert plan_step.replays >= 2, (plan_step.eager_calls, plan_step.recordings, plan_step.replays)
+w0 = time.perf_counter()
+for _ in range(n):
+    plan_step(image, label)
+h = time.perf_counter() - w0
+torch.cuda.synchronize()
+w = time.perf_counter() - w0
+print(f"recorded plan ({plan_step.recorded_ops} launches): host enqueue per step {h / n * 1e3:.2f} ms; wall per step {w / n * 1e3:.2f} ms; "
+      f"final sync waited {(w - h) * 1e3:.2f} ms for the queue to drain")
+# how fast can the host issue the plan when the GPU is not the limit?  (the queue is empty at the start; 3 steps fit the queues)
+torch.cuda.synchronize()
+w0 = time.perf_counter()
+plan_step(image, label)
+h1 = time.perf_counter() - w0
+torch.cuda.synchronize()
+print(f"one replay into an empty queue: {h1 * 1e3:.2f} ms of host time")

@@ -80,6 +80,7 @@ def _wait_for(waiter, producer):
 # recording run's timing that no replay repeats -- but kept alive here until the end-of-backward join, after which the main stream
 # (where they were allocated) is ordered behind every side-stream reader.
 PLAN_RECORDING = False
+ASPP_CONCURRENT = True   # ASPP's branches on three streams in the eager step (modeling/aspp.py); never while a plan records
 _plan_keep = []
 PLAN_EPOCH = [0]     # bumped whenever buffers a plan may have recorded are dropped (weight planes, mode switches): plans re-record
 
@@ -108,6 +109,54 @@ def join_wgrad_stream():
         for st in pool:
             _wait_for(torch.cuda.current_stream(st.device), st)
 
+
+
+# ---------------------------------------------------------------------------------- lanes: independent layers side by side
+# ASPP's branches are independent and each launches fewer workgroups than the chip has CUs (138 tiles on 256 CUs at 33 x 33): run
+# side by side they are worth 3 ms of a 44 ms step (same-box A/B, round 6).  Through round 5 the module ran them under
+# `torch.cuda.stream(...)`: autograd then runs each branch's backward on the stream of its forward and orders the streams with
+# events of its own -- dependencies no recorded plan carries.  A LANE is the same overlap kept inside this library: a fused layer
+# whose cfg names a lane switches the current stream INSIDE its Function.forward / backward (after autograd has noted the node's
+# stream, before it looks again), the lane first waits for the main stream (its operand is ready there), and the main stream
+# waits for the lanes where the results meet: lanes_join() in the module's forward, _Fork.backward / the end-of-backward
+# callback in the backward pass.  Every dependency is a zs3_stream_wait call: recorded and replayed like a launch.
+# Allocator: tensors a layer allocates inside its lane belong to the lane's pool and are reused in the lane's own stream order;
+# what crosses (the branch input and output-gradient slices from main, the branch's input gradient to main) is ordered by the
+# fork wait at the lane's next entry and by the joins.
+_lanes = {}
+_lanes_open = {}          # device index -> lanes that have work the main stream has not waited for yet
+_lanes_armed = [False]
+
+
+def lane_streams(device, n=2):
+    key = device.index
+    if key not in _lanes or len(_lanes[key]) < n:
+        _lanes[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _lanes[key]
+
+
+def _enter_lane(lane):
+    main = _current_stream()
+    _wait_for(lane, main)
+    _set_stream(lane)
+    _lanes_open.setdefault(lane.device_index, set()).add(lane)
+    return main
+
+
+def lanes_join():
+    """the current (main) stream waits for every lane that has taken work since the last join"""
+    if not _lanes_open:
+        return
+    main = _current_stream()
+    for lane in _lanes_open.pop(main.device_index, ()):
+        _wait_for(main, lane)
+
+
+def _lanes_join_at_end_of_backward():
+    _lanes_armed[0] = False
+    for idx in list(_lanes_open):
+        for lane in _lanes_open.pop(idx, ()):
+            _wait_for(torch.cuda.current_stream(lane.device), lane)
 
 
 # ---------------------------------------------------------------------------------- weight-plane cache
@@ -223,6 +272,8 @@ def _reset_backward_state():
         join_wgrad_stream()
     if _wgrad_side_of:
         _wgrad_side_of.clear()
+    if _lanes_armed[0]:
+        _lanes_join_at_end_of_backward()
 
 
 def grad_buffer(param):
@@ -364,6 +415,37 @@ class _ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, bias, residual, cfg):
+        lane = cfg.get("lane")
+        if lane is None:
+            return _ConvBnAct._forward(ctx, x, weight, gamma, beta, bias, residual, cfg)
+        main = _enter_lane(lane)
+        try:
+            return _ConvBnAct._forward(ctx, x, weight, gamma, beta, bias, residual, cfg)
+        finally:
+            _set_stream(main)
+
+    @staticmethod
+    def backward(ctx, dA, dskip=None):
+        lane = ctx.cfg.get("lane")
+        if lane is None:
+            return _ConvBnAct._backward(ctx, dA, dskip)
+        main = _enter_lane(lane)
+        if not _lanes_armed[0]:     # whoever consumes this layer's gradients on the main stream -- _Fork.backward, else the optimizer
+            _lanes_armed[0] = True
+            torch.autograd.Variable._execution_engine.queue_callback(_lanes_join_at_end_of_backward)
+        ctx.outer_stream = main      # where autograd runs the consumers of this node's results inside this pass (AccumulateGrad)
+        # parameter gradients that are READ inside this pass (added into an existing .grad by a second backward before the optimizer
+        # step, or flowing on through a non-leaf parameter): autograd does that on the main stream right behind this node
+        read_now = any(t is not None and t.requires_grad and (not t.is_leaf or t.grad is not None) for t in ctx.saved_tensors[1:3])
+        try:
+            return _ConvBnAct._backward(ctx, dA, dskip)
+        finally:
+            _set_stream(main)
+            if read_now:
+                _wait_for(main, lane)
+
+    @staticmethod
+    def _forward(ctx, x, weight, gamma, beta, bias, residual, cfg):
         require_gpu(x, weight)
         x = _dense_rows(x)
         need_grad = cfg.get("need_grad", True)  # grad mode is always off inside Function.forward: decided by the caller
@@ -452,7 +534,7 @@ class _ConvBnAct(torch.autograd.Function):
         return a
 
     @staticmethod
-    def backward(ctx, dA, dskip=None):
+    def _backward(ctx, dA, dskip=None):
         x, weight, gamma, y, a, st, mbits = ctx.saved_tensors
         cfg = ctx.cfg
         msc, msh = (st[2], st[3]) if ctx.mask_from_y else (None, None)
@@ -584,20 +666,21 @@ class _ConvBnAct(torch.autograd.Function):
                                           out=_bucket_out(weight, wp), x_affine=ctx.x_affine)
                 finally:
                     _set_stream(main)
-                dw.record_stream(main)          # (allocated on the side stream, read on main by the optimizer)
+                outer = getattr(ctx, "outer_stream", None) or main    # (a layer on a lane: `main` is the lane, autograd's stream is outer)
+                dw.record_stream(outer)         # (allocated on the side stream, read on the main stream by the optimizer)
                 first_side = _wgrad_side_of.get(id(weight))
                 if first_side is not None:
                     # a weight used by two layers: autograd ADDS this contribution to the first one on the main stream as soon as
                     # both exist -- before the end-of-backward join -- so the main stream has to see both launches finished
-                    _wait_for(main, first_side)
-                    _wait_for(main, side)
+                    _wait_for(outer, first_side)
+                    _wait_for(outer, side)
                 else:
                     _wgrad_side_of[id(weight)] = side
                 if not (weight.is_leaf and weight.grad is None):
                     # the gradient is READ inside this backward pass -- accumulated into an existing .grad (a second
                     # backward before the optimizer step) or propagated through a non-leaf weight (a transposed /
                     # computed operand) -- so the main stream cannot wait for the end-of-backward join
-                    _wait_for(main, side)
+                    _wait_for(outer, side)
                 if not _join_armed[0]:
                     _join_armed[0] = True
                     torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
@@ -690,7 +773,7 @@ def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
 
 def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
                 leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False, dropout=None,
-                next_conv=None, out_dtype=None):
+                next_conv=None, out_dtype=None, lane=None):
     """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None.
     input_has_one_consumer: promise that `x` feeds nothing but this layer (and, with pass_through, the skip tensor this
     layer hands back), which lets this layer's dgrad produce the BN-backward sums of the layer that made `x` (BnLink).
@@ -700,7 +783,7 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
     # dropout: (p, training) of an nn.Dropout that follows this layer's activation.  conv + BN + ReLU layers without a residual
     # (every dropout of the network sits behind one: aspp.py:100, decoder.py:19,23) take it into the BN-apply pass and its
     # backward (same mask as the stand-alone kernel, same position in the seed stream); anything else gets the separate pass.
-    if _handed_armed[0] or _join_armed[0]:
+    if _handed_armed[0] or _join_armed[0] or _lanes_armed[0]:
         _reset_backward_state()
     drop, drop_after = None, None
     if dropout is not None and dropout[1] and dropout[0] > 0.0:
@@ -711,7 +794,7 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
         else:
             drop_after = (float(dropout[0]), None)
     cfg = {"stride": stride, "pad": pad, "dil": dil, "act": act, "out": out, "leak": leak, "prec": prec, "geom": geom,
-           "out_dtype": out_dtype,
+           "out_dtype": out_dtype, "lane": lane,    # lane: a side stream this layer runs on, forward and backward (see lane_streams)
            "drop": drop,
            "wgrad": wgrad, "pass_through": pass_through,
            "in_link": getattr(x, "_zs3_bn_link", None) if (input_has_one_consumer and FUSE_BN_BWD_STATS) else None,
@@ -939,6 +1022,7 @@ class _Fork(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        lanes_join()      # consumers that ran on lanes (ASPP's branches): their gradients meet here, on the main stream
         gs = [g for g in grads if g is not None]
         if not gs:
             return None, None

@@ -27,8 +27,8 @@ class _ASPPModule(nn.Module):
         self.relu = nn.ReLU()
         self._init_weight()
 
-    def forward_nhwc(self, x, out=None):
-        return self.atrous_conv.forward_nhwc(x, self.bn, act=Fz.ACT_RELU, out=out)
+    def forward_nhwc(self, x, out=None, lane=None):
+        return self.atrous_conv.forward_nhwc(x, self.bn, act=Fz.ACT_RELU, out=out, lane=lane)
 
     def forward(self, x):
         return ops.nchw(self.forward_nhwc(ops.nhwc(x)))
@@ -60,17 +60,10 @@ class ASPP(nn.Module):
         self._init_weight()
         to_channels_last_(self)
 
-    # The five branches are independent and, at output stride 16, each of them launches fewer workgroups than the
-    # chip has CUs (33x33 maps): they run on three HIP streams and write into disjoint channel slices of one buffer.
-    # autograd replays each node's backward on the stream of its forward, so the backward overlaps the same way.
-    _streams = {}
-
-    def _branch_streams(self, device):
-        key = device.index
-        if key not in ASPP._streams:
-            ASPP._streams[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-        return ASPP._streams[key]
-
+    # The five branches are independent and, at output stride 16, each of them launches fewer workgroups than the chip has CUs
+    # (33x33 maps): the two heaviest atrous branches run on LANES (functional.lane_streams: side streams entered inside the fused
+    # layer, forward and backward, with recorded waits) next to the others on the main stream, all writing into disjoint channel
+    # slices of one buffer.  Worth 3 ms of the 44 ms step (same-box A/B, round 6: 44.1 against 47.1 ms).
     def forward_nhwc(self, x):
         n, h, w, _ = x.shape
         cat = torch.empty((n, h, w, 1280), dtype=ops.ACT_DTYPE, device=x.device)
@@ -78,35 +71,23 @@ class ASPP(nn.Module):
 
         xs = Fz.fork(x, 5)    # five consumers: their gradients are added in one launch, not pairwise
 
-        def branch(i):
+        def branch(i, lane=None):
             br = (self.aspp1, self.aspp2, self.aspp3, self.aspp4)[i]
-            return br.forward_nhwc(xs[i], out=cat[..., 256 * i:256 * (i + 1)])
+            return br.forward_nhwc(xs[i], out=cat[..., 256 * i:256 * (i + 1)], lane=lane)
 
         def pooled():
             p = self.global_avg_pool[1].forward_nhwc(Fz.global_avg_pool(xs[4]), bn, act=Fz.ACT_RELU)   # [N,1,1,256]
             return Fz.broadcast_to(p, (h, w), out=cat[..., 1024:1280])
 
-        # (not while a plan records: autograd runs a node's backward on the stream of its forward and orders the streams with events
-        # of its own, which no recorded plan would carry -- zs3_amd/plan.py; the recorded step keeps every node on one stream)
-        concurrent = x.is_cuda and not Fz.PLAN_RECORDING and (
-            Fz.CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())
-        if not concurrent:
-            parts = [branch(0), branch(1), branch(2), branch(3), pooled()]
-        else:
-            main = torch.cuda.current_stream()
-            s1, s2 = self._branch_streams(x.device)
-            s1.wait_stream(main)
-            s2.wait_stream(main)
-            parts = [None] * 5
-            parts[1] = branch(1)
-            parts[0] = branch(0)
-            with torch.cuda.stream(s1):
-                parts[2] = branch(2)
-            with torch.cuda.stream(s2):
-                parts[3] = branch(3)
-                parts[4] = pooled()
-            main.wait_stream(s1)
-            main.wait_stream(s2)
+        concurrent = x.is_cuda and Fz.ASPP_CONCURRENT and (Fz.CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())
+        l1, l2 = Fz.lane_streams(x.device, 2) if concurrent else (None, None)
+        parts = [None] * 5
+        parts[2] = branch(2, l1)
+        parts[3] = branch(3, l2)
+        parts[1] = branch(1)
+        parts[0] = branch(0)
+        parts[4] = pooled()
+        Fz.lanes_join()       # the projection below reads all five slices on the main stream
         return self.conv1.forward_nhwc(Fz.cat_slices(cat, parts), self.bn1, act=Fz.ACT_RELU, dropout=self.dropout)
 
     def forward(self, x):
