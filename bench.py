@@ -393,7 +393,8 @@ def main():
             bprof = bwarm = None
         gflop_img = TRAIN_GFLOP_PER_IMG.get(args.classes, 555.7)
         sync = getattr(model, "_zs3_grad_sync", None)      # armed by the model's first training forward when world > 1
-        sync_bytes = sync.bytes_reduced if sync is not None else None
+        # (per step: the buckets' own size -- replayed steps do not pass through the Python counter)
+        sync_bytes = sum(f.numel() * f.element_size() for f in sync.flat) * max(1, args.steps + args.warmup) if sync is not None else None
         if args.gmmn_steps > 0 and world == 1:
             from zs3_amd.parallel import disarm_data_parallel
             disarm_data_parallel(model)   # (--ddp-selftest: the GMMN step exchanges pred_conv's gradients itself)

@@ -410,6 +410,35 @@ int zs3_cluster_graph(const int* seg, int H, int W, int* cmap, int* seed, int* l
 int zs3_cluster_graph_batch(const int* seg, int B, int H, int W, int* cmap, int* seed, int* labels, int* ncluster, float* adj,
                             int cap, void* stream);
 
+/* ---- collectives: RCCL under the C ABI (round 6) -------------------------------------------------------------------------- */
+/* The reference's multi-GPU exchanges (nn.DataParallel's replicate / gather and the vendored SyncBN's
+ * master-slave reduction, sync_batchnorm/batchnorm.py:101-122, comm.py:98-126) as one-process-per-GPU collectives issued BY THIS
+ * LIBRARY on the stream the caller names: the SyncBN sums on the compute stream itself (pack -> all-reduce -> finalize in stream
+ * order: no hand-over to a framework's collective stream, 208 times per step), the gradient buckets on the weight-gradient side
+ * stream.  RCCL is bound at run time: zs3_comm_load(path of the librccl the process uses; NULL / "" = "librccl.so.1").
+ * Communicator set-up: rank 0 calls zs3_comm_unique_id (zs3_comm_unique_id_bytes() bytes, HOST memory), the bytes reach the other
+ * ranks by any means (zs3_amd/parallel.py: torch.distributed's store), every rank calls zs3_comm_create(id, nranks, rank) -> handle
+ * (0 = failure).  zs3_allreduce / zs3_broadcast work IN PLACE on `count` elements of dtype 0 fp32 / 1 fp64 / 2 int32 / 3 int64; op 0 =
+ * SUM, 1 = MAX.  Return codes: 0, < 0 argument / state error, 1000 + ncclResult_t for RCCL's own errors (message on stderr).
+ * All ranks must issue the collectives of one communicator in the same order; use one communicator per stream that issues them.
+ * Being entry points with a trailing stream, collectives are recorded and replayed by launch plans like kernel launches. */
+int zs3_comm_load(const char* librccl_path);
+int zs3_comm_unique_id_bytes(void);
+int zs3_comm_unique_id(void* id_out);
+long zs3_comm_create(const void* unique_id, int nranks, int rank);
+int zs3_comm_destroy(long comm);
+int zs3_comm_ranks(long comm);
+/* (a communicator of ONE rank: both collectives return without enqueuing anything -- in place they are the identity) */
+int zs3_allreduce(long comm, void* buf, long count, int dtype, int op, void* stream);
+int zs3_broadcast(long comm, void* buf, long count, int dtype, int root, void* stream);
+/* zs3_bn_sync_pack + the SUM all-reduce of its 2C + 1 doubles in one call (batchnorm.py:101-122: the replicas' sum / sum of
+ * squares / element count reduced on the master and broadcast back); zs3_bn_*_finalize(chunks = -1) read `totals` afterwards. */
+int zs3_bn_sync_exchange(long comm, const float* partial, int chunks, int C, double count, double* totals, void* stream);
+/* global normalisation of the CE behind the all-reduce of loss_ws[1..2] (utils/loss.py: the loss of the gathered batch that
+ * nn.DataParallel hands the reference's criterion, loss.py:33-46): loss_ws[0] = loss_ws[2] / loss_ws[1] / global_batch
+ * (global_batch <= 0: no batch averaging). */
+int zs3_ce_global_finish(float* loss_ws, int global_batch, void* stream);
+
 /* ---- recorded launch plans: the step loop under the C ABI (round 6) ------------------------------------------------------- */
 /* The loop body of base_trainer.py:16-20 (zero_grad / forward / loss / backward / step) is ~1000 calls of the entry points above
  * per iteration, identical from iteration to iteration up to a few scalars.  A PLAN records them once and replays them from C:

@@ -75,8 +75,22 @@ def _step(dev, ddp):
 
 
 def test_one_rank_rccl_step_equals_plain_step(dev, one_rank_group):
+    import zs3_amd.parallel as par
     l0, s0 = _step(dev, ddp=False)
+    assert par.native_available() and not par._native_comms
     l1, s1 = _step(dev, ddp=True)
+    # round 6: the collectives were issued by libzs3hip.so itself (csrc/comm.hip), one communicator per issuing stream -- the main
+    # stream (SyncBN, CE, range flag), the two ASPP lanes (their SyncBN layers) and the weight-gradient stream (the buckets)
+    assert len(par._native_comms) == 4, par._native_comms
+    par.NATIVE_RCCL = False          # the same step with every collective through torch.distributed (the round-5 path)
+    try:
+        l2, s2 = _step(dev, ddp=True)
+    finally:
+        par.NATIVE_RCCL = True
+    assert max(abs(a - b) for a, b in zip(l1, l2)) < 1e-6 * abs(l1[0]), (l1, l2)
+    for k in s1:
+        if s1[k].dtype.is_floating_point:
+            assert (s1[k] - s2[k]).abs().max().item() <= 1e-6 * max(1.0, s1[k].abs().max().item()), k
     # one rank: every collective is the identity; the SyncBN path only re-associates fp64 sums
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 1e-5, (l0, l1)
     for k in s0:
@@ -84,6 +98,54 @@ def test_one_rank_rccl_step_equals_plain_step(dev, one_rank_group):
             err = (s0[k] - s1[k]).abs().max().item()
             # (the plain run sums the BN-backward statistics in the dgrad epilogues, the SyncBN run in a separate pass)
             assert err <= 1e-5 + 1e-4 * s0[k].abs().max().item(), (k, err)
+
+
+def test_one_rank_rccl_step_replays_from_a_plan(dev, one_rank_group):
+    """The N > 1 code path as a recorded plan: with the library's own collectives (zs3_allreduce, zs3_bn_sync_exchange) the SyncBN /
+    GradSync / global-CE step records and replays like the plain one -- bit-identical to its eager self, collectives included in
+    the recorded ops."""
+    import zs3_amd.parallel as par
+    from zs3_amd import functional as Fz
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.optim import SGD
+    from zs3_amd.plan import StepPlan
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.synthetic import make_batch
+    par.FORCE_COLLECTIVES = True
+    try:
+        outs = []
+        for use_plan in (False, True):
+            torch.manual_seed(1)
+            m = DeepLab(num_classes=21, pretrained=False, sync_bn=True)
+            for name, mod in m.named_modules():
+                if name.endswith("bn3"):
+                    mod.weight.data.fill_(0.1)
+            m = m.to(dev).train()
+            groups = [{"params": m.get_1x_lr_params(), "lr": 1e-3}, {"params": m.get_10x_lr_params(), "lr": 1e-2}]
+            opt = SGD(groups, momentum=0.9, weight_decay=5e-4)
+            crit = SegmentationLosses(cuda=True).build_loss("ce")       # group="auto": global under FORCE_COLLECTIVES
+            Fz.manual_seed(5)
+            step = StepPlan(m, crit, opt, enabled=use_plan)
+            losses = []
+            for i in range(6):
+                b = make_batch(2, 97, seed=70 + i, device=dev)
+                losses.append(step(b["image"], b["label"])[1].detach().clone())
+            torch.cuda.synchronize()
+            sync = getattr(m, "_zs3_grad_sync", None)
+            assert sync is not None                                      # armed by the model's first training forward
+            assert all(sync._in_place(p) for p in sync.params if p.grad is not None)    # every gradient lives in its bucket: no pack copies
+            names = step._plan.names() if step._plan is not None else []
+            outs.append((torch.stack(losses).cpu(), {k: v.detach().clone() for k, v in m.state_dict().items()},
+                         (step.eager_calls, step.recordings, step.replays), names))
+            par.disarm_data_parallel(m)
+            step.close()
+        (le, se, ce, _), (lp, sp, cp, names) = outs
+        assert ce == (6, 0, 0) and cp == (2, 1, 3), (ce, cp)
+        assert torch.equal(le, lp), (le, lp)
+        assert not [k for k in se if not torch.equal(se[k], sp[k])]
+        assert names.count("zs3_bn_sync_exchange") == 2 * 113 and names.count("zs3_allreduce") >= 3     # buckets + CE + range flag
+    finally:
+        par.FORCE_COLLECTIVES = False
 
 
 def _gmmn_steps(dev, ddp):

@@ -17,7 +17,15 @@ def main():
     ap.add_argument("--size", type=int, default=513)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="fp32")
+    ap.add_argument("--ddp", action="store_true", help="the N > 1 code path with a one-rank RCCL group (SyncBN, GradSync, global CE)")
     args = ap.parse_args()
+    if args.ddp:
+        import torch.distributed as dist
+        import zs3_amd.parallel as par
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        par.FORCE_COLLECTIVES = True
     from zs3_amd import functional as Fz
     from zs3_amd import ops
     from zs3_amd.modeling.deeplab import DeepLab
@@ -29,7 +37,7 @@ def main():
     if args.dtype == "bf16":
         ops.set_storage(torch.bfloat16)
     torch.manual_seed(1)
-    model = DeepLab(num_classes=21, pretrained=False, sync_bn=False).to(dev).train()
+    model = DeepLab(num_classes=21, pretrained=False, sync_bn=args.ddp).to(dev).train()
     groups = [{"params": model.get_1x_lr_params(), "lr": 0.007}, {"params": model.get_10x_lr_params(), "lr": 0.07}]
     opt = SGD(groups, momentum=0.9, weight_decay=5e-4)
     crit = SegmentationLosses(cuda=True).build_loss("ce")
@@ -39,7 +47,7 @@ def main():
         step(b["image"], b["label"])
     torch.cuda.synchronize()
     Fz.PLAN_RECORDING = True        # the step as a recording sees it (ASPP on one stream, keep-alive instead of record_stream)
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step(b["image"], b["label"])
         torch.cuda.synchronize()
     Fz.PLAN_RECORDING = False
@@ -61,6 +69,14 @@ def main():
     print(f"{total} device activities in one step; not from libzs3hip.so:")
     for name, (n, us) in sorted(foreign.items(), key=lambda kv: -kv[1][0]):
         print(f"  {n:5d} x  {us:9.1f} us  {name[:150]}")
+    # call sites of the fills / copies (python stacks of the launching operators)
+    sites = {}
+    for ev in prof.events():
+        if ev.device_type == torch.autograd.DeviceType.CPU and ev.name in ("aten::zero_", "aten::fill_", "aten::copy_", "aten::_foreach_copy_", "aten::clone", "aten::zeros") and ev.stack:
+            key = (ev.name, tuple(f for f in ev.stack if "zs3_amd" in f or "bench" in f)[:3])
+            sites[key] = sites.get(key, 0) + 1
+    for (name, stack), n in sorted(sites.items(), key=lambda kv: -kv[1])[:12]:
+        print(f"  {n:5d} x {name}  <- {' <- '.join(stack)}")
     # who launched them: CPU-side operators that have such a kernel as a child
     print("launching operators (aten::*) with device time:")
     for ev in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:60]:

@@ -413,6 +413,16 @@ extern "C" int zs3_ce_fwd(const float* logits, int ld, const void* target, int t
 }
 extern "C" int zs3_ce_ws_doubles(void) { return 2 * 1024; }
 
+// behind the cross-rank SUM of loss_ws[1..2] (sum of weights, sum of weight * nll): the loss of the gathered batch
+__global__ void ce_global_finish_kernel(float* loss_ws, float inv_batch) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) loss_ws[0] = loss_ws[2] / loss_ws[1] * inv_batch;
+}
+extern "C" int zs3_ce_global_finish(float* loss_ws, int global_batch, void* stream) {
+  hipLaunchKernelGGL(ce_global_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_ws,
+                     global_batch > 0 ? 1.f / (float)global_batch : 1.f);
+  return ZS3_LAUNCH_CHECK();
+}
+
 extern "C" int zs3_ce_bwd(const float* logits, int ld, const void* target, int target_is_i64, const float* weight,
                           long P, int C, int ignore_index, int batch, const float* loss_ws, const float* gout,
                           float* dlogits, int ldo, void* stream) {

@@ -523,7 +523,10 @@ class _ConvBnAct(torch.autograd.Function):
             cfg["deferred"] = (st[2], st[3])
         ctx.pass_through = bool(cfg.get("pass_through"))
         link = cfg.get("out_link")
-        if link is not None and ctx.bn_training and need_grad and act in (ACT_NONE, ACT_RELU) and bn.get("sync") is None:
+        # (also under SyncBN since round 6: the consumer's epilogue sums dz, dz * xhat of THIS rank's rows with the global mean / invstd
+        # this layer's finalize produced; the backward all-reduces them like the sums of the separate pass -- 113 full reads of the
+        # gradient per step that the N > 1 path used to make and the one-GPU path did not)
+        if link is not None and ctx.bn_training and need_grad and act in (ACT_NONE, ACT_RELU):
             link.y, link.mean, link.istd, link.mbits = y, st[0], st[1], mbits
             if ctx.mask_from_y:
                 link.msc, link.msh = st[2], st[3]
@@ -558,14 +561,18 @@ class _ConvBnAct(torch.autograd.Function):
             if link is not None:
                 link.partial = link.y = link.mbits = None
             sync = (cfg.get("bn") or {}).get("sync") if ctx.bn_training else None
+            # dgamma / dbeta straight into the parameters' slices of the data-parallel gradient bucket, when there is one (GradSync):
+            # the all-reduce then needs no pack / unpack copies for the 226 BatchNorm vectors either
+            gout = (grad_buffer(gamma), grad_buffer(cfg.get("bn_beta"))) if gamma is not None and cfg.get("bn_beta") is not None \
+                else (None, None)
             if sync is not None:
                 from .parallel import combine_bn_partials
                 gpart, gcount = combine_bn_partials(part, m, None if sync is True else sync)
-                fin_l = ops.bn_bwd_finalize(part, m, False)       # per-rank dgamma / dbeta (summed later by GradSync)
+                fin_l = ops.bn_bwd_finalize(part, m, False, out=gout)       # per-rank dgamma / dbeta (summed later by GradSync)
                 fin_g = ops.bn_bwd_finalize(gpart, gcount, True)  # c1, c2 from the global sums and count
                 dgamma, dbeta, c1, c2 = fin_l[0], fin_l[1], fin_g[2], fin_g[3]
             else:
-                fin = ops.bn_bwd_finalize(part, m, ctx.bn_training)
+                fin = ops.bn_bwd_finalize(part, m, ctx.bn_training, out=gout)
                 dgamma, dbeta = fin[0], fin[1]
                 c1, c2 = (fin[2], fin[3]) if ctx.bn_training else (None, None)
             dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, dres=dres, act=act, leak=leak, mask_scale=msc,
@@ -593,11 +600,12 @@ class _ConvBnAct(torch.autograd.Function):
             if want_bias:
                 # column sums in two launches of the library: per-chunk partial sums, then the chunks (rows of [chunks][2][C], every
                 # second one) added in order -- no tensor-library reduction on the path (a recorded plan replays both)
+                bout = grad_buffer(cfg.get("bias_param")) if cfg.get("bias_param") is not None else None
                 if vec_ok:
-                    dbias = _sum_partials(ops.colstats(dz))
+                    dbias = _sum_partials(ops.colstats(dz), cout, bout)
                 else:  # odd channel count (21 classes): reduce the zero-padded 8-aligned copy with the HIP kernel
                     full = dy.as_strided(dy.shape[:-1] + (ops._rows(dy)[2],), dy.stride(), dy.storage_offset())
-                    dbias = _sum_partials(ops.colstats(full))[:cout]
+                    dbias = _sum_partials(ops.colstats(full), cout, bout)
         dx = dw = None
         lazy_bits = None
         if dskip is not None:
@@ -696,11 +704,13 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, dbias, dres, None
 
 
-def _sum_partials(part):
-    """[chunks][2][C] partial column sums -> [C] totals of the first plane (zs3_colsum over rows of stride 2C)"""
+def _sum_partials(part, ncols=None, out=None):
+    """[chunks][2][C] partial column sums -> totals of the first `ncols` columns of the first plane (zs3_colsum over rows of stride
+    2C), into `out` (a gradient-bucket slice) when given"""
     chunks, _, c = part.shape
-    out = torch.empty(c, dtype=torch.float32, device=part.device)
-    ops.check(ops.lib().zs3_colsum(ops.P(part), ops.I(2 * c), ops.I(chunks), ops.I(c), ops.P(out), ops.stream()), "zs3_colsum")
+    ncols = ncols or c
+    out = out.view(ncols) if out is not None and out.numel() == ncols else torch.empty(ncols, dtype=torch.float32, device=part.device)
+    ops.check(ops.lib().zs3_colsum(ops.P(part), ops.I(2 * c), ops.I(chunks), ops.I(ncols), ops.P(out), ops.stream()), "zs3_colsum")
     return out
 
 
@@ -807,9 +817,11 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
         if geom is not None or not input_has_one_consumer:
             raise RuntimeError("a deferred BatchNorm output reached a layer that does not apply it")
         cfg["in_affine"] = x_defer
+    cfg["bias_param"] = bias
     gamma = beta = None
     if bn is not None:
         gamma, beta = bn.weight, bn.bias
+        cfg["bn_beta"] = beta
         use_batch = bn.training or bn.running_mean is None
         cfg["defer_out"] = bool(
             DEFER_BN_APPLY and next_conv is not None and use_batch and act == ACT_RELU and residual is None and out is None and
@@ -872,7 +884,7 @@ class _BnAct(torch.autograd.Function):
         dA = _dense_rows(dA)
         m = y.numel() // y.shape[-1]
         part = ops.bn_bwd_stats(dA, a, y, st[0], st[1])
-        fin = ops.bn_bwd_finalize(part, m, cfg["training"])
+        fin = ops.bn_bwd_finalize(part, m, cfg["training"], out=(grad_buffer(gamma), grad_buffer(cfg.get("beta_param"))))
         c1, c2 = (fin[2], fin[3]) if cfg["training"] else (None, None)
         if cfg["training"] and cfg.get("sync") is not None:
             from .parallel import combine_bn_partials   # dgamma / dbeta stay per rank (summed by GradSync); c1, c2 are global
@@ -897,7 +909,7 @@ def bn_act(y, bn, act=ACT_NONE, out=None):
     cfg = {"training": use_batch, "nbt": nbt, "eps": bn.eps, "momentum": mom if mom is not None else 0.0, "act": act, "out": out,
            "sync": getattr(bn, "_zs3_sync_group", None) if use_batch else None,
            "running_mean": bn.running_mean if track or not use_batch else None,
-           "running_var": bn.running_var if track or not use_batch else None}
+           "running_var": bn.running_var if track or not use_batch else None, "beta_param": bn.bias}
     return _BnAct.apply(y, bn.weight, bn.bias, cfg)
 
 

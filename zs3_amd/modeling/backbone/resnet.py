@@ -139,6 +139,7 @@ class _StemWeight(torch.autograd.Function):
         out = torch.empty((co, kh, 1, 32), dtype=torch.float32, device=weight.device)
         check(lib().zs3_repack_pad(P(wl), co * kh, I(kw), I(ci), P(out), I(8), I(4), I(0), stream()), "zs3_repack_pad")
         ctx.geom = (co, ci, kh, kw)
+        ctx.param = weight if isinstance(weight, torch.nn.Parameter) else None
         return out.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -146,7 +147,9 @@ class _StemWeight(torch.autograd.Function):
         from ..._lib import I, P, check, lib, stream
         co, ci, kh, kw = ctx.geom
         d = dw.permute(0, 2, 3, 1).contiguous()                         # [64, 7, 1, 32]
-        out = torch.empty((co, kh, kw, ci), dtype=torch.float32, device=dw.device)
+        buf = Fz.grad_buffer(ctx.param) if ctx.param is not None and ctx.param.is_contiguous(memory_format=torch.channels_last) else None
+        out = buf.view(co, kh, kw, ci) if buf is not None and buf.numel() == co * kh * kw * ci else \
+            torch.empty((co, kh, kw, ci), dtype=torch.float32, device=dw.device)      # (the data-parallel bucket's slice, when there is one)
         check(lib().zs3_repack_pad(P(d), co * kh, I(kw), I(ci), P(out), I(8), I(4), I(1), stream()), "zs3_repack_pad")
         return out.permute(0, 3, 1, 2)                                  # logical OIHW, channels_last memory like the parameter
 

@@ -687,13 +687,16 @@ def bn_bwd_stats(dA, a_out, y, mean, invstd, mask_scale=None, mask_shift=None, m
     return part
 
 
-def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True):
+def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True, out=None):
     """-> (dgamma, dbeta, c1, c2).  dgamma / dbeta own their storage so that autograd can adopt them as .grad
-    without a copy."""
+    without a copy; out = (dgamma buffer or None, dbeta buffer or None): gradient-bucket slices to write them into."""
     partial, chunks, c, chost, cdev = _partial_args(partial, count)
     dev = partial.device
-    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    og, ob = out if out is not None else (None, None)
+    # (a FRESH view of the slice: autograd adopts a gradient as .grad without a copy only when nobody else holds that tensor object,
+    # and the registered slice itself stays in functional._grad_buffers)
+    dgamma = og.view(c) if og is not None and og.numel() == c and og.dtype == torch.float32 else torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = ob.view(c) if ob is not None and ob.numel() == c and ob.dtype == torch.float32 else torch.empty(c, dtype=torch.float32, device=dev)
     cc = torch.empty((2, c), dtype=torch.float32, device=dev)
     base = cc.data_ptr()
     check(lib().zs3_bn_bwd_finalize(P(partial), I(chunks), I(c), chost, cdev, P(dgamma), P(dbeta),

@@ -16,6 +16,85 @@ import torch.distributed as dist
 # single-GPU plumbing tests set this to run the SyncBN reduction path with one rank
 FORCE_COLLECTIVES = False
 
+# ---------------------------------------------------------------------------------- RCCL under the C ABI (round 6)
+# With the "nccl" (= RCCL) backend the data-path collectives of the step -- SyncBN sums, gradient buckets, the CE's weight sums, the
+# range flag -- are issued by libzs3hip.so itself (csrc/comm.hip: zs3_allreduce / zs3_bn_sync_exchange) ON THE STREAM THAT HOLDS THE
+# DATA: the SyncBN exchange is pack -> all-reduce -> finalize in the compute stream's own order (torch.distributed hands every
+# collective to RCCL's stream and back through two events: ~10 us of bubble on the dependent chain, 208 times per step), and every
+# collective is an entry point a launch plan records.  One communicator per issuing stream (a communicator's operations must not
+# run concurrently with each other: the main stream, the two ASPP lanes and the weight-gradient stream each get their own), created
+# collectively at first use -- every rank reaches the same call sites in the same order.  torch.distributed keeps rendezvous, the
+# one-time parameter broadcast and the gloo / CPU paths.  ZS3_NATIVE_RCCL=0: everything through torch.distributed as in round 5.
+import os as _os
+
+NATIVE_RCCL = _os.environ.get("ZS3_NATIVE_RCCL", "1") == "1"
+_native_comms = {}
+_native_loaded = [None]
+
+
+_native_backend = {}      # id(process group) -> is its backend RCCL?  (asked ~430 times per step: dist.get_backend costs 20 us)
+
+
+def native_available(group=None):
+    """can the library issue this group's collectives itself?  (RCCL backend, library loadable)"""
+    if not (NATIVE_RCCL and dist.is_initialized()):
+        return False
+    pg = None if group is True else group
+    key = (id(pg), id(dist.group.WORLD))      # (a destroyed and re-created default group is another object)
+    hit = _native_backend.get(key)
+    if hit is None:
+        try:
+            hit = torch.cuda.is_available() and "nccl" in str(dist.get_backend(pg))
+        except Exception:
+            hit = False
+        _native_backend.clear()
+        _native_backend[key] = hit
+    if not hit:
+        return False
+    if _native_loaded[0] is None:
+        from ._lib import lib
+        path = _os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so")
+        _native_loaded[0] = lib().zs3_comm_load(path.encode() if _os.path.exists(path) else b"") == 0
+    return _native_loaded[0]
+
+
+def native_comm(stream_handle, group=None):
+    """The library's communicator for collectives issued on the HIP stream `stream_handle` over the ranks of `group` (default:
+    all), created on first use: rank 0 of the group draws the RCCL unique id, torch.distributed carries its 128 bytes to the
+    others, every rank calls zs3_comm_create.  COLLECTIVE at first use per (stream, group)."""
+    import ctypes
+    pg = None if group is True else group
+    key = (int(stream_handle or 0), id(pg) if pg is not None else 0)
+    comm = _native_comms.get(key)
+    if comm is None:
+        from ._lib import lib
+        n = lib().zs3_comm_unique_id_bytes()
+        buf = ctypes.create_string_buffer(n)
+        rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+        if rank == 0 and lib().zs3_comm_unique_id(buf) != 0:
+            raise RuntimeError("zs3_comm_unique_id failed")
+        box = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg)
+        comm = int(lib().zs3_comm_create(box[0], world, rank))
+        if not comm:
+            raise RuntimeError("zs3_comm_create failed (RCCL's message is on stderr)")
+        _native_comms[key] = comm
+    return comm
+
+
+def native_allreduce(t, op="sum", group=None):
+    """in-place all-reduce of a dense device tensor on the CURRENT stream through the library; False when not applicable"""
+    if not (t.is_cuda and native_available(group)):
+        return False
+    from ._lib import check, lib, stream
+    code = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}.get(t.dtype)
+    if code is None or not t.is_contiguous():
+        return False
+    st = stream()
+    check(lib().zs3_allreduce(native_comm(st, group), t.data_ptr(), t.numel(), code, 0 if op == "sum" else 1, st), "zs3_allreduce")
+    return True
+
 AUTO = "auto"
 
 
@@ -118,9 +197,9 @@ class GradSync:
         if Fz.WGRAD_SIDE_STREAM:
             pool = Fz.wgrad_streams(p.device)
             side = pool[0]
-            side.wait_stream(torch.cuda.current_stream(p.device))   # gradients produced on the main stream (BN, bias)
-            for other in pool[1:]:                                  # ... and on the other streams of the wgrad pool
-                side.wait_stream(other)
+            Fz._wait_for(side, torch.cuda.current_stream(p.device))   # gradients produced on the main stream (BN, bias)
+            for other in pool[1:]:                                    # ... and on the other streams of the wgrad pool
+                Fz._wait_for(side, other)
             return side
         return None
 
@@ -154,7 +233,10 @@ class GradSync:
         have = [p for p in self.buckets[bi] if p in self._ready[bi] and p.grad is not None and not self._in_place(p)]
         if have:
             torch._foreach_copy_(self._views(bi, have), [_as_flat(p.grad, p) for p in have])
-        self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if native_allreduce(self.flat[bi], "sum", self.group):      # issued by the library on this (weight-gradient) stream
+            self._works[bi] = _NativeWork(torch.cuda.current_stream(self.flat[bi].device))
+        else:
+            self._works[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.bytes_reduced += self.flat[bi].numel() * 4
 
     def finish(self):
@@ -209,8 +291,21 @@ def exchange_range_flag(device, group=None):
     from . import ops
     if not ops.fwd_f16() or not dist.is_initialized():
         return False
-    dist.all_reduce(ops.range_flag(device), op=dist.ReduceOp.MAX, group=group)
+    flag = ops.range_flag(device)
+    if not native_allreduce(flag, "max", group):
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     return True
+
+
+class _NativeWork:
+    """a collective the library issued on `stream`: wait() makes the current stream wait for it (stream order, no host block)"""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        from . import functional as Fz
+        Fz._wait_for(torch.cuda.current_stream(self.stream.device), self.stream)
 
 
 class _null:
@@ -312,6 +407,15 @@ def combine_bn_partials(partial, count, group=None):
         buf[2 * c] = float(count)
     else:
         from . import ops
+        if dist.is_initialized() and native_available(group):
+            # pack + all-reduce issued by the library on the compute stream itself (zs3_bn_sync_exchange): no hand-over to another stream
+            from ._lib import check, lib, stream
+            c = partial.shape[2]
+            buf = torch.empty(2 * c + 1, dtype=torch.float64, device=partial.device)
+            st = stream()
+            check(lib().zs3_bn_sync_exchange(native_comm(st, group), partial.data_ptr(), partial.shape[0], c, float(count),
+                                             buf.data_ptr(), st), "zs3_bn_sync_exchange")
+            return buf, None
         buf = ops.bn_sync_pack(partial, count)
     if dist.is_initialized():
         dist.all_reduce(buf, group=group)

@@ -24,8 +24,10 @@ What makes a replay valid, and how it is kept:
 * anything that changes what the step launches drops the plan and the next calls run eagerly / re-record: another input shape
   or dtype, train / eval flips, requires_grad or parameter storage changes, another set of optimizer hyper-parameters than lr and
   weight decay, a precision / storage mode switch or range-guard fallback (functional.PLAN_EPOCH).
-Not planned (the call runs eagerly, every time): more than one rank (the collectives go through torch.distributed), an optimizer
-other than zs3_amd.optim.SGD, CPU tensors, gradient mode off.
+Several ranks: with the RCCL backend the step's collectives are entry points of the library (csrc/comm.hip) on the streams that hold
+the data, so the N > 1 step records and replays like the one-GPU step.  Not planned (the call runs eagerly, every time):
+collectives through torch.distributed (gloo, ZS3_NATIVE_RCCL=0), an optimizer other than zs3_amd.optim.SGD, CPU tensors, gradient
+mode off.
 """
 import ctypes
 import os
@@ -135,10 +137,13 @@ class StepPlan:
         if not isinstance(self.optimizer, SGD) or len(self.optimizer.param_groups) > lib().zs3_sgd_max_groups():
             return False
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return False
         from . import parallel
-        return not parallel.FORCE_COLLECTIVES
+        if parallel.FORCE_COLLECTIVES or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            # more than one rank: the step is plannable when its collectives are the library's own (RCCL backend: SyncBN sums,
+            # gradient buckets, CE weight sums and the range flag are zs3_allreduce / zs3_bn_sync_exchange calls, recorded like
+            # launches); through torch.distributed (gloo, ZS3_NATIVE_RCCL=0) they are not part of any plan
+            return parallel.native_available()
+        return True
 
     def _fingerprint(self, image, target):
         """everything that decides WHAT the step launches and WHERE its persistent operands live"""

@@ -56,9 +56,14 @@ def global_ce_normalise(loss_ws, batch, group):
     scales by the global sum(w) it finds there) and the returned loss is global sum(w*nll) / global sum(w) / global batch.
     Every rank's gradient is then its share of that loss' gradient, so GradSync's SUM reproduces the single-process one."""
     import torch.distributed as dist
+    from .. import parallel
     pg = None if group is True else group
-    dist.all_reduce(loss_ws[1:3], group=pg)
     batch = batch * dist.get_world_size(pg)
+    if parallel.native_allreduce(loss_ws[1:3], "sum", pg):
+        # the library's own collective on the compute stream + one tiny launch: nothing of the step runs outside the library
+        check(lib().zs3_ce_global_finish(P(loss_ws), I(batch), stream()), "zs3_ce_global_finish")
+        return loss_ws[0], batch
+    dist.all_reduce(loss_ws[1:3], group=pg)
     return loss_ws[2] / loss_ws[1] / (batch if batch > 0 else 1), batch
 
 
@@ -73,7 +78,10 @@ def ce_exchange_nothing(group, device):
     if group is None:
         return False
     import torch.distributed as dist
-    dist.all_reduce(torch.zeros(2, dtype=torch.float32, device=device), group=None if group is True else group)
+    from .. import parallel
+    zeros = torch.zeros(2, dtype=torch.float32, device=device)
+    if not parallel.native_allreduce(zeros, "sum", None if group is True else group):
+        dist.all_reduce(zeros, group=None if group is True else group)
     return True
 
 
