@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--ddp-steps", type=int, default=10,
                     help="timed steps of `ddp_one_rank`: the supervised step on the N > 1 code path with a one-rank RCCL group and "
                          "SyncBN (gradient buckets, 208 SyncBN all-reduces, global CE), run as a child process; 0 = skip")
+    ap.add_argument("--host-steps", type=int, default=10,
+                    help="timed steps of `host_batches`: the supervised step taking every batch from pinned host memory (54 MB over "
+                         "PCIe per step, what base_trainer.py:13 does), child process; 0 = skip")
     ap.add_argument("--script-steps", type=int, default=3,
                     help="timed iterations of `gmmn.script_loop`: the reference's own per-image x per-class loop body "
                          "(train_pascal_GMMN.py:139-268) on the drop-in modules; 0 = skip")
@@ -436,6 +439,16 @@ def main():
     if args.workload == "supervised":
         result["executor"] = executor
     if roof_main is not None:
+        # the step's own two floors next to ms_per_step: the x3-MFMA time of the step's conv flops at 2.5 PF / 3, and
+        # the step's HBM bytes (PMC passes of this command, profiles/) at the ~6.3 TB/s a streaming kernel sustains on this chip
+        tfl = args.batch * gflop_img / 1e3
+        mfma_ms = tfl / (PEAK_BF16_TF / (3.0 if args.dtype == "bf16x3" else 1.0)) * 1e3
+        step_gb = pmc_step_bytes("bf16" if args.dtype == "bf16" else "")
+        hbm_ms = step_gb / 6.3 if step_gb else None
+        roof_main["step_floor_ms"] = max(mfma_ms, hbm_ms or 0.0)
+        roof_main["step_floors"] = {"mfma_ms": mfma_ms, "hbm_ms": hbm_ms, "step_tflop": tfl, "step_hbm_gb": step_gb,
+                                    "note": "mfma_ms = conv flops of one step (fwd + dgrad + wgrad) / (2.5 PF / products per operand "
+                                            "pair); hbm_ms = HBM bytes of one step from the committed PMC passes / 6.3 TB/s"}
         result["roofline"] = roof_main
     if cpu_info is not None:
         result["cpu_baseline"] = cpu_info
@@ -448,6 +461,8 @@ def main():
         result["shard"] = shard_of_configs3(args)
     if children and args.ddp_steps > 0:
         result["ddp_one_rank"] = ddp_one_rank(args, result["ms_per_step"])
+    if children and args.host_steps > 0 and not args.host_batches:
+        result["host_batches"] = host_batches_child(args, result["ms_per_step"])
     if rank == 0:
         print(json.dumps(result))
     if world > 1 or args.ddp_selftest:
@@ -507,7 +522,7 @@ def _child_line(extra, timeout=180):
     """one bench.py child process on the same GPU (a clean process: its own allocator pool, caches and streams) -> its JSON line"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--gmmn-steps", "0", "--bf16-steps", "0", "--shard-steps", "0",
-           "--ddp-steps", "0", "--script-steps", "0", "--no-roofline"] + [str(a) for a in extra]
+           "--ddp-steps", "0", "--host-steps", "0", "--script-steps", "0", "--no-roofline"] + [str(a) for a in extra]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
@@ -525,6 +540,22 @@ def shard_of_configs3(args):
             "last_loss": d.get("last_loss"), "batch_per_gpu": 8, "classes": 60, "model_tflops": d.get("model_tflops"),
             "workload": "the supervised step on one rank's shard of BASELINE configs[3] (global B = 64 on 8 GPUs -> 8 images per rank, "
                         "60 classes), same arithmetic as `value`; child process, same GPU, no collectives (one rank)"}
+
+
+def host_batches_child(args, plain_ms):
+    """The supervised step with its batch coming from pinned HOST memory every iteration (base_trainer.py:13-14: `image.cuda(),
+    target.cuda()`): a child `bench.py --host-batches` -- the copy of batch i + 1 (54.7 MB) is queued on a copy stream while step i
+    computes.  Never `value` (that one has its inputs resident in HBM); the PCIe-inclusive rate, next to it."""
+    try:
+        d = _child_line(["--host-batches", "--steps", args.host_steps, "--warmup", 3, "--batch", args.batch, "--size", args.size,
+                         "--classes", args.classes])
+    except Exception as e:
+        return {"ms_per_step": None, "error": f"{type(e).__name__}"}
+    nbytes = args.batch * (3 + 1) * args.size * args.size * 4
+    return {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": "images/sec", "steps": d["steps"], "last_loss": d.get("last_loss"),
+            "resident_ms_per_step": plain_ms, "overhead_ms": d["ms_per_step"] - plain_ms, "host_to_device_bytes_per_step": nbytes,
+            "workload": "the supervised step of `value` with every batch copied from pinned host memory (image fp32 + label fp32), double "
+                        "buffered on a copy stream; child process, same GPU"}
 
 
 def ddp_one_rank(args, plain_ms):
@@ -581,6 +612,18 @@ def roofline_of(prof, warm_prof, instrumented, dtype):
         "all_conv_igemm_last_warmup_step": {k: {"launches": v[0], "tflops": v[1] / v[2] / 1e12, "ms": 1e3 * v[2]}
                                             for k, v in warm.items()},
     }
+
+def pmc_step_bytes(variant=""):
+    """HBM GB moved by one training step (read + write) from the newest committed PMC passes of this command"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic%s.json" % ("_" + variant if variant else ""))))
+    if not found:
+        return None
+    d = json.load(open(found[-1]))
+    if "per_step_read_GB" not in d:
+        return None
+    return float(d["per_step_read_GB"]) + float(d["per_step_write_GB"])
+
 
 def pmc_traffic(tag, variant=""):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command

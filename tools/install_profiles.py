@@ -4,7 +4,7 @@ import json, os, sys
 rnd = int(sys.argv[1])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles")
-base = "python bench.py --no-cpu-baseline --bf16-steps 0 --shard-steps 0 --ddp-steps 0 --script-steps 0"
+base = "python bench.py --no-cpu-baseline --bf16-steps 0 --shard-steps 0 --ddp-steps 0 --host-steps 0 --script-steps 0"
 runs = {"sup": ("supervised", base + " --steps 5 --warmup 2 --gmmn-steps 0", "7 steps in the trace: 2 warm-up + 5 timed"),
         "bf16": ("supervised_bf16", base + " --steps 5 --warmup 2 --gmmn-steps 0 --dtype bf16", "7 steps in the trace: 2 warm-up + 5 timed"),
         "gmmn": ("gmmn", base + " --workload gmmn --steps 4 --warmup 2 --no-roofline", "6 steps in the trace: 2 warm-up + 4 timed")}

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --bf16-steps 0 --shard-steps 0 --ddp-steps 0 --script-steps 0"
+B="python $R/bench.py --no-cpu-baseline --bf16-steps 0 --shard-steps 0 --ddp-steps 0 --host-steps 0 --script-steps 0"
 rm -rf $O/kt_* $O/pmcb_*
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/kt_sup -o p -- $B --steps 5 --warmup 2 --gmmn-steps 0 > $O/kt_sup.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/kt_bf16 -o p -- $B --steps 5 --warmup 2 --gmmn-steps 0 --dtype bf16 > $O/kt_bf16.log 2>&1

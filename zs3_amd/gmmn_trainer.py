@@ -52,6 +52,9 @@ CHAIN_MAX = max(1, int(os.environ.get("ZS3_GMMN_CHAIN", "32")))
 CHAIN_SIZES = tuple(1 << k for k in range(CHAIN_MAX.bit_length() - 1, -1, -1))
 
 
+FEATURE_PLAN = os.environ.get("ZS3_PLAN", "1") == "1"   # the frozen-backbone feature pass replayed from a recorded plan (plan.ForwardPlan)
+
+
 class GMMNStep:
     _hook_reads_generator = True   # does _after_image() need the generator's weights up to date? (GCNContextStep: no)
 
@@ -439,11 +442,23 @@ class GMMNStep:
         return [self.generator]
 
     # ------------------------------------------------------------------ frozen-backbone feature pass, pipelined
+    def _features_eager(self, image):
+        # [B, fh, fw, D]; in the 2-byte mode the backbone hands over bf16 features: the generator loop, the MMD kernels and the
+        # cluster graphs work on fp32 rows (273 MB at B = 16: one cast pass, ~0.1 ms)
+        return ops.cast(ops.nhwc(self.model.forward_before_class_prediction(image)), torch.float32)
+
     def _features(self, image):
+        """The frozen-backbone feature pass as a recorded launch plan (zs3_amd.plan.ForwardPlan): ~330 launches whose Python enqueue
+        took as long as the pass runs on the GPU (14-15 ms: the next batch's pass could not start overlapping the generator loop
+        until the host was done with it) replayed with one C call."""
         with torch.no_grad():
-            # [B, fh, fw, D]; in the 2-byte mode the backbone hands over bf16 features: the generator loop, the MMD kernels and the
-            # cluster graphs work on fp32 rows (273 MB at B = 16: one cast pass, ~0.1 ms)
-            return ops.cast(ops.nhwc(self.model.forward_before_class_prediction(image)), torch.float32)
+            if not FEATURE_PLAN:
+                return self._features_eager(image)
+            fp = self.__dict__.get("_feature_plan")
+            if fp is None:
+                from .plan import ForwardPlan
+                fp = self.__dict__["_feature_plan"] = ForwardPlan(self._features_eager, [self.model])
+            return fp(image)
 
     def prefetch(self, image):
         """Start the feature pass of the NEXT batch on a side stream.  The backbone is frozen in this step (only `pred_conv`

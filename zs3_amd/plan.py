@@ -345,3 +345,92 @@ class StepPlan:
 
     def close(self):
         self._drop()
+
+
+class ForwardPlan:
+    """A gradient-free forward of one tensor -> one tensor as a recorded plan: `fn(image)` (the frozen-backbone feature pass of the
+    GMMN step, train_pascal_GMMN.py:154-158: `model.forward_before_class_prediction(image)` under no_grad, BatchNorm in training
+    mode, dropout live) runs eagerly twice, is recorded on the third call and replayed afterwards.  Same rules as StepPlan (private
+    pool, the input rebound by pointer, dropout seeds patched in drawing order, anything that changes the launches drops the plan);
+    simpler in one respect -- no autograd thread, no optimizer.  The recorded output buffer is the plan's own: the caller gets a
+    COPY (the GMMN step reads batch t's features while batch t + 1's pass is already running)."""
+
+    def __init__(self, fn, modules, warmup=2, enabled=None):
+        self.fn, self.modules = fn, list(modules)
+        self.warmup = max(2, int(warmup))
+        self.enabled = ENABLED if enabled is None else bool(enabled)
+        self.replays = self.recordings = self.eager_calls = 0
+        self._plans = {}      # fingerprint (stream included) -> state dict
+
+    def _fingerprint(self, image):
+        mods = tuple(m.training for root in self.modules for m in root.modules())
+        params = tuple(p.data_ptr() for root in self.modules for p in root.parameters())
+        return (tuple(image.shape), image.dtype, tuple(image.stride()), image.device, mods, params, Fz.PLAN_EPOCH[0], ops.PREC_DEFAULT,
+                ops.ACT_DTYPE, ops.FWD_F16, torch.cuda.current_stream(image.device).cuda_stream)
+
+    def close(self):
+        for st in self._plans.values():
+            if st.get("plan") is not None:
+                st["plan"].close()
+        self._plans = {}
+
+    def __call__(self, image):
+        if not (self.enabled and image.is_cuda) or torch.is_grad_enabled():
+            self.eager_calls += 1
+            return self.fn(image)
+        key = self._fingerprint(image)
+        st = self._plans.get(key)
+        if st is None:
+            if len(self._plans) > 4:       # (shapes / modes come and go: keep the table small, the pools with it)
+                self.close()
+            st = self._plans[key] = {"seen": 0, "plan": None}
+        if st["plan"] is not None:
+            plan = st["plan"]
+            if image.data_ptr() != st["input"]:
+                for op, a in st["input_at"]:
+                    plan.set_ptr(op, a, image.data_ptr())
+                st["input"] = image.data_ptr()
+            for k, old in enumerate(st["seeds"]):
+                new = Fz.next_seed()
+                if plan.replace_u64(old, new) < 1:
+                    raise RuntimeError("ForwardPlan: a recorded dropout seed is gone from the plan")
+                st["seeds"][k] = new
+            plan.replay()
+            st["image"] = image
+            self.replays += 1
+            return st["out"].clone()
+        st["seen"] += 1
+        if st["seen"] <= self.warmup:
+            self.eager_calls += 1
+            return self.fn(image)
+        dev = image.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        plan, pool = LaunchPlan(), torch.cuda.MemPool()
+        drawn, next_seed = [], Fz.next_seed
+
+        def logged_seed():
+            v = next_seed()
+            drawn.append(v)
+            return v
+
+        torch.cuda.synchronize(dev)
+        Fz.next_seed, Fz.PLAN_RECORDING = logged_seed, True
+        torch._C._cuda_beginAllocateToPool(idx, pool.id)
+        try:
+            plan.begin()
+            try:
+                out = self.fn(image)
+            finally:
+                plan.end()
+        finally:
+            torch._C._cuda_endAllocateToPool(idx, pool.id)
+            Fz.next_seed, Fz.PLAN_RECORDING = next_seed, False
+        Fz._plan_keep.clear()
+        at = plan.find_ptr(image.data_ptr())
+        if not at or len(set(drawn)) != len(drawn) or not plan.find_ptr(out.data_ptr()):
+            plan.close()                   # (the pass copied its input, or its result is not what a recorded launch wrote: stay eager)
+            st["seen"] = 0
+            return out
+        st.update(plan=plan, pool=pool, seeds=list(drawn), input=image.data_ptr(), input_at=at, out=out, image=image)
+        self.recordings += 1
+        return out.clone()
