@@ -305,3 +305,31 @@ def test_every_conv_shape_at_batch_16_against_fp64_samples(dev, shape):
     e_q = ((st4[:, 1].double().sum(0) - y4d.square().sum(0)).abs().max() / y4d.square().sum(0).max()).item()
     print(f"[B=16 {shape}] f16x3 forward {e4:.1e} on {prof[0][0]} (bf16x3 {e_y:.1e}); BN sums {e_s:.1e} / {e_q:.1e}")
     assert e4 < 5e-6 and e_s < 2e-6 and e_q < 2e-6
+
+
+def test_full_size_step_replays_from_a_plan_bit_for_bit(dev):
+    """BASELINE configs[1] shape (B = 16, 513 x 513, live dropout): the recorded launch plan of the training step (zs3_amd/plan.py --
+    what bench.py's timed steps replay) against the eager step from the same state and seeds, through StepPlan.verify with the
+    plan's pool poisoned: loss, logits, all 320 gradients and every persistent tensor bit-identical."""
+    from zs3_amd import functional as Fz
+    from zs3_amd.modeling.deeplab import DeepLab
+    from zs3_amd.optim import SGD
+    from zs3_amd.plan import StepPlan
+    from zs3_amd.utils.loss import SegmentationLosses
+    from zs3_amd.utils.synthetic import make_batch
+    torch.manual_seed(1)
+    m = DeepLab(num_classes=21, pretrained=False, sync_bn=False).to(dev).train()
+    groups = [{"params": m.get_1x_lr_params(), "lr": 0.007}, {"params": m.get_10x_lr_params(), "lr": 0.07}]
+    opt = SGD(groups, momentum=0.9, weight_decay=5e-4)
+    crit = SegmentationLosses(cuda=True).build_loss("ce")
+    Fz.manual_seed(9)
+    step = StepPlan(m, crit, opt)
+    b = make_batch(16, 513, seed=3, device=dev)
+    for _ in range(4):
+        _, loss = step(b["image"], b["label"])
+    assert (step.eager_calls, step.recordings, step.replays) == (2, 1, 1) and step.recorded_ops > 850
+    bad = step.verify(b["image"], b["label"], poison=True)
+    assert not bad, bad[:10]
+    assert torch.isfinite(loss)
+    step.close()
+    torch.cuda.empty_cache()

@@ -209,3 +209,54 @@ def test_plan_entry_points_record_patch_and_replay(dev):
     torch.cuda.synchronize()
     assert torch.allclose(p.detach(), p0 - 0.35)
     plan.close()
+
+
+def test_aspp_lanes_change_nothing_but_the_schedule(dev):
+    """functional lanes (round 6): ASPP's two heavy atrous branches run on side streams entered INSIDE the fused layer (forward and
+    backward, waits recorded through zs3_stream_wait) -- the result is bit-identical to the sequential module, logits and every
+    gradient, and autograd still sees one stream."""
+    from zs3_amd import functional as Fz
+    from zs3_amd.utils.loss import SegmentationLosses
+    outs = []
+    b = _batches(dev, 2, 129, 1)[0]
+    for concurrent in (True, False):
+        Fz.ASPP_CONCURRENT = concurrent
+        try:
+            model, opt, crit = _setup(dev)
+            Fz.manual_seed(11)
+            out = model(b["image"])
+            loss = crit(out, b["label"])
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]))
+        finally:
+            Fz.ASPP_CONCURRENT = True
+    assert not Fz._lanes_open and not Fz._lanes_armed[0]                   # every lane was joined
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(a, c) for a, c in zip(outs[0][2], outs[1][2]))
+
+
+def test_feature_pass_replays_from_a_plan(dev):
+    """ForwardPlan (zs3_amd/plan.py): the GMMN step's frozen-backbone feature pass -- train-mode BatchNorm, live dropout, no
+    gradients -- recorded on its third call and replayed: features, BatchNorm running statistics and the dropout stream are those
+    of the eager calls, bit for bit, on a fresh input tensor every call."""
+    from zs3_amd import functional as Fz
+    from zs3_amd import ops
+    from zs3_amd.plan import ForwardPlan
+    res = []
+    bs = _batches(dev, 2, 129, 6)
+    for use_plan in (False, True):
+        model, _, _ = _setup(dev)
+        Fz.manual_seed(21)
+        fp = ForwardPlan(lambda im: ops.nhwc(model.forward_before_class_prediction(im)), [model], enabled=use_plan)
+        feats = []
+        with torch.no_grad():
+            for b in bs:
+                feats.append(fp(b["image"]).clone())
+        torch.cuda.synchronize()
+        res.append((feats, {k: v.detach().clone() for k, v in model.state_dict().items()}, (fp.eager_calls, fp.recordings, fp.replays)))
+        fp.close()
+    assert res[0][2] == (6, 0, 0) and res[1][2] == (2, 1, 3), (res[0][2], res[1][2])
+    assert all(torch.equal(a, c) for a, c in zip(res[0][0], res[1][0]))
+    assert not [k for k in res[0][1] if not torch.equal(res[0][1][k], res[1][1][k])]
+    assert not torch.equal(res[1][0][4], res[1][0][5])                      # (live dropout, another batch: the replays do differ)

@@ -18,7 +18,7 @@ def main():
     streams = list(c.execute("select stream_id, count(*) from kernels group by stream_id order by 2 desc"))
     sid = streams[int(sys.argv[2]) if len(sys.argv) > 2 else 0][0]
     rows = list(c.execute("select name, start, end from kernels where stream_id=? order by start", (sid,)))
-    cuts = [i for i, r in enumerate(rows) if "sgd_multi_kernel" in r[0]]
+    cuts = [i for i, r in enumerate(rows) if "sgd_multi" in r[0]]
     print(f"stream {sid}: {len(rows)} dispatches, {len(cuts)} steps (streams: {streams})")
     for a, b in zip(cuts[1:-1], cuts[2:]):
         seg = rows[a + 1:b + 1]

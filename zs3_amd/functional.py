@@ -22,6 +22,9 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # of this network launch fewer workgroups than the 256 CUs can hold, so the wgrad kernels run on a second HIP stream
 # next to the dgrad / BatchNorm chain; the main stream joins it once, at the end of backward.
 WGRAD_SIDE_STREAM = True
+# The side stream of a layer's weight gradient waits for the main stream at the point where dy exists (behind bn_act_bwd), not
+# behind the layer's data-gradient launch: dgrad and wgrad of one layer both only READ dy, so they may run side by side.
+EARLY_WGRAD_FORK = False
 # Side streams inside a hipGraph capture (GraphedStep): the side stream joins the capture through its wait on the capturing stream
 # and is joined back by the end-of-backward callback, so the captured graph keeps the dgrad / wgrad overlap of the eager step.
 CAPTURE_SIDE_STREAMS = False   # (probe: tools/probe/graph_probe.py -- 36.2 ms with, 36.8 without for fwd + bwd in the 2-byte mode: hipGraph replay does not overlap the branches; off)
@@ -80,6 +83,7 @@ def _wait_for(waiter, producer):
 # recording run's timing that no replay repeats -- but kept alive here until the end-of-backward join, after which the main stream
 # (where they were allocated) is ordered behind every side-stream reader.
 PLAN_RECORDING = False
+ASPP_LANES_LAST = True    # the lane branches are the LAST nodes created in ASPP's forward = the first to run in its backward
 ASPP_CONCURRENT = True   # ASPP's branches on three streams in the eager step (modeling/aspp.py); never while a plan records
 _plan_keep = []
 PLAN_EPOCH = [0]     # bumped whenever buffers a plan may have recorded are dropped (weight planes, mode switches): plans re-record
@@ -135,9 +139,19 @@ def lane_streams(device, n=2):
     return _lanes[key]
 
 
-def _enter_lane(lane):
+def lanes_fork(*lanes):
+    """the lanes wait for what the current (main) stream holds NOW: layers that enter them with `lane_forked` set start from this
+    point, whatever the main stream is given in between (ASPP: the main stream's own branches are enqueued before the lanes')"""
     main = _current_stream()
-    _wait_for(lane, main)
+    for lane in lanes:
+        if lane is not None:
+            _wait_for(lane, main)
+
+
+def _enter_lane(lane, wait=True):
+    main = _current_stream()
+    if wait:
+        _wait_for(lane, main)
     _set_stream(lane)
     _lanes_open.setdefault(lane.device_index, set()).add(lane)
     return main
@@ -418,7 +432,7 @@ class _ConvBnAct(torch.autograd.Function):
         lane = cfg.get("lane")
         if lane is None:
             return _ConvBnAct._forward(ctx, x, weight, gamma, beta, bias, residual, cfg)
-        main = _enter_lane(lane)
+        main = _enter_lane(lane, wait=not cfg.get("lane_forked"))
         try:
             return _ConvBnAct._forward(ctx, x, weight, gamma, beta, bias, residual, cfg)
         finally:
@@ -608,6 +622,11 @@ class _ConvBnAct(torch.autograd.Function):
                     dbias = _sum_partials(ops.colstats(full), cout, bout)
         dx = dw = None
         lazy_bits = None
+        early_side = None
+        if EARLY_WGRAD_FORK and need_w and need_x and geom is None and WGRAD_SIDE_STREAM and (
+                CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing()):
+            early_side = wgrad_stream(dy.device)
+            _wait_for(early_side, _current_stream())        # dy (and x) are ready here; the data gradient below only reads them
         if dskip is not None:
             ent = _lazy_skip.pop(dskip.data_ptr(), None)
             if ent is not None and tuple(ent[0].shape) == tuple(dskip.shape):
@@ -658,11 +677,12 @@ class _ConvBnAct(torch.autograd.Function):
                 dskip = dz
             dx = dskip
         if need_w:
-            side = wgrad_stream(dy.device) if (WGRAD_SIDE_STREAM and geom is None and (
-                CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())) else None
+            side = early_side if early_side is not None else (wgrad_stream(dy.device) if (WGRAD_SIDE_STREAM and geom is None and (
+                CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())) else None)
             if side is not None:
                 main = _current_stream()
-                _wait_for(side, main)           # dy (and x) are ready on the main stream
+                if early_side is None:
+                    _wait_for(side, main)       # dy (and x) are ready on the main stream
                 if PLAN_RECORDING:
                     _plan_keep.append((dy, x))  # (see PLAN_RECORDING: alive until the join, no allocator bookkeeping)
                 else:
@@ -783,7 +803,7 @@ def _consumer_applies(x, weight, stride, pad, dil, prec, next_conv):
 
 def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, dil=1, act=ACT_NONE, out=None,
                 leak=0.2, prec=None, geom=None, wgrad=None, pass_through=False, input_has_one_consumer=False, dropout=None,
-                next_conv=None, out_dtype=None, lane=None):
+                next_conv=None, out_dtype=None, lane=None, lane_forked=False):
     """bn: a BatchNorm module-like object with weight/bias/running_mean/running_var/eps/momentum/training, or None.
     input_has_one_consumer: promise that `x` feeds nothing but this layer (and, with pass_through, the skip tensor this
     layer hands back), which lets this layer's dgrad produce the BN-backward sums of the layer that made `x` (BnLink).
@@ -805,6 +825,7 @@ def conv_bn_act(x, weight, bn=None, bias=None, residual=None, stride=1, pad=0, d
             drop_after = (float(dropout[0]), None)
     cfg = {"stride": stride, "pad": pad, "dil": dil, "act": act, "out": out, "leak": leak, "prec": prec, "geom": geom,
            "out_dtype": out_dtype, "lane": lane,    # lane: a side stream this layer runs on, forward and backward (see lane_streams)
+           "lane_forked": bool(lane_forked),        # the forward's wait for the main stream was made by lanes_fork() already
            "drop": drop,
            "wgrad": wgrad, "pass_through": pass_through,
            "in_link": getattr(x, "_zs3_bn_link", None) if (input_has_one_consumer and FUSE_BN_BWD_STATS) else None,

@@ -27,8 +27,8 @@ class _ASPPModule(nn.Module):
         self.relu = nn.ReLU()
         self._init_weight()
 
-    def forward_nhwc(self, x, out=None, lane=None):
-        return self.atrous_conv.forward_nhwc(x, self.bn, act=Fz.ACT_RELU, out=out, lane=lane)
+    def forward_nhwc(self, x, out=None, lane=None, lane_forked=False):
+        return self.atrous_conv.forward_nhwc(x, self.bn, act=Fz.ACT_RELU, out=out, lane=lane, lane_forked=lane_forked)
 
     def forward(self, x):
         return ops.nchw(self.forward_nhwc(ops.nhwc(x)))
@@ -73,7 +73,7 @@ class ASPP(nn.Module):
 
         def branch(i, lane=None):
             br = (self.aspp1, self.aspp2, self.aspp3, self.aspp4)[i]
-            return br.forward_nhwc(xs[i], out=cat[..., 256 * i:256 * (i + 1)], lane=lane)
+            return br.forward_nhwc(xs[i], out=cat[..., 256 * i:256 * (i + 1)], lane=lane, lane_forked=lane is not None)
 
         def pooled():
             p = self.global_avg_pool[1].forward_nhwc(Fz.global_avg_pool(xs[4]), bn, act=Fz.ACT_RELU)   # [N,1,1,256]
@@ -81,12 +81,22 @@ class ASPP(nn.Module):
 
         concurrent = x.is_cuda and Fz.ASPP_CONCURRENT and (Fz.CAPTURE_SIDE_STREAMS or not torch.cuda.is_current_stream_capturing())
         l1, l2 = Fz.lane_streams(x.device, 2) if concurrent else (None, None)
+        # Order: the lanes start from the fork point (x is ready), so the host order of the five launches does not matter to the
+        # forward pass; it does to the backward pass -- autograd runs the nodes created LAST first, and the two heavy atrous
+        # branches on the lanes have to be under way before the main stream works through its own three (round 6 trace: with the
+        # lane branches created first the main stream finished its branches and then sat 1.4 ms waiting for the lanes to start and
+        # finish).
+        Fz.lanes_fork(l1, l2)
         parts = [None] * 5
-        parts[2] = branch(2, l1)
-        parts[3] = branch(3, l2)
-        parts[1] = branch(1)
-        parts[0] = branch(0)
+        if not Fz.ASPP_LANES_LAST:      # (A/B switch: the round-6 mid-round order, lane branches created first)
+            parts[2] = branch(2, l1)
+            parts[3] = branch(3, l2)
         parts[4] = pooled()
+        parts[0] = branch(0)
+        parts[1] = branch(1)
+        if Fz.ASPP_LANES_LAST:
+            parts[2] = branch(2, l1)
+            parts[3] = branch(3, l2)
         Fz.lanes_join()       # the projection below reads all five slices on the main stream
         return self.conv1.forward_nhwc(Fz.cat_slices(cat, parts), self.bn1, act=Fz.ACT_RELU, dropout=self.dropout)
 

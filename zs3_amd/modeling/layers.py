@@ -20,14 +20,14 @@ class Conv2d(nn.Conv2d):
         return self
 
     def forward_nhwc(self, x, bn=None, residual=None, act=Fz.ACT_NONE, out=None, pass_through=False,
-                     input_has_one_consumer=False, dropout=None, next_conv=None, out_dtype=None, lane=None):
+                     input_has_one_consumer=False, dropout=None, next_conv=None, out_dtype=None, lane=None, lane_forked=False):
         """dropout: the nn.Dropout module that follows bn + act in the reference's Sequential (fused where possible).
         next_conv: the conv that is the only consumer of this layer's output (it may apply this layer's BN + ReLU itself)."""
         return Fz.conv_bn_act(x, self.weight, bn=bn, bias=self.bias, residual=residual, stride=self.stride[0],
                               pad=self.padding[0], dil=self.dilation[0], act=act, out=out, pass_through=pass_through,
                               input_has_one_consumer=input_has_one_consumer,
                               dropout=None if dropout is None else (dropout.p, dropout.training), next_conv=next_conv,
-                              out_dtype=out_dtype, lane=lane)
+                              out_dtype=out_dtype, lane=lane, lane_forked=lane_forked)
 
     def forward(self, x):  # logical NCHW in / out
         return ops.nchw(self.forward_nhwc(ops.nhwc(x)))
