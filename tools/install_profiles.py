@@ -5,9 +5,9 @@ rnd = int(sys.argv[1])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles")
 base = "python bench.py --no-cpu-baseline --bf16-steps 0 --shard-steps 0 --ddp-steps 0 --host-steps 0 --script-steps 0"
-runs = {"sup": ("supervised", base + " --steps 5 --warmup 2 --gmmn-steps 0", "7 steps in the trace: 2 warm-up + 5 timed"),
-        "bf16": ("supervised_bf16", base + " --steps 5 --warmup 2 --gmmn-steps 0 --dtype bf16", "7 steps in the trace: 2 warm-up + 5 timed"),
-        "gmmn": ("gmmn", base + " --workload gmmn --steps 4 --warmup 2 --no-roofline", "6 steps in the trace: 2 warm-up + 4 timed")}
+runs = {"sup": ("supervised", base + " --steps 5 --warmup 2 --gmmn-steps 0", "11 steps in the trace: 4 that settle and record the launch plan, 2 warm-up, 5 timed (4 of them replayed from the plan)"),
+        "bf16": ("supervised_bf16", base + " --steps 5 --warmup 2 --gmmn-steps 0 --dtype bf16", "11 steps in the trace: 4 that settle and record the launch plan, 2 warm-up, 5 timed (4 of them replayed from the plan)"),
+        "gmmn": ("gmmn", base + " --workload gmmn --steps 4 --warmup 2 --no-roofline", "6 steps in the trace: 2 warm-up + 4 timed; the feature pass is recorded on its third call and replayed afterwards")}
 for key, (name, cmd, note) in runs.items():
     line = json.loads(open(os.path.join(src, f"bench_{key}.json")).read())
     head = f"# r{rnd}_{name}_kernel_stats\n\nRound {rnd}, 1x MI355X, B=16, 513x513, 21 classes, synthetic data; `rocprofv3 --kernel-trace --stats -- {cmd}` " \

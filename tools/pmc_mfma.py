@@ -32,6 +32,8 @@ def main(path, steps):
         if key not in seen:
             seen.add(key)
             cnt[k] += 1
+    if steps <= 0:      # one optimizer launch per training step (the bench adds plan-recording steps of its own since round 6)
+        steps = max(1, sum(n for k, n in cnt.items() if "sgd_multi" in k))
     names = sorted({c for v in agg.values() for c in v})
     print(f"counters: {', '.join(names)}; {steps} training steps profiled (PMC collection serialises kernels: durations are not step-time)\n")
     # effective clock of a kernel: GRBM_GUI_ACTIVE is summed over the 8 XCDs, so cycles per XCD / kernel duration = the clock the

@@ -29,6 +29,8 @@ def load(path):
 def main(root, steps):
     f = load(f"{root}/pmcb_FETCH_SIZE/p_counter_collection.csv")
     w = load(f"{root}/pmcb_WRITE_SIZE/p_counter_collection.csv")
+    if steps <= 0:      # one optimizer launch per training step: count them (round 6: the bench adds plan-recording steps of its own)
+        steps = max(1, sum(v[0] for k, v in f.items() if "sgd_multi" in k))
     out = {"steps_profiled": steps, "note": "HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH correction)",
            "per_step_read_GB": sum(v[1] for v in f.values()) * 2 * 1024 / steps / 1e9,
            "per_step_write_GB": sum(v[1] for v in w.values()) * 1024 / steps / 1e9, "kernels": {}}

@@ -19,16 +19,16 @@ done
 for set in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $set --kernel-trace -d $O/pmcb_$set -o p --output-format csv -- $B --steps 2 --warmup 1 --gmmn-steps 0 --no-roofline > /dev/null 2>&1
 done
-python $R/tools/pmc_traffic.py $O 3 > $O/pmc_traffic.json
+python $R/tools/pmc_traffic.py $O 0 > $O/pmc_traffic.json
 # the same two passes for the 2-byte mode (round 4)
 mkdir -p $O/b16
 for set in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $set --kernel-trace -d $O/b16/pmcb_$set -o p --output-format csv -- $B --steps 2 --warmup 1 --gmmn-steps 0 --no-roofline --dtype bf16 > /dev/null 2>&1
 done
-python $R/tools/pmc_traffic.py $O/b16 3 > $O/pmc_traffic_bf16.json
+python $R/tools/pmc_traffic.py $O/b16 0 > $O/pmc_traffic_bf16.json
 find $O/b16 -type f -delete
 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace -d $O/pmcb_MFMA -o p --output-format csv -- $B --steps 2 --warmup 1 --gmmn-steps 0 --no-roofline > $O/pmc_mfma.log 2>&1
-python $R/tools/pmc_mfma.py $O/pmcb_MFMA/p_counter_collection.csv 3 > $O/pmc_mfma.md
+python $R/tools/pmc_mfma.py $O/pmcb_MFMA/p_counter_collection.csv 0 > $O/pmc_mfma.md
 find $O/pmcb_FETCH_SIZE $O/pmcb_WRITE_SIZE $O/pmcb_MFMA -type f -delete
 grep '^{' $O/kt_sup.log | tail -1 > $O/bench_sup.json; grep '^{' $O/kt_bf16.log | tail -1 > $O/bench_bf16.json; grep '^{' $O/kt_gmmn.log | tail -1 > $O/bench_gmmn.json
 tail -30 $O/pmc_mfma.md
