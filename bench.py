@@ -466,6 +466,9 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1 or args.ddp_selftest:
+        from zs3_amd import parallel as _par
+        torch.cuda.synchronize()
+        _par.native_shutdown()
         dist.destroy_process_group()
 
 

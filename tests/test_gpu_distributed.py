@@ -27,6 +27,9 @@ def one_rank_group(dev):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     yield True
+    import zs3_amd.parallel as par
+    torch.cuda.synchronize()
+    par.native_shutdown()
     dist.destroy_process_group()
 
 

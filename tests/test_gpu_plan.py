@@ -260,3 +260,35 @@ def test_feature_pass_replays_from_a_plan(dev):
     assert all(torch.equal(a, c) for a, c in zip(res[0][0], res[1][0]))
     assert not [k for k in res[0][1] if not torch.equal(res[0][1][k], res[1][1][k])]
     assert not torch.equal(res[1][0][4], res[1][0][5])                      # (live dropout, another batch: the replays do differ)
+
+
+def test_plan_with_the_reference_scripts_cpu_class_weights_and_with_labels_it_cannot_rebind(dev):
+    """(1) The reference's scripts hand the criterion a CPU weight tensor and move it at every call (loss.py:36-37): the device copy
+    is made once per tensor version, so the recorded CE launch reads a buffer that stays -- replays equal eager steps.  (2) uint8
+    labels are cast by the tensor library in front of the first launch: the step does not read the caller's tensor, the plan
+    cannot rebind it -- that configuration stays eager (one attempted recording, then none), results unchanged."""
+    from zs3_amd import functional as Fz
+    from zs3_amd.plan import StepPlan
+    from zs3_amd.utils.loss import SegmentationLosses
+    w = torch.ones(21)
+    w[[10, 14]] = 100.0
+    bs = _batches(dev, 2, 65, 6)
+    outs = []
+    for use_plan in (False, True):
+        model, opt, _ = _setup(dev)
+        crit = SegmentationLosses(weight=w, cuda=True).build_loss("ce")            # CPU weights, like train_pascal.py:64-77
+        Fz.manual_seed(5)
+        step = StepPlan(model, crit, opt, enabled=use_plan)
+        losses = [step(b["image"], b["label"])[1].detach().clone() for b in bs]
+        torch.cuda.synchronize()
+        outs.append((torch.stack(losses).cpu(), (step.eager_calls, step.recordings, step.replays)))
+        step.close()
+    assert outs[1][1] == (2, 1, 3) and torch.equal(outs[0][0], outs[1][0]), outs
+    model, opt, crit = _setup(dev)
+    Fz.manual_seed(5)
+    step = StepPlan(model, crit, opt)
+    for b in bs:
+        _, loss = step(b["image"], b["label"].to(torch.uint8))
+    torch.cuda.synchronize()
+    # 2 settling calls, 1 attempted recording (it ran the step eagerly and found nothing to rebind), 3 plain eager calls
+    assert (step.recordings, step.replays, step.eager_calls) == (0, 0, 5) and step._plan is None and torch.isfinite(loss)

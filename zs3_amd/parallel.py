@@ -83,6 +83,15 @@ def native_comm(stream_handle, group=None):
     return comm
 
 
+def native_shutdown():
+    """destroy the library's communicators (before torch.distributed.destroy_process_group, or when a process group is replaced)"""
+    from ._lib import lib
+    for comm in _native_comms.values():
+        lib().zs3_comm_destroy(comm)
+    _native_comms.clear()
+    _native_backend.clear()
+
+
 def native_allreduce(t, op="sum", group=None):
     """in-place all-reduce of a dense device tensor on the CURRENT stream through the library; False when not applicable"""
     if not (t.is_cuda and native_available(group)):

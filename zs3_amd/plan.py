@@ -117,6 +117,7 @@ class StepPlan:
         self.enabled = ENABLED if enabled is None else bool(enabled)
         self.replays = self.recordings = self.eager_calls = 0
         self._one = None
+        self._giveup = None          # fingerprint of a configuration whose step turned out not to be replayable
         self._drop()
 
     # ------------------------------------------------------------------------------------------------ state
@@ -147,11 +148,16 @@ class StepPlan:
 
     def _fingerprint(self, image, target):
         """everything that decides WHAT the step launches and WHERE its persistent operands live"""
-        mods = tuple(m.training for m in self.model.modules())
+        # per module: train / eval, and the scalars its launches carry as arguments (dropout probability, BatchNorm momentum / eps)
+        mods = tuple((m.training, getattr(m, "p", None), getattr(m, "momentum", None), getattr(m, "eps", None)) for m in self.model.modules())
         params = tuple((p.data_ptr(), p.requires_grad) for g in self.optimizer.param_groups for p in g["params"])
         hyper = tuple((g["momentum"], g["nesterov"], g.get("dampening", 0)) for g in self.optimizer.param_groups)
+        owner = getattr(self.criterion, "__self__", None)      # SegmentationLosses: class weights, ignore index, batch averaging
+        w = getattr(owner, "weight", None)
+        crit = (id(owner), (w.data_ptr(), w._version) if torch.is_tensor(w) else None, getattr(owner, "ignore_index", None),
+                getattr(owner, "batch_average", None), getattr(self.criterion, "__name__", None))
         return (tuple(image.shape), image.dtype, tuple(image.stride()), tuple(target.shape), target.dtype, tuple(target.stride()),
-                image.device, mods, params, hyper, Fz.PLAN_EPOCH[0], ops.PREC_DEFAULT, ops.ACT_DTYPE, ops.FWD_F16,
+                image.device, mods, params, hyper, crit, Fz.PLAN_EPOCH[0], ops.PREC_DEFAULT, ops.ACT_DTYPE, ops.FWD_F16,
                 Fz.WGRAD_SIDE_STREAM, Fz.WGRAD_STREAMS, torch.cuda.current_stream(image.device).cuda_stream)
 
     # ------------------------------------------------------------------------------------------------ the three ways to run a step
@@ -195,7 +201,8 @@ class StepPlan:
         del keep
         if len(set(drawn)) != len(drawn):
             plan.close()
-            return prediction, loss      # (two equal 63-bit seeds: cannot tell the launches apart; stay eager, try again next call)
+            self._settled = 0            # (two equal 63-bit seeds: cannot tell the launches apart; eager now, another recording later)
+            return prediction, loss
         # The optimizer's record table {param, grad, momentum buffer, ...} was uploaded by the tensor library during the step, into pool
         # memory that an EARLIER intermediate of the same step had used: a replay re-runs that intermediate's producer and would
         # overwrite the table, whose upload is not part of the plan.  Its content is final (the gradients' addresses are the
@@ -219,8 +226,11 @@ class StepPlan:
         self._inputs = [image.data_ptr(), target.data_ptr()]
         self._input_at = [plan.find_ptr(image.data_ptr()), plan.find_ptr(target.data_ptr())]
         if not self._input_at[0] or not self._input_at[1] or image.data_ptr() == target.data_ptr():
+            # the step did not read its batch where the caller's tensors live (a cast or a .contiguous() copy the tensor library made
+            # in front of the first launch: uint8 / float64 labels, a non-contiguous image): this configuration stays eager
             plan.close()
-            return prediction, loss      # (the step did not read its batch where the caller's tensors live: a copy was made; stay eager)
+            self._plan, self._pool, self._giveup = None, None, self._key
+            return prediction, loss
         self._held = (prediction, loss, moved, image, target)
         self._grads = [(p, p.grad) for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
         self._grads_moved = False
@@ -271,6 +281,9 @@ class StepPlan:
             self._key = key
         if self._plan is not None:
             return self._replay(image, target)
+        if key == self._giveup:
+            self.eager_calls += 1
+            return self._eager(image, target)
         self._settled += 1
         if self._settled <= self.warmup:
             self.eager_calls += 1
@@ -363,7 +376,8 @@ class ForwardPlan:
         self._plans = {}      # fingerprint (stream included) -> state dict
 
     def _fingerprint(self, image):
-        mods = tuple(m.training for root in self.modules for m in root.modules())
+        mods = tuple((m.training, getattr(m, "p", None), getattr(m, "momentum", None), getattr(m, "eps", None))
+                     for root in self.modules for m in root.modules())
         params = tuple(p.data_ptr() for root in self.modules for p in root.parameters())
         return (tuple(image.shape), image.dtype, tuple(image.stride()), image.device, mods, params, Fz.PLAN_EPOCH[0], ops.PREC_DEFAULT,
                 ops.ACT_DTYPE, ops.FWD_F16, torch.cuda.current_stream(image.device).cuda_stream)

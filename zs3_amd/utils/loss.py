@@ -93,6 +93,29 @@ def ce_group(group, logit):
     return group
 
 
+_weight_cache = {}
+
+
+def _device_weight(weight, device):
+    """The class weights as a dense fp32 tensor on `device`, converted ONCE per (tensor object, version): the reference's scripts hand
+    the criterion a CPU tensor and move it at every call (loss.py:36-37); a fresh device copy per call would also be a buffer whose
+    producer (the upload) no recorded plan contains."""
+    if not torch.is_tensor(weight):
+        weight = torch.as_tensor(weight, dtype=torch.float32)
+    if weight.device == device and weight.dtype == torch.float32 and weight.is_contiguous():
+        return weight
+    key = (id(weight), str(device))
+    hit = _weight_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        return hit[2]
+    import weakref
+    dev_w = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+    if len(_weight_cache) > 16:
+        _weight_cache.clear()
+    _weight_cache[key] = (weakref.ref(weight), weight._version, dev_w)
+    return dev_w
+
+
 def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average=True, group="auto"):
     """group: "auto" (normalise over every rank's shard as soon as torch.distributed runs with more than one rank: the loss of
     the gathered batch that nn.DataParallel hands the reference's criterion) | None (this process only) | True (default process
@@ -105,7 +128,7 @@ def cross_entropy_2d(logit, target, weight=None, ignore_index=255, batch_average
     deadlock, exactly like eval-mode BatchNorm.  Pass True / a group to get the globally normalised value there too."""
     group = ce_group(group, logit)
     if weight is not None:
-        weight = weight.to(device=logit.device, dtype=torch.float32).contiguous()
+        weight = _device_weight(weight, logit.device)
     batch = logit.shape[0] if batch_average else 0
     return _CrossEntropy.apply(logit, target, weight, ignore_index, batch, group)
 
