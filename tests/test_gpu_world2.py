@@ -114,8 +114,10 @@ def _gmmn(dev, image, label, table, steps=1):
         gl, cl, _ = step(image, label, table=table)
         losses.append((gl, cl))
     torch.cuda.synchronize()
+    fp = step.__dict__.get("_feature_plan")
     return {"losses": losses, "gen": [p.detach().cpu().clone() for p in gen.parameters()],
-            "pred_w": m.decoder.pred_conv.weight.detach().cpu().clone(), "pred_b": m.decoder.pred_conv.bias.detach().cpu().clone()}
+            "pred_w": m.decoder.pred_conv.weight.detach().cpu().clone(), "pred_b": m.decoder.pred_conv.bias.detach().cpu().clone(),
+            "feature_plan": (fp.eager_calls, fp.recordings, fp.replays) if fp is not None else None}
 
 
 def _gcn(dev, image, label, table):
@@ -179,6 +181,10 @@ def _worker(rank, world, port, outdir):
         # criterion's all-reduce that the other rank issues from its cluster term -- with zeros, not through a no_grad dummy call
         lonely = torch.full_like(seen_only[sl], 3) if rank == 1 else seen_only[sl]
         res["gcn_lonely"] = _gcn(dev, image[sl].to(dev), lonely.to(dev), table.to(dev))
+        # four GMMN steps: in a single process the feature pass is recorded on its third call and replayed on the fourth; with two
+        # ranks over gloo its SyncBN-free forward has no collective, but the step's do go through torch.distributed -- the plan
+        # machinery must leave such a process alone (zs3_amd.plan.collectives_recordable)
+        res["gmmn4"] = _gmmn(dev, image[sl].to(dev), seen_only[sl].to(dev), table.to(dev), steps=4)
         torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
@@ -231,6 +237,9 @@ def test_two_ranks_on_one_device_equal_the_single_process_step():
     for k in range(2):
         assert abs(r[k]["gmmn"]["losses"][0][1] - expect) < 1e-5 * abs(expect), (r[k]["gmmn"]["losses"], expect)
     assert not torch.equal(r[0]["gmmn"]["pred_w"], solo[0]["pred_w"])     # the classifier step used both shards' gradients
+    assert r[0]["gmmn4"]["feature_plan"] == r[1]["gmmn4"]["feature_plan"] == (4, 0, 0)        # two ranks over gloo: always eager
+    solo4 = _gmmn(dev, image[:2].to(dev), seen_only[:2].to(dev), table.to(dev), steps=4)
+    assert solo4["feature_plan"] == (2, 1, 1)                                                   # one process: recorded, replayed
     # ---------------- GCN-context step (configs[4] flow): two replicated generators, same exchange
     for key in ("gen", "gcn"):
         for a, b in zip(r[0]["gcn"][key], r[1]["gcn"][key]):

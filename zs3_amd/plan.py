@@ -41,6 +41,16 @@ from ._lib import Zs3HipError, check, lib
 ENABLED = os.environ.get("ZS3_PLAN", "1") == "1"
 
 
+def collectives_recordable():
+    """With more than one rank a step contains collectives: they are part of a plan only when the library issues them itself (RCCL
+    backend: csrc/comm.hip); through torch.distributed (gloo, ZS3_NATIVE_RCCL=0) a recording would silently miss them."""
+    import torch.distributed as dist
+    from . import parallel
+    if parallel.FORCE_COLLECTIVES or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return parallel.native_available()
+    return True
+
+
 class LaunchPlan:
     """Thin owner of one zs3_plan handle."""
 
@@ -137,14 +147,9 @@ class StepPlan:
         from .optim import SGD
         if not isinstance(self.optimizer, SGD) or len(self.optimizer.param_groups) > lib().zs3_sgd_max_groups():
             return False
-        import torch.distributed as dist
-        from . import parallel
-        if parallel.FORCE_COLLECTIVES or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            # more than one rank: the step is plannable when its collectives are the library's own (RCCL backend: SyncBN sums,
-            # gradient buckets, CE weight sums and the range flag are zs3_allreduce / zs3_bn_sync_exchange calls, recorded like
-            # launches); through torch.distributed (gloo, ZS3_NATIVE_RCCL=0) they are not part of any plan
-            return parallel.native_available()
-        return True
+        # more than one rank: plannable when the collectives are the library's own (SyncBN sums, gradient buckets, CE weight sums and
+        # the range flag as zs3_allreduce / zs3_bn_sync_exchange calls, recorded like launches)
+        return collectives_recordable()
 
     def _fingerprint(self, image, target):
         """everything that decides WHAT the step launches and WHERE its persistent operands live"""
@@ -389,7 +394,7 @@ class ForwardPlan:
         self._plans = {}
 
     def __call__(self, image):
-        if not (self.enabled and image.is_cuda) or torch.is_grad_enabled():
+        if not (self.enabled and image.is_cuda) or torch.is_grad_enabled() or not collectives_recordable():
             self.eager_calls += 1
             return self.fn(image)
         key = self._fingerprint(image)
