@@ -353,7 +353,21 @@ def main():
                        # launch exactly once.  (An event pair is ~50-100 us of host time and a kernel boundary the
                        # GPU cannot overlap: 127 pairs in a step made that step ~25 ms longer.)
 
+        # With a recorded plan the instrumented steps are replays too: the event pairs are recorded by zs3_plan_replay itself around
+        # the sampled launches (zs3_plan_time_ops), on the stream each launch runs on.  The k-th convolution launch of the plan is the
+        # k-th record of the eager warm-up step above (same launch order), which supplies its kernel tag and algorithmic flops.
+        conv_ops = plan_step.conv_ops()
+        in_replay = bool(conv_ops) and len(conv_ops) == len(warm_prof) and ops.PROFILE_CFGS is not None
+        dominant = [k for k, rec in enumerate(warm_prof) if ops.PROFILE_CFGS is not None and rec[4] in ops.PROFILE_CFGS]
+        timed_sets = []
+
         def sampled_step(i):
+            if instrument(i) and in_replay:
+                pick = dominant[nth[0] % STRIDE::STRIDE]
+                nth[0] += 1
+                ops.PROFILE, ops.PROFILE_SAMPLE = None, None
+                timed_sets.append((plan_step.time_next_replay([conv_ops[k] for k in pick]), pick))
+                return supervised_step(i)
             if instrument(i):
                 ops.PROFILE = timed_prof
                 ops.PROFILE_SAMPLE = [STRIDE, nth[0] % STRIDE, -1]
@@ -363,6 +377,10 @@ def main():
             return supervised_step(i, eager=instrument(i))
         dt, last = run(sampled_step, steps, 0)
         ops.PROFILE, ops.PROFILE_CFGS, ops.PROFILE_SAMPLE = None, None, None
+        for sid, pick in timed_sets:
+            for k, ms in zip(pick, plan_step.timed_ms(sid, len(pick))):
+                timed_prof.append((warm_prof[k][0], warm_prof[k][1], _Duration(ms), None, warm_prof[k][4]))
+        measure_supervised.replayed_instrumented = bool(timed_sets)
         return dt, last, timed_prof, warm_prof, sum(1 for i in range(steps) if instrument(i))
 
     bf16_info = None
@@ -373,11 +391,14 @@ def main():
         # are a finite pool that the side-stream waits of the weight-gradient launches share)
         roof_main = roofline_of(prof, warm_prof, instrumented, args.dtype) if (rank == 0 and prof) else None
         prof, warm_prof = [], []
+        inst_replayed = bool(getattr(measure_supervised, "replayed_instrumented", False))
+        n_eager = 0 if inst_replayed else instrumented
         executor = {"plan": bool(plan_step.recorded_ops), "recorded_launches": plan_step.recorded_ops,
-                    "timed_steps_replayed": args.steps - instrumented if plan_step.recorded_ops else 0,
-                    "timed_steps_eager": instrumented if plan_step.recorded_ops else args.steps,
+                    "timed_steps_replayed": args.steps - n_eager if plan_step.recorded_ops else 0,
+                    "timed_steps_eager": n_eager if plan_step.recorded_ops else args.steps,
                     "note": "zs3_amd/plan.py: the step's entry-point calls recorded once (include/zs3hip.h, zs3_plan_*) and replayed from C, "
-                            "bit-identical to the eager step; the steps instrumented for `roofline` (HIP events around sampled launches) run eagerly"}
+                            "bit-identical to the eager step; the `roofline` events of the instrumented steps are recorded by the replay "
+                            "itself (zs3_plan_time_ops) around the sampled launches"}
         if args.bf16_steps > 0 and world == 1 and args.dtype == "bf16x3":
             # the 2-byte mode (BASELINE configs[4] "bf16") on the same model, optimizer and batch: activations and
             # inter-layer gradients stored as bf16, plain bf16 products
@@ -577,6 +598,16 @@ def ddp_one_rank(args, plain_ms):
             "rccl_bytes_per_rank_per_step": d.get("rccl_bytes_per_rank_per_step"), "sync_bn": True, "ranks": 1,
             "workload": "the supervised step of `value` through the N > 1 path: one-rank RCCL group, GradSync buckets (in-place all-reduce "
                         "from the weight-gradient stream), 208 SyncBN all-reduces, globally normalised CE; child process, same GPU"}
+
+
+class _Duration:
+    """a measured duration in the place of an event pair (the records of launches timed inside a plan replay)"""
+
+    def __init__(self, ms):
+        self.ms = ms
+
+    def elapsed_time(self, _end):
+        return self.ms
 
 
 def roofline_of(prof, warm_prof, instrumented, dtype):

@@ -478,6 +478,12 @@ int zs3_plan_set_ptr(long plan, int op, int arg, const void* ptr);
 int zs3_plan_replace_ptr(long plan, const void* old_ptr, const void* new_ptr);
 /* overwrite scalar / host-array argument `arg` (0-based position in the entry point's parameter list) of op with `bytes` bytes */
 int zs3_plan_patch(long plan, int op, int arg, const void* data, int bytes);
+/* HIP-event timing of chosen ops inside ONE replay: zs3_plan_time_ops arms a set of n ascending op indices (-> the set's id, or
+ * < 0; n = 0 disarms); the NEXT zs3_plan_replay records an event pair around each of them on the op's own stream and disarms; after
+ * the caller has synchronised, zs3_plan_timed_ms(plan, set, out_ms, cap) -> the n durations in milliseconds.  Sets stay readable until
+ * the plan is destroyed.  (bench.py: the dominant kernel's launches timed inside replayed steps.) */
+int zs3_plan_time_ops(long plan, const int* ops, int n);
+int zs3_plan_timed_ms(long plan, int set, float* out_ms, int cap);
 /* read argument `arg` of op back (-> its size in bytes; cap = room at out): tests and debugging */
 int zs3_plan_get_arg(long plan, int op, int arg, void* out, int cap);
 /* kind of argument `arg` of op as a character code: 'p' pointer, 's' stream, 'i' int, 'l' long, 'f' float, 'd' double, 'u' unsigned long

@@ -191,6 +191,14 @@ def test_plan_entry_points_record_patch_and_replay(dev):
     assert plan.replace_ptr(x.data_ptr(), x2.data_ptr()) == 1
     plan.replay()
     assert torch.equal(out, ops.affine_act(x2, sc, sh, act=1, drop=(0.5, 2222)))
+    sid = plan.time_ops([0])                     # HIP events around op 0 inside the next replay, on the op's own stream
+    plan.replay()
+    torch.cuda.synchronize()
+    ms = plan.timed_ms(sid, 1)
+    assert len(ms) == 1 and 0.0 < ms[0] < 5.0
+    plan.replay()                                # one-shot: this replay records nothing new, the set stays readable
+    torch.cuda.synchronize()
+    assert plan.timed_ms(sid, 1) == ms and lib().zs3_plan_time_ops(plan.handle, (ctypes.c_int * 2)(0, 0), 2) == -3
     assert lib().zs3_plan_patch(plan.handle, 0, 0, (ctypes.c_float * 1)(1.0), 4) == -4       # pointers are not patched as scalars
     assert lib().zs3_plan_patch(plan.handle, 5, 0, (ctypes.c_float * 1)(1.0), 4) == -1
     plan.close()

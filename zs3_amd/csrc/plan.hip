@@ -26,12 +26,27 @@ struct WaitBlock {
   void* producer;
 };
 
+// HIP-event pairs around chosen ops of ONE replay (bench.py's roofline: the dominant kernel's launches timed inside replayed steps)
+struct TimedSet {
+  std::vector<int> ops;                 // ascending op indices
+  std::vector<hipEvent_t> begin, end;   // one pair per op, recorded on the op's own stream
+};
+
 struct Plan {
   std::vector<Op> ops;
   std::vector<unsigned char> arena;
   std::mutex mu;          // forward launches come from the caller's thread, backward launches from autograd's device thread
   int failed_op = -1;
   int failed_rc = 0;
+  std::vector<TimedSet*> timed;   // every set ever armed (read back by index)
+  int armed = -1;                 // index of the set the NEXT replay records, -1 = none
+  ~Plan() {
+    for (TimedSet* t : timed) {
+      for (hipEvent_t e : t->begin) hipEventDestroy(e);
+      for (hipEvent_t e : t->end) hipEventDestroy(e);
+      delete t;
+    }
+  }
 };
 
 static std::atomic<Plan*> g_recording{nullptr};
@@ -130,8 +145,22 @@ extern "C" int zs3_plan_replay(long plan, int first, int count) {
   const int last = count < 0 ? n : (first + count < n ? first + count : n);
   const unsigned char* base = pl->arena.data();
   static const bool trace = getenv("ZS3_PLAN_TRACE") != nullptr;   // debugging: name every op on stderr and synchronise behind it
+  TimedSet* ts = pl->armed >= 0 ? pl->timed[pl->armed] : nullptr;   // one-shot: this replay records the armed set's events
+  pl->armed = -1;
+  size_t tk = 0;
   for (int i = first; i < last; ++i) {
     const Op& op = pl->ops[i];
+    hipStream_t tstream = nullptr;
+    bool timed_op = false;
+    if (ts) {
+      while (tk < ts->ops.size() && ts->ops[tk] < i) ++tk;
+      if (tk < ts->ops.size() && ts->ops[tk] == i && op.fn != FN_STREAM_WAIT) {
+        const FnDesc& f = plan_fns[op.fn];
+        std::memcpy(&tstream, base + op.offset + f.args[f.nargs - 1].offset, sizeof tstream);   // (the trailing `void* stream`)
+        timed_op = true;
+        hipEventRecord(ts->begin[tk], tstream);
+      }
+    }
     if (trace) {
       fprintf(stderr, "[zs3_plan] op %d %s\n", i, op.fn == FN_STREAM_WAIT ? "zs3_stream_wait" : plan_fns[op.fn].name);
       fflush(stderr);
@@ -145,6 +174,7 @@ extern "C" int zs3_plan_replay(long plan, int first, int count) {
       rc = plan_fns[op.fn].call(base + op.offset);
       if (Plan* rec = plan_recording()) plan_push(rec, op.fn, base + op.offset);
     }
+    if (timed_op) hipEventRecord(ts->end[tk], tstream);
     if (rc == 0 && trace) rc = (int)hipDeviceSynchronize();
     if (rc != 0) {
       pl->failed_op = i;
@@ -153,6 +183,45 @@ extern "C" int zs3_plan_replay(long plan, int first, int count) {
     }
   }
   return 0;
+}
+
+extern "C" int zs3_plan_time_ops(long plan, const int* ops, int n) {
+  Plan* pl = as_plan(plan);
+  if (!pl || n < 0 || (n > 0 && !ops)) return -1;
+  if (n == 0) {
+    pl->armed = -1;
+    return 0;
+  }
+  TimedSet* t = new TimedSet();
+  for (int k = 0; k < n; ++k) {
+    if (ops[k] < 0 || ops[k] >= (int)pl->ops.size() || (k > 0 && ops[k] <= ops[k - 1]) || pl->ops[ops[k]].fn == FN_STREAM_WAIT) {
+      delete t;
+      return -3;
+    }
+    hipEvent_t b = nullptr, e = nullptr;
+    if (hipEventCreate(&b) != hipSuccess || hipEventCreate(&e) != hipSuccess) {
+      delete t;
+      return (int)hipGetLastError();
+    }
+    t->ops.push_back(ops[k]);
+    t->begin.push_back(b);
+    t->end.push_back(e);
+  }
+  pl->timed.push_back(t);
+  pl->armed = (int)pl->timed.size() - 1;
+  return pl->armed;
+}
+
+extern "C" int zs3_plan_timed_ms(long plan, int set, float* out_ms, int cap) {
+  Plan* pl = as_plan(plan);
+  if (!pl || set < 0 || set >= (int)pl->timed.size() || !out_ms) return -1;
+  TimedSet* t = pl->timed[set];
+  const int n = (int)t->ops.size() < cap ? (int)t->ops.size() : cap;
+  for (int k = 0; k < n; ++k) {
+    const hipError_t rc = hipEventElapsedTime(&out_ms[k], t->begin[k], t->end[k]);
+    if (rc != hipSuccess) return -(int)rc - 100;     // (not recorded / not finished: the caller synchronises first)
+  }
+  return n;
 }
 
 extern "C" int zs3_plan_failed_op(long plan) { return plan ? as_plan(plan)->failed_op : -1; }

@@ -105,6 +105,21 @@ class LaunchPlan:
     def patch(self, op, arg, carray):
         check(lib().zs3_plan_patch(self.handle, op, arg, carray, ctypes.sizeof(carray)), "zs3_plan_patch")
 
+    def time_ops(self, indices):
+        """arm HIP-event pairs around these ops (ascending indices) for the NEXT replay -> set id for timed_ms()"""
+        arr = (ctypes.c_int * len(indices))(*indices)
+        rc = lib().zs3_plan_time_ops(self.handle, arr, len(indices))
+        if rc < 0:
+            check(rc, "zs3_plan_time_ops")
+        return rc
+
+    def timed_ms(self, set_id, n):
+        out = (ctypes.c_float * n)()
+        rc = lib().zs3_plan_timed_ms(self.handle, set_id, out, n)
+        if rc < 0:
+            check(rc, "zs3_plan_timed_ms")
+        return list(out)[:rc]
+
     def close(self):
         if self.handle:
             lib().zs3_plan_destroy(self.handle)
@@ -356,6 +371,19 @@ class StepPlan:
             del hold
         finally:
             torch._C._cuda_endAllocateToPool(idx, self._pool.id)
+
+    def conv_ops(self):
+        """indices of the recorded convolution launches (forward and data gradient), in launch order -- the order ops.PROFILE lists
+        them in an eager step"""
+        if self._plan is None:
+            return []
+        return [i for i, n in enumerate(self._plan.names()) if n in ("zs3_conv_igemm", "zs3_conv_igemm_in", "zs3_conv_igemm_bnstats")]
+
+    def time_next_replay(self, indices):
+        return self._plan.time_ops(sorted(indices))
+
+    def timed_ms(self, set_id, n):
+        return self._plan.timed_ms(set_id, n)
 
     @property
     def recorded_ops(self):
