@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "zs3hip.h"
@@ -63,24 +64,35 @@ static void push_raw(Plan* plan, int32_t fn, const void* block, size_t bytes) {
 
 void plan_push(Plan* plan, int fn, const void* block) { push_raw(plan, fn, block, plan_fns[fn].block_bytes); }
 
-// One reusable event per waiting stream: a wait refers to the record that precedes it, so re-recording the event for the next
-// wait of the same stream is safe (the torch.cuda.Event reuse of functional._wait_for, moved under the C ABI so that the
-// dependency can be recorded and replayed).
-static hipEvent_t wait_event_of(hipStream_t waiter) {
+// Events of the waits: a small ring per (waiting stream, producing stream) pair.  A wait refers to the record that precedes it, so
+// an event can be recorded again for a later wait -- but not by leaning on that for back-to-back waits of ONE stream on several
+// producers (the end-of-backward join: main waits for side 0, then side 1; lanes_join likewise): the first version kept one event
+// per waiting stream and re-recorded it for the second producer microseconds after the first wait was enqueued, which is only
+// correct if the runtime binds a wait to the event's state at enqueue time; a pair's ring of four makes no such assumption about
+// any wait younger than three later waits of the same pair.
+struct PairHash {
+  size_t operator()(const std::pair<hipStream_t, hipStream_t>& k) const {
+    return std::hash<void*>()((void*)k.first) * 1000003u ^ std::hash<void*>()((void*)k.second);
+  }
+};
+struct EventRing {
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned next = 0;
+};
+
+static hipEvent_t wait_event_of(hipStream_t waiter, hipStream_t producer) {
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, hipEvent_t> events;
+  static std::unordered_map<std::pair<hipStream_t, hipStream_t>, EventRing, PairHash> rings;
   std::lock_guard<std::mutex> lock(mu);
-  auto it = events.find(waiter);
-  if (it != events.end()) return it->second;
-  hipEvent_t ev = nullptr;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-  events.emplace(waiter, ev);
-  return ev;
+  EventRing& r = rings[std::make_pair(waiter, producer)];
+  hipEvent_t& e = r.ev[r.next++ & 3];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
 }
 
 static int stream_wait_impl(void* waiter, void* producer) {
   if (waiter == producer) return 0;
-  hipEvent_t ev = wait_event_of((hipStream_t)waiter);
+  hipEvent_t ev = wait_event_of((hipStream_t)waiter, (hipStream_t)producer);
   if (!ev) return (int)hipGetLastError();
   hipError_t rc = hipEventRecord(ev, (hipStream_t)producer);
   if (rc != hipSuccess) return (int)rc;
