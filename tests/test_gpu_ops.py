@@ -640,6 +640,41 @@ def test_sgd_resumes_from_a_torch_optim_state_dict(dev):
     assert buf.stride() == pp[0].stride() and rel(buf, opt_r.state[pr[0]]["momentum_buffer"]) < 1e-6
 
 
+@pytest.mark.parametrize("ngroups", [2, 9])
+def test_sgd_groups_as_launch_arguments_and_as_a_packed_table(dev, ngroups):
+    """zs3_amd.optim.SGD against torch.optim.SGD over four steps with a learning rate that changes before every step (what
+    lr_scheduler.py:46-76 does): up to zs3_sgd_max_groups() = 8 parameter groups travel as launch arguments of zs3_sgd_multi_g (the
+    table holds the group index -- the form a recorded plan patches), more groups take the packed {lr, wd} table of zs3_sgd_multi;
+    momentum, weight decay and Nesterov as train_pascal.py:55-60 sets them."""
+    from zs3_amd.optim import SGD
+    g = torch.Generator().manual_seed(5)
+    shapes = [(8, 6, 3, 3), (16, 8, 1, 1), (5,), (4, 3, 7, 7), (33,), (7, 5), (64,), (3, 2, 3, 3), (9,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(4)]
+    per = [list(range(k, len(shapes), ngroups)) for k in range(ngroups)]
+
+    def groups(params):
+        return [{"params": [params[i] for i in idx], "lr": 0.1 * (k + 1), "weight_decay": 1e-4 * k} for k, idx in enumerate(per) if idx]
+
+    pr = [torch.nn.Parameter(t.clone()) for t in init]
+    pp = [torch.nn.Parameter((t.to(dev).contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t.to(dev))) for t in init]
+    opt_r = torch.optim.SGD(groups(pr), momentum=0.9, weight_decay=5e-4, nesterov=True)
+    opt = SGD(groups(pp), momentum=0.9, weight_decay=5e-4, nesterov=True)
+    for it in range(4):
+        for o in (opt_r, opt):
+            for k, grp in enumerate(o.param_groups):
+                grp["lr"] = 0.1 * (k + 1) * (1.0 - 0.2 * it)
+        for p, q, gr in zip(pr, pp, grads[it]):
+            p.grad = gr.clone()
+            gq = gr.to(dev)
+            q.grad = gq.contiguous(memory_format=torch.channels_last) if gq.dim() == 4 else gq
+        opt_r.step()
+        opt.step()
+    torch.cuda.synchronize()
+    for q, p in zip(pp, pr):
+        assert rel(q, p) < 1e-6, tuple(p.shape)
+
+
 def test_sampled_noise_is_keyed_on_the_sampled_pixel(dev):
     """train_pascal_GMMN.py:216,229-236: z is drawn per class pixel and indexed with random_idx, so a pixel sampled twice
     brings the same noise row.  zs3_gather_cat_noise keys row r's noise on noise_key[r]."""
