@@ -289,3 +289,39 @@ def test_training_step_is_bit_reproducible(dev, storage):
     finally:
         ops.set_storage(torch.float32)
         ops.PREC_DEFAULT = 3
+
+
+@pytest.mark.gpu
+def test_generator_rows_stay_fp32_in_the_2_byte_mode():
+    """Round 6: the eager generator path of the GMMN / GCN-context step (images with an unseen class, train_pascal_GMMN.py:242) runs
+    its two Linear layers as row GEMMs; in the 2-byte mode the launcher's default output type is bf16, and the fp32-only row kernels
+    behind it (zs3_scatter_rows ...) then read a bf16 buffer as fp32 -- garbage features and, once in a few runs, a memory fault.
+    The rows keep their own type now, and the row kernels refuse anything but fp32."""
+    from zs3_amd import ops
+    from zs3_amd.gmmn_trainer import _rows_gemm
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(144, 600, generator=g).to(dev)
+    w = (torch.randn(256, 600, generator=g) / 600 ** 0.5).to(dev)
+    b = torch.randn(256, generator=g).to(dev)
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    idx = torch.randperm(289, generator=g)[:144].to(dev)
+    outs = {}
+    for storage in (torch.float32, torch.bfloat16):
+        ops.set_storage(storage)
+        try:
+            y = _rows_gemm(x, ops.prep_weight(w), b)
+            assert y.dtype == torch.float32 and tuple(y.shape) == (144, 256)
+            rows = torch.zeros(289, 256, device=dev)
+            ops.scatter_rows(y, idx, rows)
+            torch.cuda.synchronize()
+            assert torch.equal(rows[idx], y)
+            outs[storage] = y.clone()
+            with pytest.raises(TypeError):
+                ops.scatter_rows(y.bfloat16(), idx, rows)
+            with pytest.raises(TypeError):
+                ops.gather_rows(rows.bfloat16(), idx)
+        finally:
+            ops.set_storage(torch.float32)
+    assert ((outs[torch.float32] - ref).abs().max() / ref.abs().max()).item() < 1e-4           # x3 products
+    assert ((outs[torch.bfloat16] - ref).abs().max() / ref.abs().max()).item() < 2e-2          # plain bf16 products, fp32 rows

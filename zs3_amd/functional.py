@@ -84,7 +84,7 @@ def _wait_for(waiter, producer):
 # (where they were allocated) is ordered behind every side-stream reader.
 PLAN_RECORDING = False
 ASPP_LANES_LAST = True    # the lane branches are the LAST nodes created in ASPP's forward = the first to run in its backward
-ASPP_CONCURRENT = True   # ASPP's branches on three streams in the eager step (modeling/aspp.py); never while a plan records
+ASPP_CONCURRENT = os.environ.get("ZS3_ASPP_LANES", "1") == "1"   # ASPP's two heavy atrous branches on lanes (modeling/aspp.py)
 _plan_keep = []
 PLAN_EPOCH = [0]     # bumped whenever buffers a plan may have recorded are dropped (weight planes, mode switches): plans re-record
 

@@ -40,8 +40,13 @@ from ._lib import F, I, P, check, lib, require_gpu, stream
 
 
 def _rows_gemm(x, wp, b, act=Fz.ACT_NONE, leak=0.2):
+    """One Linear layer of the generator on rows.  The output keeps the rows' own element type -- the generators work on fp32 rows in
+    either storage mode: without `out_dtype` the launcher allocates the activation storage type, and in the
+    2-byte mode the fp32-only row kernels behind this call (zs3_scatter_rows, zs3_gather_rows, the MMD) then read a bf16 buffer as
+    fp32, twice past its end (found in round 6 as a once-in-a-few-runs memory fault of the 2-byte GCN-context test: the generated
+    features of images with an unseen class)."""
     n, c = x.shape
-    y, _ = ops.conv2d_fwd(x.view(1, 1, n, c), wp, shift=b, act=act, leak=leak)
+    y, _ = ops.conv2d_fwd(x.view(1, 1, n, c), wp, shift=b, act=act, leak=leak, out_dtype=x.dtype)
     return y.view(n, wp.cout)
 
 
@@ -406,7 +411,7 @@ class GMMNStep:
         hd_s = ops.gather_rows(hd, ridx)
         dw2 = ops.conv2d_wgrad(d_out.view(1, 1, s, -1), hd_s.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1)
         db2 = ops.colstats(d_out)[:, 0].sum(0)
-        dhd = ops.conv2d_dgrad(d_out.view(1, 1, s, -1), wp2, (1, s)).view(s, -1)
+        dhd = ops.conv2d_dgrad(d_out.view(1, 1, s, -1), wp2, (1, s), out_dtype=d_out.dtype).view(s, -1)     # (fp32 rows: see _rows_gemm)
         if seed is not None:
             dhd = ops.dropout(dhd, drop.p, seed, row_idx=ridx)
         h_s = ops.gather_rows(h, ridx)

@@ -801,6 +801,7 @@ def counter_add2(c0, v0, c1, v1):
 
 
 def gather_cat_noise(a, idx, ca, cb, ldo, n, seed, seed_dev=None, noise_key=None):
+    _fp32_rows(a)
     """[a[idx] | U[0,1)^cb | 0] rows: zs3_gather_cat on a zs3_uniform tensor without materialising the noise.  noise_key:
     optional int64 [n] -- the noise of row r is the noise of "pixel" noise_key[r] (duplicate samples share it)."""
     out = torch.empty((n, ldo), dtype=torch.float32, device=a.device)
@@ -868,7 +869,16 @@ def label_order(target, size):
     return out[0], out[1], hist, out[2]
 
 
+def _fp32_rows(*tensors):
+    """the row kernels (gather / scatter / index_add / gather_cat) move fp32 rows and nothing else: a bf16 tensor handed to them would be
+    read as fp32, twice past its end"""
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError(f"row kernels take fp32 rows, got {t.dtype}")
+
+
 def gather_cat(a, idx, ca, b, cb, ldo):
+    _fp32_rows(a, b)
     n = b.shape[0]
     out = torch.empty((n, ldo), dtype=torch.float32, device=a.device)
     check(lib().zs3_gather_cat(P(a), I(a.stride(0)), P(idx), I(ca), P(b), I(b.stride(0)), I(cb), P(out), I(ldo),
@@ -877,6 +887,7 @@ def gather_cat(a, idx, ca, b, cb, ldo):
 
 
 def gather_rows(src, idx, c=None):
+    _fp32_rows(src)
     c = c or src.shape[1]
     n = idx.shape[0]
     out = torch.empty((n, c), dtype=torch.float32, device=src.device)
@@ -886,6 +897,7 @@ def gather_rows(src, idx, c=None):
 
 
 def scatter_rows(src, idx, out, c=None):
+    _fp32_rows(src, out)
     c = c or src.shape[1]
     check(lib().zs3_scatter_rows(P(src), I(src.stride(0)), P(idx), P(out), I(out.stride(0)), ctypes.c_long(idx.shape[0]),
                                  I(c), stream()), "zs3_scatter_rows")
@@ -893,6 +905,7 @@ def scatter_rows(src, idx, out, c=None):
 
 
 def index_add_rows(src, idx, out, c=None):
+    _fp32_rows(src, out)
     c = c or src.shape[1]
     check(lib().zs3_index_add_rows(P(src), I(src.stride(0)), P(idx), P(out), I(out.stride(0)), I(idx.shape[0]), I(c),
                                    stream()), "zs3_index_add_rows")

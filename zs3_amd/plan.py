@@ -51,6 +51,17 @@ def collectives_recordable():
     return True
 
 
+def _module_scalars(root):
+    """per module of `root`: train / eval and the scalars its launches carry as arguments (dropout probability, BatchNorm momentum /
+    eps), read from the instance dictionaries (a getattr() that misses costs nn.Module an exception: 3 x 500 of them per call was
+    1.5 ms of host time in front of every step)"""
+    out = []
+    for m in root.modules():
+        d = m.__dict__
+        out.append((d.get("training"), d.get("p"), d.get("momentum"), d.get("eps")))
+    return tuple(out)
+
+
 class LaunchPlan:
     """Thin owner of one zs3_plan handle."""
 
@@ -169,7 +180,7 @@ class StepPlan:
     def _fingerprint(self, image, target):
         """everything that decides WHAT the step launches and WHERE its persistent operands live"""
         # per module: train / eval, and the scalars its launches carry as arguments (dropout probability, BatchNorm momentum / eps)
-        mods = tuple((m.training, getattr(m, "p", None), getattr(m, "momentum", None), getattr(m, "eps", None)) for m in self.model.modules())
+        mods = _module_scalars(self.model)
         params = tuple((p.data_ptr(), p.requires_grad) for g in self.optimizer.param_groups for p in g["params"])
         hyper = tuple((g["momentum"], g["nesterov"], g.get("dampening", 0)) for g in self.optimizer.param_groups)
         owner = getattr(self.criterion, "__self__", None)      # SegmentationLosses: class weights, ignore index, batch averaging
@@ -212,7 +223,14 @@ class StepPlan:
             try:
                 prediction, loss = self._eager(image, target)
             finally:
-                nops = plan.end()
+                plan.end()
+        except BaseException:
+            # the step itself failed (out of memory, a shape error): nothing was recorded that anyone will replay
+            plan.close()
+            torch.cuda.synchronize(dev)
+            Fz._plan_keep.clear()
+            self._settled = 0
+            raise
         finally:
             torch._C._cuda_endAllocateToPool(idx, pool.id)
             Fz.next_seed, Fz.PLAN_RECORDING = next_seed, False
@@ -261,10 +279,12 @@ class StepPlan:
 
     def _replay(self, image, target):
         plan = self._plan
-        if self._grads_moved:          # an eager step ran since the last replay and left its own gradient tensors on the parameters:
-            for p, g in self._grads:   # hand the plan's back (the tensors the replayed launches write)
+        # the parameters' .grad are the tensors the replayed launches write -- also after an eager step in between (it left its own
+        # gradient tensors there) or a zero_grad() of the caller's
+        for p, g in self._grads:
+            if p.grad is not g:
                 p.grad = g
-            self._grads_moved = False
+        self._grads_moved = False
         for slot, t in enumerate((image, target)):
             ptr = t.data_ptr()
             if ptr != self._inputs[slot]:
@@ -323,7 +343,8 @@ class StepPlan:
         results bit for bit: loss, prediction, every gradient and every persistent tensor.  `poison`: the pool's free memory -- where
         the plan's activations and workspaces live between replays -- is filled with NaN patterns first, so that a launch missing
         from the plan (a fill or copy the tensor library made while recording) shows up instead of finding last step's bytes.
-        Leaves the model one step further (the eager step's result).  Returns a list of mismatching names (empty = identical)."""
+        Leaves the model one step further (the eager step's result) and DROPS the plan (the next calls settle and record again).
+        Returns a list of mismatching names (empty = identical)."""
         if self._plan is None:
             raise RuntimeError("StepPlan.verify: no recorded plan (call the step warmup + 1 times first)")
         state = self.state_tensors()
@@ -409,8 +430,7 @@ class ForwardPlan:
         self._plans = {}      # fingerprint (stream included) -> state dict
 
     def _fingerprint(self, image):
-        mods = tuple((m.training, getattr(m, "p", None), getattr(m, "momentum", None), getattr(m, "eps", None))
-                     for root in self.modules for m in root.modules())
+        mods = tuple(_module_scalars(root) for root in self.modules)
         params = tuple(p.data_ptr() for root in self.modules for p in root.parameters())
         return (tuple(image.shape), image.dtype, tuple(image.stride()), image.device, mods, params, Fz.PLAN_EPOCH[0], ops.PREC_DEFAULT,
                 ops.ACT_DTYPE, ops.FWD_F16, torch.cuda.current_stream(image.device).cuda_stream)
