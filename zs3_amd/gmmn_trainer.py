@@ -325,7 +325,7 @@ class GMMNStep:
         else:
             ops.conv2d_wgrad(dgen.view(1, 1, s, -1), hd.view(1, 1, s, -1), wp2.cout, wp2.cin, 1, 1, out=st["dw2"])
             ops.colsum(dgen, out=st["db2"])
-            dhd = ops.conv2d_dgrad(dgen.view(1, 1, s, -1), wp2, (1, s)).view(s, -1)
+            dhd = ops.conv2d_dgrad(dgen.view(1, 1, s, -1), wp2, (1, s), out_dtype=dgen.dtype).view(s, -1)     # (fp32 rows: see _rows_gemm)
             dpre = ops.dropout_act_bwd(dhd, h, drop.p if use_drop else 0.0, dseed, lrelu.negative_slope, row_idx=st["ridx"],
                                        seed_dev=st["seed_dev"])
             ops.conv2d_wgrad(dpre.view(1, 1, s, -1), x.view(1, 1, s, -1), wp1.cout, wp1.cin, 1, 1, out=st["dw1"])

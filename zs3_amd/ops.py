@@ -811,6 +811,7 @@ def gather_cat_noise(a, idx, ca, cb, ldo, n, seed, seed_dev=None, noise_key=None
 
 
 def dropout_act_bwd(dy, h, p, seed, leak, row_idx=None, seed_dev=None):
+    _fp32_rows(dy, h)
     m, c, ldd = _rows(dy)
     out = torch.empty((m, c), dtype=torch.float32, device=dy.device)
     check(lib().zs3_dropout_act_bwd(P(dy), I(ldd), P(h), I(_rows(h)[2]), P(out), I(c), ctypes.c_long(m), I(c), F(p),
@@ -835,6 +836,7 @@ def pad_rows(t, cp):
 
 
 def colsum(x, out=None):
+    _fp32_rows(x, out)
     m, c, ld = _rows(x)
     if out is None:
         out = torch.empty(c, dtype=torch.float32, device=x.device)
