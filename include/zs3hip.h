@@ -184,6 +184,11 @@ int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, int lda, cons
 /* SyncBN (sync_batchnorm/batchnorm.py:60-67,101-122): this rank's per-channel fp64 totals of the [chunks][2][C] partial sums and
    its sample count, written as the 2C+1 doubles ONE all-reduce carries across ranks. */
 int zs3_bn_sync_pack(const float* partial, int chunks, int C, double count, double* totals, void* stream);
+/* the same for the BACKWARD sums (sum dz, sum dz * xhat), which are this rank's dbeta / dgamma as they stand: also written as fp32
+   vectors (dgamma, dbeta: C floats each, either may be NULL) -- the per-rank finalize launch of the SyncBN backward folded into the
+   pack (113 launches per step) */
+int zs3_bn_sync_pack_bwd(const float* partial, int chunks, int C, double count, double* totals, float* dgamma, float* dbeta,
+                         void* stream);
 int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,
                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                         float* running_var, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
@@ -434,6 +439,8 @@ int zs3_broadcast(long comm, void* buf, long count, int dtype, int root, void* s
 /* zs3_bn_sync_pack + the SUM all-reduce of its 2C + 1 doubles in one call (batchnorm.py:101-122: the replicas' sum / sum of
  * squares / element count reduced on the master and broadcast back); zs3_bn_*_finalize(chunks = -1) read `totals` afterwards. */
 int zs3_bn_sync_exchange(long comm, const float* partial, int chunks, int C, double count, double* totals, void* stream);
+int zs3_bn_sync_exchange_bwd(long comm, const float* partial, int chunks, int C, double count, double* totals, float* dgamma,
+                             float* dbeta, void* stream);      /* zs3_bn_sync_pack_bwd + the all-reduce of the totals */
 /* global normalisation of the CE behind the all-reduce of loss_ws[1..2] (utils/loss.py: the loss of the gathered batch that
  * nn.DataParallel hands the reference's criterion, loss.py:33-46): loss_ws[0] = loss_ws[2] / loss_ws[1] / global_batch
  * (global_batch <= 0: no batch averaging). */

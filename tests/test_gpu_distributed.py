@@ -146,7 +146,10 @@ def test_one_rank_rccl_step_replays_from_a_plan(dev, one_rank_group):
         assert ce == (6, 0, 0) and cp == (2, 1, 3), (ce, cp)
         assert torch.equal(le, lp), (le, lp)
         assert not [k for k in se if not torch.equal(se[k], sp[k])]
-        assert names.count("zs3_bn_sync_exchange") == 2 * 113 and names.count("zs3_allreduce") >= 3     # buckets + CE + range flag
+        # one exchange per BatchNorm and pass (the backward one also writes this rank's dgamma / dbeta: no per-rank finalize launch)
+        assert names.count("zs3_bn_sync_exchange") == 113 and names.count("zs3_bn_sync_exchange_bwd") == 113
+        assert names.count("zs3_bn_bwd_finalize") == 113
+        assert names.count("zs3_allreduce") >= 3     # buckets + CE + range flag
     finally:
         par.FORCE_COLLECTIVES = False
 

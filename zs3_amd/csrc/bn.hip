@@ -243,15 +243,18 @@ __global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_fwd_finalize_kernel(co
 
 // SyncBN: this rank's fp64 totals and sample count in the layout the all-reduce carries (one launch instead of a cast, a
 // reduction, a fill and two splits on the host side of the exchange)
+// (backward pass: this rank's sums ARE its dbeta / dgamma -- written here, the per-rank finalize launch that produced them is gone)
 template <int FIN_CH, int FIN_GROUPS>
 __global__ __launch_bounds__(FIN_CH * FIN_GROUPS) void bn_sync_pack_kernel(const float* partial, int chunks, int C, double count,
-                                                                          double* out) {
+                                                                          double* out, float* dgamma, float* dbeta) {
   int c;
   double s, q;
   const bool owner = combine_partials<FIN_CH, FIN_GROUPS>(partial, chunks, C, c, s, q);
   if (owner) {
     out[c] = s;
     out[C + c] = q;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * C] = count;
 }
@@ -563,15 +566,25 @@ extern "C" int zs3_bn_bwd_stats(const float* dA, int ldd, const float* a_out, in
   return ZS3_LAUNCH_CHECK();
 }
 
-extern "C" int zs3_bn_sync_pack(const float* partial, int chunks, int C, double count, double* totals, void* stream) {
+static int bn_sync_pack_launch(const float* partial, int chunks, int C, double count, double* totals, float* dgamma, float* dbeta,
+                               void* stream) {
   if (chunks <= 0 || C <= 0 || !totals) return -1;
   if (chunks >= fin_tall_rows())
     hipLaunchKernelGGL((bn_sync_pack_kernel<8, 128>), dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, partial, chunks, C,
-                       count, totals);
+                       count, totals, dgamma, dbeta);
   else
     hipLaunchKernelGGL((bn_sync_pack_kernel<ZS3_FIN_CH, ZS3_FIN_GROUPS>), dim3((C + ZS3_FIN_CH - 1) / ZS3_FIN_CH), dim3(ZS3_FIN_CH * ZS3_FIN_GROUPS), 0, (hipStream_t)stream, partial, chunks, C,
-                       count, totals);
+                       count, totals, dgamma, dbeta);
   return ZS3_LAUNCH_CHECK();
+}
+
+extern "C" int zs3_bn_sync_pack(const float* partial, int chunks, int C, double count, double* totals, void* stream) {
+  return bn_sync_pack_launch(partial, chunks, C, count, totals, nullptr, nullptr, stream);
+}
+
+extern "C" int zs3_bn_sync_pack_bwd(const float* partial, int chunks, int C, double count, double* totals, float* dgamma,
+                                    float* dbeta, void* stream) {
+  return bn_sync_pack_launch(partial, chunks, C, count, totals, dgamma, dbeta, stream);
 }
 
 extern "C" int zs3_bn_fwd_finalize(const float* partial, int chunks, int C, double count, const double* count_dev,

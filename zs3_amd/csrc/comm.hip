@@ -136,3 +136,11 @@ extern "C" int zs3_bn_sync_exchange(long comm, const float* partial, int chunks,
   if (rc != 0) return rc;
   return zs3_allreduce(comm, totals, 2L * C + 1, 1, 0, stream);
 }
+
+// the backward exchange: zs3_bn_sync_pack_bwd (totals + this rank's dgamma / dbeta) and the SUM all-reduce of the totals
+extern "C" int zs3_bn_sync_exchange_bwd(long comm, const float* partial, int chunks, int C, double count, double* totals,
+                                        float* dgamma, float* dbeta, void* stream) {
+  const int rc = zs3_bn_sync_pack_bwd(partial, chunks, C, count, totals, dgamma, dbeta, stream);
+  if (rc != 0) return rc;
+  return zs3_allreduce(comm, totals, 2L * C + 1, 1, 0, stream);
+}

@@ -580,11 +580,15 @@ class _ConvBnAct(torch.autograd.Function):
             gout = (grad_buffer(gamma), grad_buffer(cfg.get("bn_beta"))) if gamma is not None and cfg.get("bn_beta") is not None \
                 else (None, None)
             if sync is not None:
-                from .parallel import combine_bn_partials
-                gpart, gcount = combine_bn_partials(part, m, None if sync is True else sync)
-                fin_l = ops.bn_bwd_finalize(part, m, False, out=gout)       # per-rank dgamma / dbeta (summed later by GradSync)
-                fin_g = ops.bn_bwd_finalize(gpart, gcount, True)  # c1, c2 from the global sums and count
-                dgamma, dbeta, c1, c2 = fin_l[0], fin_l[1], fin_g[2], fin_g[3]
+                from .parallel import combine_bn_partials_bwd
+                # per-rank dgamma / dbeta (summed later by GradSync) come out of the pack launch of the exchange where the library
+                # issues it; c1, c2 from the global sums and count
+                gpart, gcount, dgamma, dbeta = combine_bn_partials_bwd(part, m, None if sync is True else sync, out=gout)
+                if dgamma is None:
+                    fin_l = ops.bn_bwd_finalize(part, m, False, out=gout)
+                    dgamma, dbeta = fin_l[0], fin_l[1]
+                fin_g = ops.bn_bwd_finalize(gpart, gcount, True, want_param_grads=False)
+                c1, c2 = fin_g[2], fin_g[3]
             else:
                 fin = ops.bn_bwd_finalize(part, m, ctx.bn_training, out=gout)
                 dgamma, dbeta = fin[0], fin[1]
@@ -910,7 +914,7 @@ class _BnAct(torch.autograd.Function):
         if cfg["training"] and cfg.get("sync") is not None:
             from .parallel import combine_bn_partials   # dgamma / dbeta stay per rank (summed by GradSync); c1, c2 are global
             gpart, gcount = combine_bn_partials(part, m, None if cfg["sync"] is True else cfg["sync"])
-            fin_g = ops.bn_bwd_finalize(gpart, gcount, True)
+            fin_g = ops.bn_bwd_finalize(gpart, gcount, True, want_param_grads=False)
             c1, c2 = fin_g[2], fin_g[3]
         dy = ops.bn_act_bwd(dA, a, y, st[0], st[1], gamma, c1, c2, act=cfg["act"])
         return dy.reshape(y.shape), fin[0], fin[1], None

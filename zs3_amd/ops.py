@@ -692,6 +692,12 @@ def bn_bwd_finalize(partial, count, use_batch_stats, want_param_grads=True, out=
     without a copy; out = (dgamma buffer or None, dbeta buffer or None): gradient-bucket slices to write them into."""
     partial, chunks, c, chost, cdev = _partial_args(partial, count)
     dev = partial.device
+    if not want_param_grads:      # c1, c2 only (the kernel skips NULL outputs)
+        cc = torch.empty((2, c), dtype=torch.float32, device=dev)
+        base = cc.data_ptr()
+        check(lib().zs3_bn_bwd_finalize(P(partial), I(chunks), I(c), chost, cdev, None, None, base, base + 4 * c,
+                                        I(int(use_batch_stats)), stream()), "zs3_bn_bwd_finalize")
+        return None, None, cc[0], cc[1]
     og, ob = out if out is not None else (None, None)
     # (a FRESH view of the slice: autograd adopts a gradient as .grad without a copy only when nobody else holds that tensor object,
     # and the registered slice itself stays in functional._grad_buffers)

@@ -431,6 +431,25 @@ def combine_bn_partials(partial, count, group=None):
     return buf, None
 
 
+def combine_bn_partials_bwd(partial, count, group=None, out=(None, None)):
+    """The backward exchange of SyncBN: -> (exchange buffer, None, dgamma, dbeta).  With the library's own collectives this rank's
+    dgamma / dbeta (its local sums as they stand) are written by the pack launch itself into `out` (gradient-bucket slices) or fresh
+    vectors; otherwise dgamma = dbeta = None and the caller runs the per-rank finalize as before."""
+    if partial.is_cuda and dist.is_initialized() and native_available(group) and partial.dtype == torch.float32:
+        from ._lib import check, lib, stream
+        c = partial.shape[2]
+        buf = torch.empty(2 * c + 1, dtype=torch.float64, device=partial.device)
+        og, ob = out
+        dgamma = og.view(c) if og is not None and og.numel() == c and og.dtype == torch.float32 else torch.empty(c, dtype=torch.float32, device=partial.device)
+        dbeta = ob.view(c) if ob is not None and ob.numel() == c and ob.dtype == torch.float32 else torch.empty(c, dtype=torch.float32, device=partial.device)
+        st = stream()
+        check(lib().zs3_bn_sync_exchange_bwd(native_comm(st, group), partial.data_ptr(), partial.shape[0], c, float(count),
+                                             buf.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st), "zs3_bn_sync_exchange_bwd")
+        return buf, None, dgamma, dbeta
+    buf, cnt = combine_bn_partials(partial, count, group)
+    return buf, cnt, None, None
+
+
 def enable_sync_bn(module, group=None, enabled=True):
     """SynchronizedBatchNorm2d synchronises across ranks by itself whenever torch.distributed runs with more than one rank
     (modeling/sync_batchnorm/batchnorm.py); this call only selects a process group other than the default one, or switches
