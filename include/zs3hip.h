@@ -432,6 +432,7 @@ int zs3_comm_unique_id_bytes(void);
 int zs3_comm_unique_id(void* id_out);
 long zs3_comm_create(const void* unique_id, int nranks, int rank);
 int zs3_comm_destroy(long comm);
+int zs3_comm_abort(long comm);     /* ncclCommAbort: ends the communicator's collectives in flight (peers that never arrive), frees it */
 int zs3_comm_ranks(long comm);
 /* (a communicator of ONE rank: both collectives return without enqueuing anything -- in place they are the identity) */
 int zs3_allreduce(long comm, void* buf, long count, int dtype, int op, void* stream);

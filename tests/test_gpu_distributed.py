@@ -103,6 +103,47 @@ def test_one_rank_rccl_step_equals_plain_step(dev, one_rank_group):
             assert err <= 1e-5 + 1e-4 * s0[k].abs().max().item(), (k, err)
 
 
+def test_native_probe_and_its_fallback(dev, one_rank_group, monkeypatch):
+    """The first multi-rank use of the library's own communicator checks itself (parallel.native_probe: rank r contributes r + 1,
+    every rank must read the triangular number; verdicts MIN-reduced through torch.distributed).  One rank exercises the code:
+    the good path answers True; a communicator that cannot be created, a wrong sum and a collective that never completes all
+    answer False with a warning, after which the collectives of the step go through torch.distributed."""
+    import zs3_amd.parallel as par
+    assert par.native_probe() is True
+
+    # a wrong sum: the probe believes the group has three ranks (the communicator of the first probe is cached: nothing is created)
+    with monkeypatch.context() as mp:
+        mp.setattr(dist, "get_world_size", lambda g=None: 3)
+        with pytest.warns(UserWarning, match="wrong sum"):
+            assert par.native_probe() is False
+    def broken(*a, **k):
+        raise RuntimeError("zs3_comm_create failed (injected)")
+    with monkeypatch.context() as mp:
+        mp.setattr(par, "native_comm", broken)
+        with pytest.warns(UserWarning, match="torch.distributed instead"):
+            assert par.native_probe() is False
+    assert not par._native_comms                           # (a failed probe destroys the group's communicators)
+    # a collective that never completes: the event never reports done, the communicator is aborted
+    with monkeypatch.context() as mp:
+        mp.setattr(par, "PROBE_TIMEOUT_S", 0.05)
+        mp.setattr(torch.cuda.Event, "query", lambda self: False)
+        with pytest.warns(UserWarning, match="did not complete"):
+            assert par.native_probe() is False
+    assert not par._native_comms
+    # the verdict is what native_available caches for a multi-rank group
+    with monkeypatch.context() as mp:
+        par._native_backend.clear()
+        mp.setattr(par, "native_probe", lambda g=None: False)
+        real = dist.get_world_size
+        mp.setattr(dist, "get_world_size", lambda g=None: 2)
+        assert par.native_available() is False
+        mp.setattr(dist, "get_world_size", real)
+        t = torch.ones(8, device=dev)
+        assert par.native_allreduce(t) is False            # callers take the torch.distributed branch
+    par._native_backend.clear()
+    assert par.native_available() is True
+
+
 def test_one_rank_rccl_step_replays_from_a_plan(dev, one_rank_group):
     """The N > 1 code path as a recorded plan: with the library's own collectives (zs3_allreduce, zs3_bn_sync_exchange) the SyncBN /
     GradSync / global-CE step records and replays like the plain one -- bit-identical to its eager self, collectives included in

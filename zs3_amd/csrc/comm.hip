@@ -24,6 +24,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -70,7 +71,7 @@ extern "C" int zs3_comm_load(const char* librccl_path) {
   }
   g_rccl.handle = h;
   const bool ok = bind(g_rccl.GetUniqueId, "ncclGetUniqueId") && bind(g_rccl.CommInitRank, "ncclCommInitRank") &&
-                  bind(g_rccl.CommDestroy, "ncclCommDestroy") && bind(g_rccl.AllReduce, "ncclAllReduce") &&
+                  bind(g_rccl.CommDestroy, "ncclCommDestroy") && bind(g_rccl.CommAbort, "ncclCommAbort") && bind(g_rccl.AllReduce, "ncclAllReduce") &&
                   bind(g_rccl.Broadcast, "ncclBroadcast") && bind(g_rccl.GetErrorString, "ncclGetErrorString");
   if (!ok) {
     g_rccl = Rccl();
@@ -103,6 +104,15 @@ extern "C" int zs3_comm_destroy(long comm) {
   if (!g_rccl.handle || !comm) return -1;
   Comm* c = reinterpret_cast<Comm*>(comm);
   const int rc = fail(g_rccl.CommDestroy(c->comm), "ncclCommDestroy");
+  delete c;
+  return rc;
+}
+
+// ncclCommAbort: ends the communicator's kernels in flight (a collective whose peers never arrive) and frees it
+extern "C" int zs3_comm_abort(long comm) {
+  if (!g_rccl.handle || !comm) return -1;
+  Comm* c = reinterpret_cast<Comm*>(comm);
+  const int rc = fail(g_rccl.CommAbort(c->comm), "ncclCommAbort");
   delete c;
   return rc;
 }

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "zs3hip.h"
@@ -326,6 +327,15 @@ struct PwArgs {
 
 constexpr int PW_ARRAY = 32 * WS_ROW;   // one 64-channel array of a stage: 32 positions
 
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int PREC, int NCO, int NCI, bool XAFF = false, bool IO16 = false>   // IO16: as conv_wgrad_strip_kernel
 __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
   static_assert(!IO16 || (PREC == 1 && !XAFF), "bf16-stored operands: plain bf16 products, no producer-side transform");
@@ -501,12 +511,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_pw_kernel(const PwArgs p) {
         reads_after(std::integral_constant<int, j>{});
       };
       auto blocks = [&](auto plc) {
-        prod(plc, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        if constexpr (NCI > 1) prod(plc, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        if constexpr (NCO > 1) {
-          prod(plc, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-          if constexpr (NCI > 1) prod(plc, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-        }
+        static_for<NCO * NCI>([&](auto bc) {
+          constexpr int B = decltype(bc)::value;
+          prod(plc, std::integral_constant<int, B / NCI>{}, std::integral_constant<int, B % NCI>{});
+        });
       };
       blocks(std::integral_constant<int, 0>{});
       if constexpr (PREC == 3) {
@@ -627,11 +635,20 @@ struct PwPlan {
   long workspace_floats;
 };
 
-PwPlan pw_plan(long M, int co, int ci) {
+PwPlan pw_plan(long M, int co, int ci, bool prec3 = false) {
   PwPlan s{};
   if (co < 64 || ci < 64 || M < 32 * 12) return s;
   s.nco = co >= 128 ? 2 : 1;
   s.nci = ci >= 128 ? 2 : 1;
+  // wide tiles for the layers whose larger side has >= 1024 channels (x3 products only): a (4, 2) or (2, 4) consumer block reads
+  // 6 arrays per K step for 8 products instead of 4 for 4 -- 25 % fewer operand bytes through L2 and the fabric, 33 % fewer LDS
+  // reads per MFMA
+  // (alone, B = 16 at 33^2: 256 <-> 1024 channels 60.0 -> 56.7 us, 512 <-> 2048 192 -> 170 us; inside the step the change is not
+  // visible: 43.04 / 43.04 / 42.86 against 43.19 / 43.05 / 42.81 ms, tools/probe/ab_quick.sh.  ZS3_WGRAD_PW_WIDE=0 turns it off)
+  static const int wide = getenv("ZS3_WGRAD_PW_WIDE") ? atoi(getenv("ZS3_WGRAD_PW_WIDE")) : 1024;
+  if (wide && prec3 && co >= 256 && ci >= 256 && (co >= wide || ci >= wide)) {
+    if (co >= ci) s.nco = 4; else s.nci = 4;
+  }
   s.lds_bytes = 2 * (s.nco + s.nci) * PW_ARRAY;
   const long steps = (M + 31) / 32;
   const int tiles = ((co + 64 * s.nco - 1) / (64 * s.nco)) * ((ci + 64 * s.nci - 1) / (64 * s.nci));
@@ -695,9 +712,9 @@ int reduce_slabs(const float* workspace, float* dw, long n, int splitk, hipStrea
 // zs3_conv_wgrad_pw_plan returns 1 when the layer is eligible (>= 64 channels on both sides) with the split-K factor and the
 // workspace floats the launch needs, else 0 (use zs3_conv_wgrad).
 extern "C" int zs3_conv_wgrad_pw_plan(long M, int co, int ci, int* splitk_out, long* workspace_floats) {
-  const PwPlan s = pw_plan(M, co, ci);
-  if (splitk_out) *splitk_out = s.splitk;
-  if (workspace_floats) *workspace_floats = s.workspace_floats;
+  const PwPlan s = pw_plan(M, co, ci), w = pw_plan(M, co, ci, true);     // (the caller does not say which products: the larger workspace)
+  if (splitk_out) *splitk_out = s.splitk > w.splitk ? s.splitk : w.splitk;
+  if (workspace_floats) *workspace_floats = s.workspace_floats > w.workspace_floats ? s.workspace_floats : w.workspace_floats;
   return s.ok;
 }
 
@@ -710,7 +727,7 @@ extern "C" int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, flo
   if (io != 0 && io != 3) return -7;                 // one of the two operands bf16: zs3_conv_wgrad
   if (io && (prec != 1 || x_scale)) return -7;       // bf16-stored operands: plain-bf16 products, no transform
   const int io16 = io ? 1 : 0;
-  const PwPlan s = pw_plan(M, co_write, ci_write);
+  const PwPlan s = pw_plan(M, co_write, ci_write, prec == 3 && !io);
   if (!s.ok) return -7;
   if (s.splitk > 1 && (workspace == nullptr || ((uintptr_t)workspace & 15))) return -3;
   PwArgs a{};
@@ -727,8 +744,10 @@ extern "C" int zs3_conv_wgrad_pw(const float* dy, const float* x, float* dw, flo
   hipStream_t st = (hipStream_t)stream;
   const int grid = a.tiles_co * a.tiles_ci * s.splitk;
   int rc;
-  const int key = (prec == 3 ? 4 : 0) + (s.nco == 2 ? 2 : 0) + (s.nci == 2 ? 1 : 0);
+  const int key = s.nco == 4 ? 8 : s.nci == 4 ? 9 : (prec == 3 ? 4 : 0) + (s.nco == 2 ? 2 : 0) + (s.nci == 2 ? 1 : 0);
   switch (key) {
+    case 8: rc = launch_pw<3, 4, 2>(a, grid, s.lds_bytes, io16, st); break;
+    case 9: rc = launch_pw<3, 2, 4>(a, grid, s.lds_bytes, io16, st); break;
     case 0: rc = launch_pw<1, 1, 1>(a, grid, s.lds_bytes, io16, st); break;
     case 1: rc = launch_pw<1, 1, 2>(a, grid, s.lds_bytes, io16, st); break;
     case 2: rc = launch_pw<1, 2, 1>(a, grid, s.lds_bytes, io16, st); break;

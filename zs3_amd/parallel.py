@@ -36,7 +36,9 @@ _native_backend = {}      # id(process group) -> is its backend RCCL?  (asked ~4
 
 
 def native_available(group=None):
-    """can the library issue this group's collectives itself?  (RCCL backend, library loadable)"""
+    """can the library issue this group's collectives itself?  (RCCL backend, library loadable, and -- over several ranks -- the
+    first communicator's all-reduce came back with the right sum on every rank: native_probe).  COLLECTIVE at the first call per
+    process group when it has more than one rank."""
     if not (NATIVE_RCCL and dist.is_initialized()):
         return False
     pg = None if group is True else group
@@ -47,15 +49,65 @@ def native_available(group=None):
             hit = torch.cuda.is_available() and "nccl" in str(dist.get_backend(pg))
         except Exception:
             hit = False
+        if hit and _native_loaded[0] is None:
+            from ._lib import lib
+            path = _os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so")
+            _native_loaded[0] = lib().zs3_comm_load(path.encode() if _os.path.exists(path) else b"") == 0
+        hit = bool(hit and _native_loaded[0])
+        if hit and dist.get_world_size(pg) > 1:
+            hit = native_probe(pg)
         _native_backend.clear()
         _native_backend[key] = hit
-    if not hit:
-        return False
-    if _native_loaded[0] is None:
-        from ._lib import lib
-        path = _os.path.join(_os.path.dirname(torch.__file__), "lib", "librccl.so")
-        _native_loaded[0] = lib().zs3_comm_load(path.encode() if _os.path.exists(path) else b"") == 0
-    return _native_loaded[0]
+    return hit
+
+
+PROBE_TIMEOUT_S = float(_os.environ.get("ZS3_NATIVE_PROBE_TIMEOUT", "60"))
+
+
+def native_probe(group=None):
+    """One all-reduce through the library's own communicator of the current stream, checked on every rank: rank r contributes r + 1,
+    every rank must read world * (world + 1) / 2.  A communicator that cannot be created, a wrong sum, or a collective that does not
+    come back within PROBE_TIMEOUT_S (the communicator is aborted) on ANY rank (the verdicts are MIN-reduced through
+    torch.distributed) sends the whole job to the torch.distributed collectives, with one warning -- the binding in csrc/comm.hip is
+    the one part of the step that a one-GPU box cannot exercise with real peers, so the first multi-rank run checks it itself."""
+    import time
+    import warnings
+    from ._lib import lib, stream
+    pg = None if group is True else group
+    rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+    st, ok, why, comm = stream(), True, "", 0
+    try:
+        comm = native_comm(st, pg)
+        t = torch.full((4,), float(rank + 1), dtype=torch.float32, device="cuda")
+        rc = lib().zs3_allreduce(comm, t.data_ptr(), 4, 0, 0, st)
+        if rc != 0:
+            ok, why = False, f"zs3_allreduce returned {rc}"
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            t0 = time.time()
+            while not ev.query():
+                if time.time() - t0 > PROBE_TIMEOUT_S:
+                    ok, why = False, f"the all-reduce did not complete within {PROBE_TIMEOUT_S:.0f} s"
+                    lib().zs3_comm_abort(comm)
+                    _native_comms.pop((int(st or 0), id(pg) if pg is not None else 0), None)
+                    comm = 0
+                    break
+                time.sleep(0.001)
+            if ok and t.tolist() != [world * (world + 1) / 2.0] * 4:
+                ok, why = False, f"wrong sum {t.tolist()} over {world} ranks"
+    except Exception as e:      # noqa: BLE001 (anything the binding raises: fall back, loudly)
+        ok, why = False, repr(e)
+    verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=pg)
+    if int(verdict.item()) == 1:
+        return True
+    warnings.warn("zs3_amd: the library's own RCCL communicator failed its first all-reduce"
+                  + (f" on this rank ({why})" if why else " on another rank")
+                  + "; the step's collectives go through torch.distributed instead (ZS3_NATIVE_RCCL=0 selects that from the start)")
+    for key in [k for k in _native_comms if k[1] == (id(pg) if pg is not None else 0)]:
+        lib().zs3_comm_destroy(_native_comms.pop(key))
+    return False
 
 
 def native_comm(stream_handle, group=None):
