@@ -123,6 +123,9 @@ def main():
     cpu_info = cpu_baseline(args) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # the step's streams take their hardware queues before the process group creates its own (zs3_amd.functional.warm_streams)
+    from zs3_amd import functional as _Fz
+    _Fz.warm_streams(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

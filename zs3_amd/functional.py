@@ -105,6 +105,33 @@ def wgrad_stream(device):
     return pool[i]
 
 
+def warm_streams(device=None):
+    """Touch the streams of the step in a fixed order -- current (main) stream, the two ASPP lanes, the weight-gradient stream(s) --
+    so that each gets its hardware queue NOW.
+
+    Why: the HIP runtime multiplexes streams onto at most GPU_MAX_HW_QUEUES (default 4) hardware queues, handed out in order of first
+    use, later streams sharing the least-used one; kernels of streams that share a queue run in submission order.  WHICH streams
+    share decides the step (measured with `rocprofv3 --kernel-trace`, tools/probe/db_queues.py, B = 16 at 513^2): main, lane, lane,
+    weight gradient on four queues of their own: 42.4-43.8 ms; the weight-gradient stream on the MAIN stream's queue (what the
+    one-rank N > 1 selftest got through round 6, its streams being created after the process group's): 48.5-49.4 ms, every data
+    gradient followed by a 40-55 us hole on the main stream; two weight-gradient streams on two queues of their own: 52-60 ms (their
+    launches cover all 256 CUs and starve the main chain); raising GPU_MAX_HW_QUEUES beside RCCL's own streams: 58-86 ms.
+    Call it before torch.distributed.init_process_group / the first communicator (bench.py does; a model does at its first forward,
+    which is early enough in a single-process run).  Idempotent and cheap (four 4-byte fills)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index in _warmed:
+        return
+    _warmed.add(device.index)
+    scratch = torch.empty(64, dtype=torch.float32, device=device)
+    order = [torch.cuda.current_stream(device)] + list(lane_streams(device)) + list(wgrad_streams(device))
+    for st in order:
+        ops.check(ops.lib().zs3_fill_zero(scratch.data_ptr(), ctypes.c_long(256), st.cuda_stream), "zs3_fill_zero")
+        st.synchronize()
+
+
+_warmed = set()
+
+
 def join_wgrad_stream():
     """Make the current stream wait for every wgrad launched on the side streams (called at the end of backward)."""
     _join_armed[0] = False
