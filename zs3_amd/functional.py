@@ -38,7 +38,9 @@ _lazy_skip = {}            # data_ptr of a block-output gradient -> (tensor, sig
 # The layers' weight gradients are independent of each other: with WGRAD_STREAMS > 1 they go round-robin over a small pool
 # of side streams, each launch sized (split-K) for its share of the chip (ZS3_WGRAD_CUS, read by zs3_conv_wgrad_plan) --
 # fewer K splits per layer = less split-K slab traffic, the same number of workgroups in flight.
-WGRAD_STREAMS = max(1, int(os.environ.get("ZS3_WGRAD_STREAMS", "2")))   # same-box A/B: 52.85 -> 51.85 ms per step with 2 (3: no further gain)
+# (round 6: the two streams of rounds 3-5 had been sharing ONE hardware queue all along -- see warm_streams -- so they were one
+# stream in effect; on two queues of their own they starve the main chain, 52-60 ms.  One stream: 43.9-44.1 against 43.9-44.2.)
+WGRAD_STREAMS = max(1, int(os.environ.get("ZS3_WGRAD_STREAMS", "1")))
 _side = {}
 _side_next = {}
 _join_armed = [False]
@@ -97,6 +99,18 @@ def wgrad_streams(device):
     return _side[key]
 
 
+def feature_stream(device):
+    """the stream of the GMMN step's prefetched feature pass (gmmn_trainer.GMMNStep.prefetch): one per device, created here so that
+    warm_streams can give it a hardware queue of its own"""
+    key = device.index
+    if key not in _feature:
+        _feature[key] = torch.cuda.Stream(device=device)
+    return _feature[key]
+
+
+_feature = {}
+
+
 def wgrad_stream(device):
     """the side stream the next weight-gradient launch goes to (round-robin over the pool)"""
     pool = wgrad_streams(device)
@@ -123,7 +137,10 @@ def warm_streams(device=None):
         return
     _warmed.add(device.index)
     scratch = torch.empty(64, dtype=torch.float32, device=device)
-    order = [torch.cuda.current_stream(device)] + list(lane_streams(device)) + list(wgrad_streams(device))
+    # (the GMMN step's feature stream takes the fourth queue; the weight-gradient stream, the next one created, then shares it --
+    # the runtime hands a fifth stream the LAST of the least-used queues -- which is idle in the supervised step and carries one
+    # small launch per step in the GMMN step)
+    order = [torch.cuda.current_stream(device)] + list(lane_streams(device)) + [feature_stream(device)] + list(wgrad_streams(device))
     for st in order:
         ops.check(ops.lib().zs3_fill_zero(scratch.data_ptr(), ctypes.c_long(256), st.cuda_stream), "zs3_fill_zero")
         st.synchronize()

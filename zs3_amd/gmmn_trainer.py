@@ -90,6 +90,8 @@ class GMMNStep:
         context_aware: the generator's second input is the image's mean embedding over labelled pixels instead of
         noise (train_context_GMMN_GCNcontext.py:345-348)."""
         self.model = model.module if hasattr(model, "module") else model
+        if torch.cuda.is_available():
+            Fz.warm_streams()        # (hardware queues in a fixed order, the feature stream on its own: functional.warm_streams)
         self.generator = generator
         self.optimizer, self.optimizer_generator = optimizer, optimizer_generator
         self.criterion = criterion
@@ -476,7 +478,7 @@ class GMMNStep:
         if self._feat_stream is None:
             # (a CU-masked stream that leaves 16-64 CUs to the generator loop -- hipExtStreamCreateWithCUMask -- was measured:
             # 61-65 ms per step instead of 38.5: the masked queue slows the convolutions far more than the loop gains)
-            self._feat_stream = torch.cuda.Stream(device=dev)
+            self._feat_stream = Fz.feature_stream(dev)
         self._feat_stream.wait_stream(torch.cuda.current_stream(dev))    # the image (and the previous feature pass) are ready
         with torch.cuda.stream(self._feat_stream):
             real = self._features(image)

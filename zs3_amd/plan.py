@@ -155,6 +155,8 @@ class StepPlan:
         self._one = None
         self._giveup = None          # fingerprint of a configuration whose step turned out not to be replayable
         self._drop()
+        if torch.cuda.is_available():
+            Fz.warm_streams()        # (the step's streams take their hardware queues in a fixed order: functional.warm_streams)
 
     # ------------------------------------------------------------------------------------------------ state
     def _drop(self):
