@@ -481,7 +481,9 @@ class GMMNStep:
             self._feat_stream = Fz.feature_stream(dev)
         self._feat_stream.wait_stream(torch.cuda.current_stream(dev))    # the image (and the previous feature pass) are ready
         with torch.cuda.stream(self._feat_stream):
+            _tick("feat-begin", self._feat_stream)
             real = self._features(image)
+            _tick("feat-end", self._feat_stream)
             done = torch.cuda.Event()
             done.record()
         self._prefetched = (image, real, done)
@@ -525,9 +527,11 @@ class GMMNStep:
                 self._resplit()
             self._dp_ready = True
         real = self._take_features(image)
+        _tick("take")
         if next_image is not None:      # the caller already knows the next batch: overlap its feature pass with this loop
             self.prefetch(next_image)   # (queued before the loop: 38.5 ms per step; after it: 39.9 ms; with the loop on a
             # high-priority stream: 101 ms -- HIP priority streams misbehave on this runtime, as in round 1)
+            _tick("prefetch")
         fh, fw, d = real.shape[1], real.shape[2], real.shape[3]
         npix = fh * fw
         if self._st is None or self._st["shape"] != (b, npix) or self._st.get("adam_sig") != self._adam_signature():
@@ -548,6 +552,7 @@ class GMMNStep:
         tgt_l, tgt_cls, hist, order = ops.label_order(target, (fh, fw))                           # [B, npix] int64 each
         self._before_images(tgt_l.view(b, fh, fw))
         hist_h = hist.cpu().tolist()
+        _tick("hist")
         if table is not None:
             table_f = table.contiguous().float()
         training = self.generator.training
@@ -600,6 +605,7 @@ class GMMNStep:
         if n_mmd > st["ring"].shape[0]:
             st["ring"] = torch.zeros((n_mmd, self.bsg), dtype=torch.int64).pin_memory()
         st["ring_pos"] = 0
+        _tick("table")
         pending = 0        # table mode: sampled updates queued but not yet replayed
         # a subclass hook after every image forces the queued generator updates out first only if it reads the generator
         per_image_hook = type(self)._after_image is not GMMNStep._after_image and self._hook_reads_generator
@@ -715,6 +721,7 @@ class GMMNStep:
                 pending = 0
             self._after_image(i, tgt_l[i].view(fh, fw), real_rows[i], has_unseen)
         self._join_side_work()       # (subclasses: per-image work that was queued on another stream)
+        _tick("loop")
         pg = None if self.group is True else self.group
         if self.group is not None:   # generator replicas -> their average (parameters only; Adam moments stay per rank)
             from .parallel import all_reduce_tensors
@@ -736,6 +743,7 @@ class GMMNStep:
             from .parallel import exchange_range_flag
             exchange_range_flag(dev, pg)
         self.optimizer.step()
+        _tick("classifier")
         if ring_slots:
             if n_ring > st["loss_ring"].numel():
                 raise RuntimeError("more generator updates in one step than the loss ring holds")
@@ -747,6 +755,7 @@ class GMMNStep:
         if ops._range_flags:
             tail.append(ops.range_flag(dev).float())
         vals = torch.cat((mmd_losses, *tail)).cpu()
+        _tick("readback")
         if len(tail) == 2:
             if float(vals[-1]) != 0.0:
                 Fz.check_forward_range(flag_value=1)     # lowers the flag, warns, bf16x3 forward products from here on
@@ -754,6 +763,17 @@ class GMMNStep:
         g_batch = sum(float(vals[sl]) / nuniq for sl, nuniq in mmd_slots)
         self.last_updates = len(mmd_slots)
         return g_batch, float(vals[-1]), out
+
+
+_TICKS = [] if os.environ.get("ZS3_GMMN_TICKS") else None      # host time stamps inside GMMNStep.__call__ (tools/probe)
+
+
+def _tick(tag, stream_obj=None):
+    if _TICKS is not None:
+        import time
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream_obj) if stream_obj is not None else ev.record()
+        _TICKS.append((tag, time.perf_counter(), ev))
 
 
 class GMMNTrainer:
