@@ -91,42 +91,10 @@ _plan_keep = []
 PLAN_EPOCH = [0]     # bumped whenever buffers a plan may have recorded are dropped (weight planes, mode switches): plans re-record
 
 
-# CU masks (probe switches, off by default): the KFD deals the bits of a queue's CU mask round-robin over the 8 XCDs first (bit i ->
-# XCD i % 8), then over the shader engines of an XCD, so "the low 8 k bits" is k CUs of every XCD.  ZS3_WGRAD_MASK_CUS = k: the
-# weight-gradient stream may only use k CUs per XCD (the main chain keeps 32 - k per XCD to itself); ZS3_FEATURE_RESERVE_CUS = k:
-# the GMMN step's feature stream and the lanes stay off k CUs per XCD (the generator loop's 64-workgroup launches find them free).
-WGRAD_MASK_CUS = int(os.environ.get("ZS3_WGRAD_MASK_CUS", "0"))
-FEATURE_RESERVE_CUS = int(os.environ.get("ZS3_FEATURE_RESERVE_CUS", "0"))
-_hip_rt = []
-
-
-def _masked_stream(device, first_bit, n_bits):
-    """a stream whose queue may use the CUs [first_bit, first_bit + n_bits) of the 256-bit mask (hipExtStreamCreateWithCUMask)"""
-    if not _hip_rt:
-        _hip_rt.append(ctypes.CDLL("libamdhip64.so"))
-    words = (ctypes.c_uint32 * 8)()
-    for b in range(first_bit, first_bit + n_bits):
-        words[b // 32] |= 1 << (b % 32)
-    handle = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = _hip_rt[0].hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(8), words)
-    if rc != 0:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask: {rc}")
-    return torch.cuda.ExternalStream(handle.value, device=device)
-
-
-def _side_stream(device, kind):
-    if kind == "wgrad" and WGRAD_MASK_CUS > 0:
-        return _masked_stream(device, 0, 8 * WGRAD_MASK_CUS)
-    if kind in ("feature", "lane") and FEATURE_RESERVE_CUS > 0:
-        return _masked_stream(device, 8 * FEATURE_RESERVE_CUS, 256 - 8 * FEATURE_RESERVE_CUS)
-    return torch.cuda.Stream(device=device)
-
-
 def wgrad_streams(device):
     key = device.index
     if key not in _side:
-        _side[key] = [_side_stream(device, "wgrad") for _ in range(WGRAD_STREAMS)]
+        _side[key] = [torch.cuda.Stream(device=device) for _ in range(WGRAD_STREAMS)]
         _side_next[key] = 0
     return _side[key]
 
@@ -136,7 +104,7 @@ def feature_stream(device):
     warm_streams can give it a hardware queue of its own"""
     key = device.index
     if key not in _feature:
-        _feature[key] = _side_stream(device, "feature")
+        _feature[key] = torch.cuda.Stream(device=device)
     return _feature[key]
 
 
@@ -211,7 +179,7 @@ _lanes_armed = [False]
 def lane_streams(device, n=2):
     key = device.index
     if key not in _lanes or len(_lanes[key]) < n:
-        _lanes[key] = [_side_stream(device, "lane") for _ in range(n)]
+        _lanes[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _lanes[key]
 
 
