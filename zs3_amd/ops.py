@@ -167,10 +167,16 @@ def pick_tile(m, ncols, k=0, taps=1):
     if m >= 8192 and k >= 512 and ncols >= 256 and (taps > 1 or ((m + 255) // 256) * ((ncols + 127) // 128) >= SMALL_LAUNCH_TILES):
         return 31 if DMA_RULE else 11    # (multi-tap layers: the strip-resident kernel is asked next, _choose_tile)
     if ncols >= 256 and 128 <= k <= 256:
-        return 14    # 1x1 layers with a short K and many column tiles (256->1024 @33^2, 128->512 @65^2, their dgrads): 4-9 % faster per layer, 52.2 -> 51.7 ms per step in a same-box A/B
-    return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 1000 else 14
+        # 1x1 layers with a short K and many column tiles that the persistent pointwise kernel does not take (the loading epilogues:
+        # layer 3's conv1 data gradient 256 -> 1024 @33^2 with residual + BatchNorm-backward sums, 22 launches per step, and the
+        # 128 -> 512 @65^2 ones).  Round 2 put them on 64 x 64 tiles (4-9 % faster per layer alone, 52.2 -> 51.7 ms per step then);
+        # re-checked inside the round-6 step (tools/probe/r6t.sh, same box, interleaved): 128 x 128 tiles 42.37 / 42.39 ms against
+        # 42.62 / 42.63 -- the round-4 epilogue (operands of four rows fetched ahead) amortises over the larger tile
+        return SHORTK_TILE
+    return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= TILE_SWITCH else 14
 
 
+SHORTK_TILE, TILE_SWITCH = 11, 1000
 PW_MAXK = 512      # longest reduction the persistent pointwise kernel takes (longer: the LDS-DMA kernel)
 
 
@@ -362,7 +368,12 @@ def _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw,
         return 52
     if ncols <= 64:
         return 14
-    return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= 512 else 14
+    return 11 if ((m + 127) // 128) * ((ncols + 127) // 128) >= TILE16_SWITCH else 14
+
+
+# 2-byte mode: 128 x 128 tiles from this many of them, 64 x 64 below.  512 through round 5; inside the round-6 step (r6t.sh): always
+# 128 x 128 27.16 / 27.16 ms, switch at 512: 27.38 / 27.46, at 1200: 27.43 / 27.54, at 3000: 27.96 / 27.94, always 64 x 64: 27.95 / 28.04
+TILE16_SWITCH = 0
 
 
 def conv_igemm(x, w_pk, *, ho, wo, cin_pad, cin_valid, kh, kw, stride, pad_h, pad_w, dil, ncols, out=None,
