@@ -302,11 +302,14 @@ def conv_out_size(h, k, stride, pad, dil):
 
 
 _TILE_CHOICE, _MTILES = {}, {}
+TILE_OVERRIDE = {}     # (m, ncols, cin, taps, stride, dgrad, store-only epilogue, io) -> tile_cfg, set by A/B probes before the first launch
 
 
 def _choose_tile(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad, prec,
                  pw_epilogue, io=0):
     """tile_cfg of a conv launch: the caller's explicit choice where that kernel can run the launch, else the rules."""
+    if TILE_OVERRIDE and tile_cfg == 0:     # probe: one geometry on another kernel (tools/probe/r6q.sh)
+        tile_cfg = TILE_OVERRIDE.get((m, ncols, min(cin_pad, cin_valid), kh * kw, stride, int(bool(dgrad)), int(bool(pw_epilogue)), io), 0)
     if io:
         return _choose_tile16(tile_cfg, xshape, m, ho, wo, cin_pad, cin_valid, ldx, kh, kw, stride, pad_h, pad_w, dil, ncols, dgrad,
                               prec, pw_epilogue, io)
