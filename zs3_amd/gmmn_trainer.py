@@ -57,6 +57,11 @@ CHAIN_MAX = max(1, int(os.environ.get("ZS3_GMMN_CHAIN", "32")))
 CHAIN_SIZES = tuple(1 << k for k in range(CHAIN_MAX.bit_length() - 1, -1, -1))
 
 
+# ASPP's atrous branches side by side on the lanes (functional.py) inside this step's frozen-backbone feature pass.  Off: the pass shares
+# the chip with the generator loop of the previous batch, whose 64-workgroup launches wait for free CU slots; three streams of big
+# convolutions instead of one leave it fewer (same box, interleaved, tools/probe/r6p.sh: 26.18 / 26.21 ms per step with the lanes,
+# **25.00 / 24.94 without**; the supervised step, where nothing latency-bound runs beside the pass, keeps them: +2.6 ms without)
+FEATURE_LANES = False
 FEATURE_PLAN = os.environ.get("ZS3_PLAN", "1") == "1"   # the frozen-backbone feature pass replayed from a recorded plan (plan.ForwardPlan)
 
 
@@ -452,7 +457,13 @@ class GMMNStep:
     def _features_eager(self, image):
         # [B, fh, fw, D]; in the 2-byte mode the backbone hands over bf16 features: the generator loop, the MMD kernels and the
         # cluster graphs work on fp32 rows (273 MB at B = 16: one cast pass, ~0.1 ms)
-        return ops.cast(ops.nhwc(self.model.forward_before_class_prediction(image)), torch.float32)
+        lanes = Fz.ASPP_CONCURRENT
+        if not FEATURE_LANES:
+            Fz.ASPP_CONCURRENT = False
+        try:
+            return ops.cast(ops.nhwc(self.model.forward_before_class_prediction(image)), torch.float32)
+        finally:
+            Fz.ASPP_CONCURRENT = lanes
 
     def _features(self, image):
         """The frozen-backbone feature pass as a recorded launch plan (zs3_amd.plan.ForwardPlan): ~330 launches whose Python enqueue
