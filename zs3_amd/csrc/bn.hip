@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void group_colsum_kernel(const float* x_, int 
 // form on the largest ones (6.5 TB/s against 6.0), and every thread pays its seven per-channel operand loads for one element.
 // Inside the step (same box, interleaved, identical losses): fp32 storage 43.91 / 44.04 ms at 16384, 43.81 / 43.80 at 2048,
 // 42.67 at 4096 against 43.85 at 512; 2-byte mode 28.82 / 28.68 at 16384, 27.71 / 27.76 at 8192, **27.43 / 27.37 at 4096**,
-// 27.55 / 27.50 at 2048, 27.62 / 27.64 at 1024, 28.94 / 28.90 at 512 (tools/probe/r6z.sh, r6z2.sh; ZS3_EW_MAXBLOCKS overrides).
+// 27.55 / 27.50 at 2048, 27.62 / 27.64 at 1024, 28.94 / 28.90 at 512 (tools/probe/r6z2.sh; ZS3_EW_MAXBLOCKS overrides).
 // Four-elements-in-flight, branch-free forms of the two kernels (bit-identical, 20-25 % faster alone on the 17-70 MB tensors, slower
 // on the 270 MB ones) bought nothing beyond the cap inside the step and were not kept (docs/LAB_NOTES.md).
 inline int ew_blocks(long total) {
