@@ -62,6 +62,11 @@ CHAIN_SIZES = tuple(1 << k for k in range(CHAIN_MAX.bit_length() - 1, -1, -1))
 # convolutions instead of one leave it fewer (same box, interleaved, tools/probe/r6p.sh: 26.18 / 26.21 ms per step with the lanes,
 # **25.00 / 24.94 without**; the supervised step, where nothing latency-bound runs beside the pass, keeps them: +2.6 ms without)
 FEATURE_LANES = False
+# ... and its persistent pointwise launches (conv_pw.hip: 34 per pass, two resident workgroups per CU, each launch holding its CUs for
+# 60-140 us) on 192 x 2 workgroups instead of 256 x 2: some CUs stay free for the loop all through those launches.  Same box, interleaved
+# (tools/probe/r6i.sh, r6i2.sh): 25.59 / 25.77 -> 24.49 / 24.69 ms on one box, 24.77 / 25.08 -> 24.40 / 24.45 on another (160-224 within
+# 0.2 ms of that; 128: 25.2-25.4).  The supervised step keeps 256 (192 there: 42.00 / 42.03 against 42.18 / 42.04, noise).  0 = leave alone.
+FEATURE_PW_WGS = 192
 FEATURE_PLAN = os.environ.get("ZS3_PLAN", "1") == "1"   # the frozen-backbone feature pass replayed from a recorded plan (plan.ForwardPlan)
 
 
@@ -469,14 +474,20 @@ class GMMNStep:
         """The frozen-backbone feature pass as a recorded launch plan (zs3_amd.plan.ForwardPlan): ~330 launches whose Python enqueue
         took as long as the pass runs on the GPU (14-15 ms: the next batch's pass could not start overlapping the generator loop
         until the host was done with it) replayed with one C call."""
-        with torch.no_grad():
-            if not FEATURE_PLAN:
-                return self._features_eager(image)
-            fp = self.__dict__.get("_feature_plan")
-            if fp is None:
-                from .plan import ForwardPlan
-                fp = self.__dict__["_feature_plan"] = ForwardPlan(self._features_eager, [self.model])
-            return fp(image)
+        # (the persistent pointwise kernel's launches size themselves when they are enqueued -- recorded or replayed -- from this setting)
+        prev = lib().zs3_conv_pw_set_wgs(FEATURE_PW_WGS) if FEATURE_PW_WGS else 0
+        try:
+            with torch.no_grad():
+                if not FEATURE_PLAN:
+                    return self._features_eager(image)
+                fp = self.__dict__.get("_feature_plan")
+                if fp is None:
+                    from .plan import ForwardPlan
+                    fp = self.__dict__["_feature_plan"] = ForwardPlan(self._features_eager, [self.model])
+                return fp(image)
+        finally:
+            if prev:
+                lib().zs3_conv_pw_set_wgs(prev)
 
     def prefetch(self, image):
         """Start the feature pass of the NEXT batch on a side stream.  The backbone is frozen in this step (only `pred_conv`
