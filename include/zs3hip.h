@@ -108,6 +108,11 @@ int zs3_conv_halo_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_v
 int zs3_conv_pw_ok(int N, int H, int W, int Ho, int Wo, int cin_pad, int cin_valid, int ldx, int KH, int KW, int stride,
                    int pad_h, int pad_w, int tile_cfg);
 int zs3_conv_pw_set_wgs(int wgs);
+/* zs3_conv_halo_set_wgs: workgroups per launch of the strip-resident kernel (tile_cfg 41 / 42): 0 (default) = one per tile, n > 0 =
+ * launches with more tiles run on n workgroups walking the tiles, all handed out at once -- a kernel of another stream then starts beside
+ * the launch instead of waiting for its rounds (the GMMN step's frozen feature pass beside the generator's update chain).  Returns the
+ * previous setting. */
+int zs3_conv_halo_set_wgs(int wgs);
 /* zs3_conv_igemm (no affine / activation) with the two backward-pass epilogue fusions of the residual network:
  * (1) bn_partial != NULL: the epilogue also produces the BatchNorm-backward sums of the layer the output gradient belongs
  *     to: bn_partial[mtiles][2][ncols] = (sum dz, sum dz*xhat) per row tile, with dz = stored value * ReLU mask and

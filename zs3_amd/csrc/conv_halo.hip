@@ -43,6 +43,7 @@ struct HaloGeom {
   int sgn;         // +1 forward, -1 dgrad (tap offsets mirrored)
   int toff0, tstep_col, tstep_row;   // flattened-pixel offset of tap 0; its change to the next tap in a row / to the next row's first tap
   int lds_bytes;
+  int ntiles;      // row tiles x column tiles of the launch (the grid, unless zs3_conv_halo_set_wgs caps it)
 };
 
 constexpr int HALO_BSLOT = 8192, HALO_NSLOT = 2;   // weight tiles in LDS: the one being multiplied and the next (three more are in flight in registers)
@@ -82,7 +83,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = (p.ncols + BN - 1) / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // One tile per workgroup (grid = tiles), or -- zs3_conv_halo_set_wgs -- a grid of at most that many workgroups that walk the tiles
+  // t, t + grid, ...: every workgroup of the launch is handed out at once.  A kernel of another hardware queue starts beside such a
+  // launch almost as if the chip were idle, beside a many-round launch it waits ~35 us (tools/probe/queue_gate.py: a chain of 5 us
+  // launches runs at 5.9 us per launch beside the 182-tile layer-3 launch, at 38 us beside the 2774-tile decoder launch); the GMMN
+  // step's frozen feature pass runs beside the generator's update chain (gmmn_trainer.FEATURE_HALO_WGS).
+  const int ntiles = g.ntiles;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  const int tile = xcd_remap(t, ntiles);
   const int mt = tile / ntn, nt = tile - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
   const int T = g.T, NS = g.nch * T, NSR = g.ns;
@@ -472,7 +480,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     store_tile_rows<RPP, (BM == 256 ? 2 : 4)>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
   }
   if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
+  if (t + (int)gridDim.x < ntiles) __syncthreads();   // (a further tile: its producers overwrite the LDS the epilogue staged through)
+  }
 }
+
+int g_halo_wgs = 0;      // zs3_conv_halo_set_wgs: > 0 = launches with more tiles run on this many workgroups (a multiple of 8: xcd_remap)
 
 bool halo_geometry(const ConvArgs& a, int bm, int prec, HaloGeom* out) {
   const int T = a.KH * a.KW;
@@ -520,8 +532,10 @@ int launch_halo_n(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
       return -4;
     configured = true;
   }
-  const int grid = ((a.M + BM - 1) / BM) * ((a.ncols + 127) / 128);
-  hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG, A16, INAFF>), dim3(grid), dim3(512), g.lds_bytes, st, a, g);
+  HaloGeom gg = g;
+  gg.ntiles = ((a.M + BM - 1) / BM) * ((a.ncols + 127) / 128);
+  const int grid = (g_halo_wgs > 0 && gg.ntiles > g_halo_wgs) ? g_halo_wgs : gg.ntiles;
+  hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG, A16, INAFF>), dim3(grid), dim3(512), g.lds_bytes, st, a, gg);
   return ZS3_LAUNCH_CHECK();
 }
 template <int PREC, int BM, bool A16 = false, bool INAFF = false>
@@ -559,6 +573,14 @@ int zs3conv::launch_halo(const ConvArgs& a, int bm, int prec, hipStream_t st) {
   if (bm == 256)
     return prec == 1 ? launch_halo_t<1, 256>(a, g, st) : prec == 4 ? launch_halo_t<4, 256>(a, g, st) : launch_halo_t<3, 256>(a, g, st);
   return prec == 1 ? launch_halo_t<1, 192>(a, g, st) : prec == 4 ? launch_halo_t<4, 192>(a, g, st) : launch_halo_t<3, 192>(a, g, st);
+}
+
+// Workgroups per launch of the strip-resident kernel: 0 (default) = one per tile; n > 0 = launches with more than n tiles run on n
+// workgroups that walk the tiles (every workgroup handed out at once: see the kernel).  Returns the previous setting.
+extern "C" int zs3_conv_halo_set_wgs(int wgs) {
+  const int old = g_halo_wgs;
+  g_halo_wgs = wgs > 0 ? (wgs + 7) / 8 * 8 : 0;
+  return old;
 }
 
 // Whether tile_cfg 41 / 42 can run this convolution (callers fall back to tile_cfg 31 otherwise): 0 = no, otherwise the number

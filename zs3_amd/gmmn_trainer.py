@@ -67,6 +67,11 @@ FEATURE_LANES = False
 # (tools/probe/r6i.sh, r6i2.sh): 25.59 / 25.77 -> 24.49 / 24.69 ms on one box, 24.77 / 25.08 -> 24.40 / 24.45 on another (160-224 within
 # 0.2 ms of that; 128: 25.2-25.4).  The supervised step keeps 256 (192 there: 42.00 / 42.03 against 42.18 / 42.04, noise).  0 = leave alone.
 FEATURE_PW_WGS = 192
+# ... and its strip-resident launches with more tiles than this (the decoder's 3x3 layers at 129^2: 2774 tiles, layer 2's at 65^2) on this
+# many workgroups that walk the tiles (zs3_conv_halo_set_wgs).  A launch handed out in one go and 32 CUs short of the chip: beside it the
+# update chain's launches start as if the chip were idle (tools/probe/queue_gate.py: 6.5 us per launch against 47 beside the one-tile-
+# per-workgroup launch, 4.8 alone; the convolution itself 960 against 967 us).  0 = one workgroup per tile.
+FEATURE_HALO_WGS = 224
 FEATURE_PLAN = os.environ.get("ZS3_PLAN", "1") == "1"   # the frozen-backbone feature pass replayed from a recorded plan (plan.ForwardPlan)
 
 
@@ -476,6 +481,7 @@ class GMMNStep:
         until the host was done with it) replayed with one C call."""
         # (the persistent pointwise kernel's launches size themselves when they are enqueued -- recorded or replayed -- from this setting)
         prev = lib().zs3_conv_pw_set_wgs(FEATURE_PW_WGS) if FEATURE_PW_WGS else 0
+        prev_halo = lib().zs3_conv_halo_set_wgs(FEATURE_HALO_WGS) if FEATURE_HALO_WGS else None
         try:
             with torch.no_grad():
                 if not FEATURE_PLAN:
@@ -488,6 +494,8 @@ class GMMNStep:
         finally:
             if prev:
                 lib().zs3_conv_pw_set_wgs(prev)
+            if prev_halo is not None:
+                lib().zs3_conv_halo_set_wgs(prev_halo)
 
     def prefetch(self, image):
         """Start the feature pass of the NEXT batch on a side stream.  The backbone is frozen in this step (only `pred_conv`
