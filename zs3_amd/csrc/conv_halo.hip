@@ -73,7 +73,7 @@ constexpr int HALO_MAXP = 3;
 // INAFF: the producers apply x' = max(x * in_scale[c] + in_shift[c], 0) before the split -- the BatchNorm-apply + ReLU of the layer
 // that produced x, whose activation tensor then never exists in memory (two VALU operations per element in waves that have
 // the slack; an instantiation of its own, so the plain kernel's code is untouched).
-template <int PREC, int BM, int NPG, bool A16 = false, bool INAFF = false>
+template <int PREC, int BM, int NPG, bool A16 = false, bool INAFF = false, bool PERSIST = false>
 __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const HaloGeom g) {
   static_assert(!A16 || PREC == 1, "bf16-stored input: plain bf16 products only");
   static_assert(!(A16 && INAFF), "the input transform reads fp32 storage");
@@ -83,14 +83,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntn = (p.ncols + BN - 1) / BN;
-  // One tile per workgroup (grid = tiles), or -- zs3_conv_halo_set_wgs -- a grid of at most that many workgroups that walk the tiles
-  // t, t + grid, ...: every workgroup of the launch is handed out at once.  A kernel of another hardware queue starts beside such a
+  // One tile per workgroup (grid = tiles), or -- PERSIST, zs3_conv_halo_set_wgs -- a grid of at most that many workgroups that walk the
+  // tiles t, t + grid, ...: every workgroup of the launch is handed out at once.  An instantiation of its own: the loop around the tile
+  // costs the allocator its last registers (230 -> 256 with 32-124 spilled), the one-tile kernel stays as it was.  A kernel of another hardware queue starts beside such a
   // launch almost as if the chip were idle, beside a many-round launch it waits ~35 us (tools/probe/queue_gate.py: a chain of 5 us
   // launches runs at 5.9 us per launch beside the 182-tile layer-3 launch, at 38 us beside the 2774-tile decoder launch); the GMMN
   // step's frozen feature pass runs beside the generator's update chain (gmmn_trainer.FEATURE_HALO_WGS).
-  const int ntiles = g.ntiles;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-  const int tile = xcd_remap(t, ntiles);
+  int t = blockIdx.x;
+  do {
+  const int tile = PERSIST ? xcd_remap(t, g.ntiles) : xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / ntn, nt = tile - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
   const int T = g.T, NS = g.nch * T, NSR = g.ns;
@@ -480,8 +481,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ConvArgs p, const 
     store_tile_rows<RPP, (BM == 256 ? 2 : 4)>(p, ctile, LDC, m0 + half * (BM / 2), BM / 2, col, c4, r0, sc, sh, affine, vec, bs_s, bs_q);
   }
   if (p.bs_partial) finish_bwd_stats<BN, RPP, 512>(p, ctile, tid, c4, r0, mt, n0, bs_s, bs_q);
-  if (t + (int)gridDim.x < ntiles) __syncthreads();   // (a further tile: its producers overwrite the LDS the epilogue staged through)
-  }
+  if constexpr (!PERSIST) break;
+  t += gridDim.x;
+  if (t >= g.ntiles) break;
+  __syncthreads();   // (a further tile: its producers overwrite the LDS the epilogue staged through)
+  } while (true);
 }
 
 int g_halo_wgs = 0;      // zs3_conv_halo_set_wgs: > 0 = launches with more tiles run on this many workgroups (a multiple of 8: xcd_remap)
@@ -534,7 +538,21 @@ int launch_halo_n(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
   }
   HaloGeom gg = g;
   gg.ntiles = ((a.M + BM - 1) / BM) * ((a.ncols + 127) / 128);
-  const int grid = (g_halo_wgs > 0 && gg.ntiles > g_halo_wgs) ? g_halo_wgs : gg.ntiles;
+  // the tile-walking form exists for the 192-row forward instantiations (f16x3 and plain bf16): what a frozen feature pass launches
+  if constexpr (BM == 192 && (PREC == 4 || PREC == 1)) {
+    if (g_halo_wgs > 0 && gg.ntiles > g_halo_wgs && !a.dgrad) {
+      static bool configured_p = false;
+      if (!configured_p) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<PREC, BM, NPG, A16, INAFF, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          return -4;
+        configured_p = true;
+      }
+      hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG, A16, INAFF, true>), dim3(g_halo_wgs), dim3(512), g.lds_bytes, st, a, gg);
+      return ZS3_LAUNCH_CHECK();
+    }
+  }
+  const int grid = gg.ntiles;
   hipLaunchKernelGGL((conv_halo_kernel<PREC, BM, NPG, A16, INAFF>), dim3(grid), dim3(512), g.lds_bytes, st, a, gg);
   return ZS3_LAUNCH_CHECK();
 }

@@ -68,10 +68,12 @@ FEATURE_LANES = False
 # 0.2 ms of that; 128: 25.2-25.4).  The supervised step keeps 256 (192 there: 42.00 / 42.03 against 42.18 / 42.04, noise).  0 = leave alone.
 FEATURE_PW_WGS = 192
 # ... and its strip-resident launches with more tiles than this (the decoder's 3x3 layers at 129^2: 2774 tiles, layer 2's at 65^2) on this
-# many workgroups that walk the tiles (zs3_conv_halo_set_wgs).  A launch handed out in one go and 32 CUs short of the chip: beside it the
+# many workgroups that walk the tiles (zs3_conv_halo_set_wgs).  A launch handed out in one go and 64 CUs short of the chip: beside it the
 # update chain's launches start as if the chip were idle (tools/probe/queue_gate.py: 6.5 us per launch against 47 beside the one-tile-
-# per-workgroup launch, 4.8 alone; the convolution itself 960 against 967 us).  0 = one workgroup per tile.
-FEATURE_HALO_WGS = 224
+# per-workgroup launch, 4.8 alone; the convolution itself ~6 % longer at 224 workgroups, ~13 % at 192).  GMMN step, same box x3: 24.18 /
+# 24.31 / 24.24 ms one workgroup per tile, 22.95 / 22.64 / 22.85 at 224, 22.47 / 22.27 / 22.63 at 192.  The same treatment of the
+# register-staged kernel (tile loop, grids sized for 224 CUs) bought nothing (23.5 against 23.1-23.5) and was not kept.  0 = one per tile.
+FEATURE_HALO_WGS = 192
 FEATURE_PLAN = os.environ.get("ZS3_PLAN", "1") == "1"   # the frozen-backbone feature pass replayed from a recorded plan (plan.ForwardPlan)
 
 
