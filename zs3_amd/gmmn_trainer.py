@@ -68,12 +68,14 @@ FEATURE_LANES = False
 # 0.2 ms of that; 128: 25.2-25.4).  The supervised step keeps 256 (192 there: 42.00 / 42.03 against 42.18 / 42.04, noise).  0 = leave alone.
 FEATURE_PW_WGS = 192
 # ... and its strip-resident launches with more tiles than this (the decoder's 3x3 layers at 129^2: 2774 tiles, layer 2's at 65^2) on this
-# many workgroups that walk the tiles (zs3_conv_halo_set_wgs).  A launch handed out in one go and 64 CUs short of the chip: beside it the
+# many workgroups that walk the tiles (zs3_conv_halo_set_wgs).  A launch handed out in one go on half the chip: beside it the
 # update chain's launches start as if the chip were idle (tools/probe/queue_gate.py: 6.5 us per launch against 47 beside the one-tile-
 # per-workgroup launch, 4.8 alone; the convolution itself ~6 % longer at 224 workgroups, ~13 % at 192).  GMMN step, same box x3: 24.18 /
-# 24.31 / 24.24 ms one workgroup per tile, 22.95 / 22.64 / 22.85 at 224, 22.47 / 22.27 / 22.63 at 192.  The same treatment of the
+# 24.31 / 24.24 ms one workgroup per tile, 22.95 / 22.64 / 22.85 at 224, 22.47 / 22.27 / 22.63 at 192; another box: 22.48 / 22.73 at 192,
+# 21.89 / 22.01 / 22.18 / 21.86 at 160, 21.67 / 21.52 at 144, **21.56 / 21.53 at 128**, 21.86 / 21.89 at 96 (the pass is not the step's critical
+# path, the loop is: the decoder's launches may take half the chip).  The same treatment of the
 # register-staged kernel (tile loop, grids sized for 224 CUs) bought nothing (23.5 against 23.1-23.5) and was not kept.  0 = one per tile.
-FEATURE_HALO_WGS = 192
+FEATURE_HALO_WGS = 128
 FEATURE_PLAN = os.environ.get("ZS3_PLAN", "1") == "1"   # the frozen-backbone feature pass replayed from a recorded plan (plan.ForwardPlan)
 
 
@@ -482,8 +484,10 @@ class GMMNStep:
         took as long as the pass runs on the GPU (14-15 ms: the next batch's pass could not start overlapping the generator loop
         until the host was done with it) replayed with one C call."""
         # (the persistent pointwise kernel's launches size themselves when they are enqueued -- recorded or replayed -- from this setting)
-        prev = lib().zs3_conv_pw_set_wgs(FEATURE_PW_WGS) if FEATURE_PW_WGS else 0
-        prev_halo = lib().zs3_conv_halo_set_wgs(FEATURE_HALO_WGS) if FEATURE_HALO_WGS else None
+        # -- only for a pass that runs BESIDE a generator loop (prefetch): alone on the chip it takes all of it
+        beside = bool(self.__dict__.get("_prefetching"))
+        prev = lib().zs3_conv_pw_set_wgs(FEATURE_PW_WGS) if FEATURE_PW_WGS and beside else 0
+        prev_halo = lib().zs3_conv_halo_set_wgs(FEATURE_HALO_WGS) if FEATURE_HALO_WGS and beside else None
         try:
             with torch.no_grad():
                 if not FEATURE_PLAN:
@@ -514,7 +518,11 @@ class GMMNStep:
         self._feat_stream.wait_stream(torch.cuda.current_stream(dev))    # the image (and the previous feature pass) are ready
         with torch.cuda.stream(self._feat_stream):
             _tick("feat-begin", self._feat_stream)
-            real = self._features(image)
+            self.__dict__["_prefetching"] = True
+            try:
+                real = self._features(image)
+            finally:
+                self.__dict__["_prefetching"] = False
             _tick("feat-end", self._feat_stream)
             done = torch.cuda.Event()
             done.record()
