@@ -1173,3 +1173,43 @@ def test_weight_shared_by_two_layers_accumulates_both_weight_gradients(dev):
         got = wg.grad.clone()
         torch.cuda.synchronize()
         assert torch.equal(got, want) or rel(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3+in_affine", "bf16-stored"])
+def test_strip_kernel_on_a_capped_grid_is_bit_identical(dev, mode):
+    """zs3_conv_halo_set_wgs: launches of the strip-resident kernel with more tiles than the cap run on that many workgroups walking
+    the tiles (csrc/conv_halo.hip, PERSIST instantiations: 192-row forward tiles) -- same output and BatchNorm sums, bit for bit, as
+    one workgroup per tile; a launch the form does not exist for (the 256-row tile, a data gradient) ignores the cap."""
+    from zs3_amd import ops
+    from zs3_amd._lib import lib
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(2, 65, 65, 128, device=dev, generator=g)
+    wt = torch.randn(128, 128, 3, 3, device=dev, generator=g) * 0.05
+    sc, sh = torch.rand(128, device=dev, generator=g) + 0.5, torch.randn(128, device=dev, generator=g) * 0.1
+    dy = torch.randn(2, 65, 65, 128, device=dev, generator=g)
+
+    def run():
+        if mode == "bf16-stored":
+            ops.set_storage(torch.bfloat16)
+            try:
+                wp = ops.prep_weight(wt)
+                return ops.conv2d_fwd(x.to(torch.bfloat16), wp, 1, 2, 2, tile_cfg=42, want_stats=True, prec=1) + (None,)
+            finally:
+                ops.set_storage(torch.float32)
+        wp = ops.prep_weight(wt, f16_forward=True)
+        aff = (sc, sh) if mode.endswith("in_affine") else None
+        y, st = ops.conv2d_fwd(x, wp, 1, 2, 2, tile_cfg=42, want_stats=True, prec=4, in_affine=aff)
+        y256, _ = ops.conv2d_fwd(x, wp, 1, 2, 2, tile_cfg=41, want_stats=True, prec=4, in_affine=aff)
+        return y, st, (y256, ops.conv2d_dgrad(dy, ops.prep_weight(wt), (65, 65), 1, 2, 2, tile_cfg=42))
+
+    ref = run()
+    prev = lib().zs3_conv_halo_set_wgs(8)       # 45 row tiles of 192 rows on 8 workgroups: five or six tiles each
+    try:
+        out = run()
+    finally:
+        lib().zs3_conv_halo_set_wgs(prev)
+    torch.cuda.synchronize()
+    assert prev == 0
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    if ref[2] is not None:
+        assert torch.equal(out[2][0], ref[2][0]) and torch.equal(out[2][1], ref[2][1])
