@@ -51,6 +51,12 @@ class GCNContextStep(GMMNStep):
         self.last_generator_GCN_loss = 0.0
         self.last_num_clusters = 0
 
+    def _feature_shaping(self):
+        # This step's loop is cut after every image (the graph update reads the generator) and carries the cluster work: the prefetched
+        # feature pass is its critical path, not the loop -- every cap on the pass costs (same box, tools/probe/r6c.sh: lanes on and no
+        # caps 36.90 / 36.75 ms per step; ASPP in sequence 37.27 / 37.15; strip launches on 224 workgroups 37.59 / 37.51, on 128: 40.95).
+        return True, 0, 0
+
     def _replica_parameters(self):
         return list(self.generator.parameters()) + list(self.generator_GCN.parameters())
 

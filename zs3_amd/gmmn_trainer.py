@@ -468,11 +468,17 @@ class GMMNStep:
         return [self.generator]
 
     # ------------------------------------------------------------------ frozen-backbone feature pass, pipelined
+    def _feature_shaping(self):
+        """(ASPP lanes, persistent pointwise workgroups, strip-kernel workgroups) of this step's frozen feature pass: how much of the chip
+        a pass that runs beside the generator loop leaves to it.  Tuned for THIS step's balance (the loop is its critical path);
+        subclasses with another balance override it (GCNContextStep: the pass is the critical path there)."""
+        return FEATURE_LANES, FEATURE_PW_WGS, FEATURE_HALO_WGS
+
     def _features_eager(self, image):
         # [B, fh, fw, D]; in the 2-byte mode the backbone hands over bf16 features: the generator loop, the MMD kernels and the
         # cluster graphs work on fp32 rows (273 MB at B = 16: one cast pass, ~0.1 ms)
         lanes = Fz.ASPP_CONCURRENT
-        if not FEATURE_LANES:
+        if not self._feature_shaping()[0]:
             Fz.ASPP_CONCURRENT = False
         try:
             return ops.cast(ops.nhwc(self.model.forward_before_class_prediction(image)), torch.float32)
@@ -486,8 +492,9 @@ class GMMNStep:
         # (the persistent pointwise kernel's launches size themselves when they are enqueued -- recorded or replayed -- from this setting)
         # -- only for a pass that runs BESIDE a generator loop (prefetch): alone on the chip it takes all of it
         beside = bool(self.__dict__.get("_prefetching"))
-        prev = lib().zs3_conv_pw_set_wgs(FEATURE_PW_WGS) if FEATURE_PW_WGS and beside else 0
-        prev_halo = lib().zs3_conv_halo_set_wgs(FEATURE_HALO_WGS) if FEATURE_HALO_WGS and beside else None
+        _, pw_wgs, halo_wgs = self._feature_shaping()
+        prev = lib().zs3_conv_pw_set_wgs(pw_wgs) if pw_wgs and beside else 0
+        prev_halo = lib().zs3_conv_halo_set_wgs(halo_wgs) if halo_wgs and beside else None
         try:
             with torch.no_grad():
                 if not FEATURE_PLAN:
