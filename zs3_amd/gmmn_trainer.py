@@ -76,6 +76,14 @@ FEATURE_PW_WGS = 192
 # path, the loop is: the decoder's launches may take half the chip).  The same treatment of the
 # register-staged kernel (tile loop, grids sized for 224 CUs) bought nothing (23.5 against 23.1-23.5) and was not kept.  0 = one per tile.
 FEATURE_HALO_WGS = 128
+# The caps above are where the bench's configuration balances (225 updates per step beside one pass: the pass and the loop end together).
+# Another class count, crop or batch shifts the balance -- with a short loop the capped pass would be the critical path (the GCN-context
+# step: +4 ms) -- so a GMMNStep steers between these (pointwise, strip) settings, one notch per step at most, by what the previous step's
+# events say: the pass ended more than FEATURE_SLACK_MS after loop + classifier -> a notch towards the whole chip, the loop ended later
+# than the pass -> a notch towards the caps above.  Results do not depend on the notch (the capped launches are bit-identical).
+FEATURE_NOTCHES = ((0, 0), (224, 224), (192, 192), (192, 160), (FEATURE_PW_WGS, FEATURE_HALO_WGS))
+FEATURE_ADAPT = True
+FEATURE_SLACK_MS = 0.4
 FEATURE_PLAN = os.environ.get("ZS3_PLAN", "1") == "1"   # the frozen-backbone feature pass replayed from a recorded plan (plan.ForwardPlan)
 
 
@@ -472,7 +480,27 @@ class GMMNStep:
         """(ASPP lanes, persistent pointwise workgroups, strip-kernel workgroups) of this step's frozen feature pass: how much of the chip
         a pass that runs beside the generator loop leaves to it.  Tuned for THIS step's balance (the loop is its critical path);
         subclasses with another balance override it (GCNContextStep: the pass is the critical path there)."""
-        return FEATURE_LANES, FEATURE_PW_WGS, FEATURE_HALO_WGS
+        if not FEATURE_ADAPT:
+            return FEATURE_LANES, FEATURE_PW_WGS, FEATURE_HALO_WGS
+        pw, halo = FEATURE_NOTCHES[self.__dict__.setdefault("_feature_notch", len(FEATURE_NOTCHES) - 1)]
+        return FEATURE_LANES, pw, halo
+
+    def _steer_feature_shaping(self, loop_end, step_end):
+        """one notch per step from the events of the step that just ended: `loop_end` / `step_end` on the main stream (behind the
+        generator loop / behind the classifier update), the prefetched pass's completion event on the feature stream"""
+        pf = self._prefetched
+        if not FEATURE_ADAPT or pf is None or len(pf) < 4 or type(self)._feature_shaping is not GMMNStep._feature_shaping:
+            return
+        notch = self.__dict__.setdefault("_feature_notch", len(FEATURE_NOTCHES) - 1)
+        done = pf[3]
+        if not done.query():                                   # the pass is still running behind the step's last launch: it is the critical path
+            notch -= 1
+        else:
+            if step_end.elapsed_time(done) > FEATURE_SLACK_MS:   # (the read-back that follows waited for the main stream only)
+                notch -= 1
+            elif loop_end.elapsed_time(done) < -FEATURE_SLACK_MS:  # the pass ended before the loop did: the loop is the critical path
+                notch += 1
+        self.__dict__["_feature_notch"] = min(max(notch, 0), len(FEATURE_NOTCHES) - 1)
 
     def _features_eager(self, image):
         # [B, fh, fw, D]; in the 2-byte mode the backbone hands over bf16 features: the generator loop, the MMD kernels and the
@@ -533,7 +561,9 @@ class GMMNStep:
             _tick("feat-end", self._feat_stream)
             done = torch.cuda.Event()
             done.record()
-        self._prefetched = (image, real, done)
+            timed = torch.cuda.Event(enable_timing=True)      # (for _steer_feature_shaping; the wait below uses `done`)
+            timed.record()
+        self._prefetched = (image, real, done, timed)
 
     def _take_features(self, image):
         pf, self._prefetched = self._prefetched, None
@@ -768,6 +798,10 @@ class GMMNStep:
                 pending = 0
             self._after_image(i, tgt_l[i].view(fh, fw), real_rows[i], has_unseen)
         self._join_side_work()       # (subclasses: per-image work that was queued on another stream)
+        loop_end = None
+        if FEATURE_ADAPT and self._prefetched is not None:
+            loop_end = torch.cuda.Event(enable_timing=True)
+            loop_end.record()
         _tick("loop")
         pg = None if self.group is True else self.group
         if self.group is not None:   # generator replicas -> their average (parameters only; Adam moments stay per rank)
@@ -801,8 +835,14 @@ class GMMNStep:
         tail = [closs.detach().reshape(1)]
         if ops._range_flags:
             tail.append(ops.range_flag(dev).float())
+        step_end = None
+        if loop_end is not None:
+            step_end = torch.cuda.Event(enable_timing=True)
+            step_end.record()
         vals = torch.cat((mmd_losses, *tail)).cpu()
         _tick("readback")
+        if step_end is not None:
+            self._steer_feature_shaping(loop_end, step_end)
         if len(tail) == 2:
             if float(vals[-1]) != 0.0:
                 Fz.check_forward_range(flag_value=1)     # lowers the flag, warns, bf16x3 forward products from here on
