@@ -540,6 +540,9 @@ int launch_halo_n(const ConvArgs& a, const HaloGeom& g, hipStream_t st) {
   gg.ntiles = ((a.M + BM - 1) / BM) * ((a.ncols + 127) / 128);
   // the tile-walking form exists for the 192-row forward instantiations (f16x3 and plain bf16): what a frozen feature pass launches
   if constexpr (BM == 192 && (PREC == 4 || PREC == 1)) {
+    // (every launch with more tiles than the cap, also the 182-tile layer-3 launches that are handed out in one go as they are: walking
+    // their tiles on 128 workgroups makes them 70 % longer, 140 against 82 us, and the GMMN step 0.6 ms shorter -- the CUs they leave are
+    // what the loop, the step's critical path, runs on; capping only the many-round launches: 21.8-21.9 against 21.2-21.4 ms)
     if (g_halo_wgs > 0 && gg.ntiles > g_halo_wgs && !a.dgrad) {
       static bool configured_p = false;
       if (!configured_p) {
